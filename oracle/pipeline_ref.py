@@ -1,0 +1,75 @@
+"""Oracle (test infrastructure): the denoising loop of EMOAnimationPipeline.__call__
+(EMOAnimationPipeline.py:698-823), restated over the oracle UNet.  fp32 CPU.
+
+Loop arithmetic pinned by tests/golden/loop_tiny.safetensors (a generator-side re-enactment of
+the reference loop body around the reference's own UNet); the scheduler is parity-unpinned
+(see scheduler_ref.py).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .scheduler_ref import SchedulerRef, counter_normal, uniform_windows
+from .unet_ref import round_banks_fp16, unet_forward
+
+
+def denoise_loop(unet_sd, unet_cfg, ref_sd, ref_cfg, latents, ref_latents, text_embeddings, *,
+                 scheduler: SchedulerRef, num_inference_steps=50, guidance_scale=7.5,
+                 context_frames=16, context_stride=1, context_overlap=4, context_batch_size=1,
+                 fusion_blocks="midup", seed=0, audio_features=None, speed_embeddings=None,
+                 rank=0, world_size=1, return_eps=False):
+    """latents (1,4,F_tot,h,w); ref_latents (1,4,h,w); text_embeddings (2,L,D) = [uncond, cond].
+
+    Per step (EMOAnimationPipeline.py:698-823):
+      ReferenceNet write pass on ref_latents.repeat(2*cbs) at the current t      (:711-716)
+      windows = uniform(0, steps, F_tot, context_frames, stride, overlap)       (:748-755)
+      per window batch: x = cat(latents[:,:,c]).repeat(2); reader.update (fp16 banks); UNet;
+                        noise_pred[:,:,c] += pred; counter[:,:,c] += 1            (:759-794)
+      eps = uc + s*(c - uc) on noise_pred/counter                                (:812-814)
+      latents = scheduler.step(eps, t, latents)                                  (:817)
+    rank/world_size shard windows exactly as `global_context[rank::world_size]` (:757); with
+    world_size>1 this function processes ALL ranks' windows in rank order (it is an oracle)."""
+    timesteps = scheduler.set_timesteps(num_inference_steps)
+    cbs = context_batch_size
+    text = torch.cat([text_embeddings] * cbs) if cbs > 1 else text_embeddings  # (:631) [uc.., c..] per cat
+    f_tot = latents.shape[2]
+    eps_trace = []
+    for si, t in enumerate(timesteps):
+        noise_pred = torch.zeros(2, *latents.shape[1:])
+        counter = torch.zeros(1, 1, f_tot, 1, 1)
+        ref_in = ref_latents.repeat(2 * cbs, 1, 1, 1).unsqueeze(2)  # F=1 instance
+        _, written = unet_forward(ref_sd, ref_cfg, ref_in, t, text, bank_mode="write", fusion_blocks=fusion_blocks)
+        banks = round_banks_fp16(written)
+        windows = uniform_windows(0, num_inference_steps, f_tot, context_frames, context_stride, context_overlap)
+        nb = math.ceil(len(windows) / cbs)
+        batches = [windows[i * cbs:(i + 1) * cbs] for i in range(nb)]
+        for r in range(world_size):
+            for context in batches[r::world_size]:
+                x = torch.cat([latents[:, :, c] for c in context]).repeat(2, 1, 1, 1, 1)
+                x = scheduler.scale_model_input(x, t)
+                b, _, f, _, _ = x.shape
+                uc_rows = torch.zeros(b * f, dtype=torch.bool)
+                uc_rows[: (b // 2) * f] = True
+                af = None
+                if audio_features is not None:  # (F_tot, L_a, D) per-frame ctx; uc rows get zeros
+                    cond = torch.cat([audio_features[c] for c in context])
+                    af = torch.cat([torch.zeros_like(cond), cond])
+                pred = unet_forward(unet_sd, unet_cfg, x, t, text[:b], bank_mode="read", banks=banks,
+                                    uc_rows=uc_rows, fusion_blocks=fusion_blocks, audio_features=af,
+                                    speed_embeddings=speed_embeddings)
+                pred_uc, pred_c = pred.chunk(2)
+                pred = torch.stack([pred_uc, pred_c])
+                for j, c in enumerate(context):
+                    noise_pred[:, :, c] = noise_pred[:, :, c] + pred[:, j]
+                    counter[:, :, c] = counter[:, :, c] + 1
+        uc, cc = (noise_pred / counter).chunk(2)
+        eps = uc + guidance_scale * (cc - uc)
+        if return_eps:
+            eps_trace.append(eps.clone())
+        z = None
+        if scheduler.kind == "ddpm" or scheduler.eta > 0:
+            z = counter_normal(seed, si, latents.numel()).reshape(latents.shape)
+        latents = scheduler.step(eps, t, latents, noise=z)
+    return (latents, eps_trace) if return_eps else latents

@@ -1,0 +1,298 @@
+"""Pin the oracle (oracle/*) against golden vectors captured from the reference's own code
+(tools/oracle/gen_golden.py).  CPU only.  Tolerance: rtol 1e-3 / atol 1e-4 (north_star) - the
+oracle actually matches to ~1e-6; integer paths are bit-exact."""
+import json
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from emote_hack_amd.synth import seeded_randn, synth_state_dict
+from oracle import conditioning_ref as C
+from oracle import scheduler_ref as S
+from oracle import unet_ref as U
+from oracle.pipeline_ref import denoise_loop
+from tests import cases
+
+G = cases.GOLDEN_DIR
+RTOL, ATOL = 1e-3, 1e-4
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol)
+
+
+@pytest.fixture(scope="module")
+def ints():
+    return json.load(open(os.path.join(G, "ints.json")))
+
+
+@pytest.fixture(scope="module")
+def mods():
+    return load_file(os.path.join(G, "modules.safetensors"))
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    return load_file(os.path.join(G, "unet_tiny.safetensors"))
+
+
+def sd_for(shapes, prefix):
+    return synth_state_dict(shapes, prefix=prefix)
+
+
+# ------------------------------------------------------------------ INT, bit-exact
+def test_windows_bit_exact(ints):
+    for c in ints["windows"]:
+        f, ctx, stride, ov = c["args"]
+        assert S.uniform_windows(0, 50, f, ctx, stride, ov) == c["windows"]
+    for c in ints["windows_step"]:
+        f, ctx, stride, ov = c["args"]
+        assert S.uniform_windows(c["step"], 50, f, ctx, stride, ov) == c["windows"]
+
+
+def test_speed_buckets_bit_exact(ints):
+    sp = torch.tensor(ints["speed_buckets"]["speeds"])
+    assert C.speed_bucket_index(sp).tolist() == ints["speed_buckets"]["buckets"]
+    # survey probe goldens
+    assert C.speed_bucket_index(torch.tensor([-1, -0.13, 0, 0.07, 0.49, 2.0])).tolist() == [0, 3, 4, 4, 6, 8]
+
+
+def test_timestep_tables():
+    assert S.timestep_table(50, 1000, 0) == list(range(980, -1, -20))
+    assert S.timestep_table(50, 1000, 1) == list(range(981, 0, -20))
+
+
+def test_bank_order(ints):
+    strip = lambda names: [n.replace(".transformer_blocks.0", "") for n in names]
+    assert U.transformer_block_order(cases.TINY_MOTION, "midup") == strip(ints["bank_order_tiny_midup"])
+    assert U.transformer_block_order(cases.TINY_MOTION, "full") == strip(ints["bank_order_tiny_full"])
+    assert U.transformer_block_order(cases.SD15_MOTION, "midup") == strip(ints["bank_order_sd15_midup"])
+
+
+# ------------------------------------------------------------------ modules
+def test_timestep_embedding(mods):
+    ts = torch.tensor([981, 1, 500, 0, 999])
+    e = U.timestep_embedding(ts, 320, True, 0)
+    close(e, mods["temb/sinusoid320"], 1e-5, 1e-6)
+    # survey probe golden
+    assert torch.allclose(e[0, :3], torch.tensor([0.67996, -0.79843, 0.57806]), atol=1e-4)
+    assert torch.allclose(e[0, 160:163], torch.tensor([0.73325, 0.60209, 0.81599]), atol=1e-4)
+    close(U.timestep_embedding(ts, 32, False, 1), mods["temb/sinusoid32_noflip_shift1"], 1e-5, 1e-6)
+    sd = sd_for({"linear_1.weight": (128, 32), "linear_1.bias": (128,), "linear_2.weight": (128, 128),
+                 "linear_2.bias": (128,)}, "time_embedding.")
+    t = U.timestep_embedding(ts, 32, True, 0)
+    out = U._lin(sd, "linear_2", torch.nn.functional.silu(U._lin(sd, "linear_1", t)))
+    close(out, mods["temb/mlp_out"])
+
+
+def resnet_shapes(cin, cout, temb=128):
+    d = {"norm1.weight": (cin,), "norm1.bias": (cin,), "conv1.weight": (cout, cin, 3, 3), "conv1.bias": (cout,),
+         "time_emb_proj.weight": (cout, temb), "time_emb_proj.bias": (cout,), "norm2.weight": (cout,),
+         "norm2.bias": (cout,), "conv2.weight": (cout, cout, 3, 3), "conv2.bias": (cout,)}
+    if cin != cout:
+        d.update({"conv_shortcut.weight": (cout, cin, 1, 1), "conv_shortcut.bias": (cout,)})
+    return d
+
+
+@pytest.mark.parametrize("name,cin,cout", [("resnet_sc", 32, 64), ("resnet_id", 64, 64)])
+def test_resnet(mods, name, cin, cout):
+    sd = {"r." + k: v for k, v in sd_for(resnet_shapes(cin, cout), name + ".").items()}
+    x, emb = seeded_randn((2, cin, 4, 8, 8), 11), seeded_randn((2, 128), 12)
+    close(U.resnet_block(sd, "r", x, emb, 8, 1e-5), mods[f"{name}/out"])
+
+
+def test_samplers(mods):
+    sd = {"d." + k: v for k, v in sd_for({"conv.weight": (64, 64, 3, 3), "conv.bias": (64,)}, "down.").items()}
+    close(U._conv_per_frame(sd, "d.conv", seeded_randn((1, 64, 3, 8, 8), 13), stride=2, padding=1), mods["down/out"])
+    sd = {"u." + k: v for k, v in sd_for({"conv.weight": (64, 64, 3, 3), "conv.bias": (64,)}, "up.").items()}
+    close(U.upsample(sd, "u", seeded_randn((1, 64, 3, 4, 4), 14)), mods["up/out"])
+
+
+def attn_shapes(c, kv):
+    return {"to_q.weight": (c, c), "to_k.weight": (c, kv), "to_v.weight": (c, kv), "to_out.0.weight": (c, c),
+            "to_out.0.bias": (c,)}
+
+
+@pytest.mark.parametrize("d", [40, 80, 160])
+def test_attention_real_head_dims(mods, d):
+    c = 8 * d
+    sd = {"a." + k: v for k, v in sd_for(attn_shapes(c, c), f"attn{d}.").items()}
+    x = seeded_randn((1, 64, c), 20 + d)
+    close(U.attention(sd, "a", x, None, 8), mods[f"attn{d}/self_out"])
+    sd = {"a." + k: v for k, v in sd_for(attn_shapes(c, 768), f"xattn{d}.").items()}
+    close(U.attention(sd, "a", x, seeded_randn((1, 7, 768), 21 + d), 8), mods[f"attn{d}/cross_out"])
+
+
+def test_feed_forward(mods):
+    sd = {"f." + k: v for k, v in sd_for({"net.0.proj.weight": (512, 64), "net.0.proj.bias": (512,),
+                                          "net.2.weight": (64, 256), "net.2.bias": (64,)}, "ff.").items()}
+    close(U.feed_forward(sd, "f", seeded_randn((2, 16, 64), 30)), mods["ff/out"])
+
+
+def tf_shapes(c, ctx, lin):
+    from emote_hack_amd.spec import TransformerSpec, _transformer_shapes
+    d = {}
+    _transformer_shapes(TransformerSpec("t", c, 4, ctx, lin), d)
+    return {k[2:]: v for k, v in d.items()}
+
+
+@pytest.mark.parametrize("name,lin", [("tf3d", False), ("tf3d_lin", True)])
+def test_transformer3d(mods, name, lin):
+    sd = {"t." + k: v for k, v in sd_for(tf_shapes(64, 32, lin), name + ".").items()}
+    x = seeded_randn((2, 64, 3, 4, 4), 40)
+    close(U.transformer3d(sd, "t", x, seeded_randn((2, 5, 32), 41), 4, 8, lin), mods[f"{name}/out"])
+    close(U.transformer3d(sd, "t", x, seeded_randn((6, 5, 32), 42), 4, 8, lin), mods[f"{name}/out_perframe_ctx"])
+
+
+def motion_shapes(c, heads, pe=24):
+    from emote_hack_amd.spec import MotionSpec, _motion_shapes
+    d = {}
+    _motion_shapes(MotionSpec("m", c, heads, 2, pe), d)
+    return {k[2:]: v for k, v in d.items()}
+
+
+def test_motion_module(mods):
+    sd = {"m." + k: v for k, v in sd_for(motion_shapes(64, 4), "motion.").items()}
+    close(U.motion_module(sd, "m", seeded_randn((2, 64, 4, 4, 4), 50), 4), mods["motion/out"])
+    sd = {"m." + k: v for k, v in sd_for(motion_shapes(320, 8), "motion320.").items()}
+    close(U.motion_module(sd, "m", seeded_randn((1, 320, 12, 4, 4), 51), 8), mods["motion320/out"])
+
+
+# ------------------------------------------------------------------ tiny UNet end to end
+def tiny_sd(cfg, prefix="", has_out=True):
+    from emote_hack_amd.spec import build_spec, param_shapes
+    return synth_state_dict(param_shapes(build_spec(cfg, has_out=has_out)), prefix=prefix)
+
+
+def test_unet_tiny_plain_motion_linear(tiny):
+    x, ctx = cases.tiny_inputs(2, 4)
+    close(U.unet_forward(tiny_sd(cases.TINY), cases.TINY, x[:, :, :2], 981, ctx), tiny["plain/out"])
+    sd = tiny_sd(cases.TINY_MOTION)
+    close(U.unet_forward(sd, cases.TINY_MOTION, x, torch.tensor(961), ctx), tiny["motion/out"])
+    close(U.unet_forward(tiny_sd(cases.TINY_LINEAR), cases.TINY_LINEAR, x, 500, ctx), tiny["linear/out"])
+
+
+def ctrl_residuals():
+    res_shapes = [(2, 32, 4, 16, 16)] * 3 + [(2, 32, 4, 8, 8)] + [(2, 64, 4, 8, 8)] * 2 + [(2, 64, 4, 4, 4)] * 3 + \
+                 [(2, 64, 4, 2, 2)] * 3
+    return tuple(0.1 * seeded_randn(s, 100 + i) for i, s in enumerate(res_shapes)), 0.1 * seeded_randn((2, 64, 4, 2, 2), 99)
+
+
+def test_unet_tiny_controlnet_residuals(tiny):
+    x, ctx = cases.tiny_inputs(2, 4)
+    down_res, mid_res = ctrl_residuals()
+    y = U.unet_forward(tiny_sd(cases.TINY_MOTION), cases.TINY_MOTION, x, 961, ctx,
+                       down_block_additional_residuals=down_res, mid_block_additional_residual=mid_res)
+    close(y, tiny["motion/out_ctrl"])
+
+
+def test_reference_write_read(tiny):
+    x, ctx = cases.tiny_inputs(2, 4)
+    ref_sd = tiny_sd(cases.TINY, cases.REF_PREFIX)
+    ref_lat = seeded_randn((1, 4, 16, 16), 3).repeat(2, 1, 1, 1).unsqueeze(2)
+    _, written = U.unet_forward(ref_sd, cases.TINY, ref_lat, 961, ctx, bank_mode="write")
+    order = U.transformer_block_order(cases.TINY, "midup")
+    assert len(order) == 10
+    for i, p in enumerate(order):
+        close(written[p], tiny[f"banks/{i}"])
+    banks = U.round_banks_fp16(written)
+    y = U.unet_forward(tiny_sd(cases.TINY_MOTION), cases.TINY_MOTION, x, 961, ctx, bank_mode="read", banks=banks,
+                       uc_rows=cases.uc_rows(2, 4))
+    close(y, tiny["read/out"])
+    # uc rows must equal a run without banks (SURVEY 3.3 probe)
+    close(y[:1], tiny["motion/out"][:1], 1e-4, 1e-5)
+    assert (y[1] - tiny["motion/out"][1]).abs().max() > 1e-2
+
+
+@pytest.mark.parametrize("kind", ["ddim", "ddpm"])
+def test_denoise_loop(kind):
+    g = load_file(os.path.join(G, "loop_tiny.safetensors"))
+    lat, eps = denoise_loop(tiny_sd(cases.TINY_MOTION), cases.TINY_MOTION, tiny_sd(cases.TINY, cases.REF_PREFIX),
+                            cases.TINY, seeded_randn((1, 4, 8, 16, 16), 5), seeded_randn((1, 4, 16, 16), 3),
+                            seeded_randn((2, 5, 32), 2), scheduler=S.SchedulerRef(kind), num_inference_steps=3,
+                            guidance_scale=7.5, context_frames=4, context_stride=1, context_overlap=2, seed=0,
+                            return_eps=True)
+    for i in range(3):
+        close(eps[i], g[f"{kind}/eps{i}"], 2e-3, 2e-4)  # CFG x7.5 amplifies rounding
+    close(lat, g[f"{kind}/latents"], 2e-3, 2e-4)
+
+
+# ------------------------------------------------------------------ scheduler self-consistency (parity unpinned)
+@pytest.mark.parametrize("kind", ["ddim", "ddpm"])
+def test_scheduler_coefficients_match_step(kind):
+    sch = S.SchedulerRef(kind)
+    ts = sch.set_timesteps(50)
+    x, eps, z = seeded_randn((1, 4, 2, 8, 8), 1), seeded_randn((1, 4, 2, 8, 8), 2), seeded_randn((1, 4, 2, 8, 8), 3)
+    for t in (ts[0], ts[10], ts[-2], ts[-1]):
+        cx, ce, cn = sch.coefficients(t)
+        close(cx * x + ce * eps + cn * z, sch.step(eps, t, x, noise=z), 1e-5, 1e-5)
+
+
+def test_ddim_x0_identity():
+    """EMOAnimationPipeline.py:397-399: pred_x0 = (x - sqrt(1-a) eps)/sqrt(a); a DDIM step with the
+    TRUE eps walks x_t = sqrt(a)x0 + sqrt(1-a)eps to the same x0 at the previous alpha."""
+    sch = S.SchedulerRef("ddim")
+    ts = sch.set_timesteps(50)
+    x0, eps = seeded_randn((1, 4, 1, 8, 8), 1), seeded_randn((1, 4, 1, 8, 8), 2)
+    t = ts[5]
+    a, ap = sch.alphas_cumprod[t], sch.alphas_cumprod[t - 20]
+    xt = a.sqrt() * x0 + (1 - a).sqrt() * eps
+    close(sch.step(eps, t, xt), ap.sqrt() * x0 + (1 - ap).sqrt() * eps, 1e-4, 1e-5)
+
+
+def test_counter_normal_stats():
+    z = S.counter_normal(0, 3, 1 << 16)
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1) < 0.02
+    assert torch.equal(z, S.counter_normal(0, 3, 1 << 16))
+    assert not torch.equal(z, S.counter_normal(0, 4, 1 << 16))
+
+
+# ------------------------------------------------------------------ conditioning (A17/A18)
+def test_conditioning():
+    g = load_file(os.path.join(G, "conditioning.safetensors"))
+    sp = torch.tensor(cases.SPEEDS, dtype=torch.float32)
+    close(C.speed_encoder_encode(sp), g["speed_encoder/encode"], 1e-5, 1e-6)
+    # survey probe golden
+    assert torch.allclose(C.speed_encoder_encode(torch.tensor([-0.13]))[0],
+                          torch.tensor([1, 1, 0.9705, -0.7163, -0.9992, -1, -1, -1, -1.0]), atol=1e-4)
+    sd = sd_for({"mlp.0.weight": (64, 9), "mlp.0.bias": (64,), "mlp.2.weight": (64, 64), "mlp.2.bias": (64,)}, "speed_encoder.")
+    close(C.speed_encoder(sd, sp), g["speed_encoder/out"])
+    sd = sd_for({"speed_embedding.weight": (9, 64), "speed_mlp.0.weight": (64, 64),
+                 "speed_mlp.0.bias": (64,), "speed_mlp.2.weight": (64, 64), "speed_mlp.2.bias": (64,)}, "speed_controller.")
+    close(C.speed_controller(sd, sp), g["speed_controller/out"])
+    chans = [1, 64, 128, 256, 32]
+    shp = {}
+    for i, k in enumerate((0, 2, 4, 6)):
+        shp[f"encoder.{k}.weight"] = (chans[i + 1], chans[i], 3, 3)
+        shp[f"encoder.{k}.bias"] = (chans[i + 1],)
+    close(C.face_region_controller(sd_for(shp, "face_region."), seeded_randn((2, 1, 8, 8), 60)), g["face_region/out"])
+    lay = {}
+    for i in range(2):
+        for n in ("query", "key", "value"):
+            lay[f"layers.{i}.{n}.weight"] = (48, 48)
+            lay[f"layers.{i}.{n}.bias"] = (48,)
+    close(C.net_audio_attention_layers(sd_for(lay, "audio_layers."), seeded_randn((2, 6, 48), 61),
+                                       seeded_randn((2, 6, 48), 62), 2), g["audio_layers/out"])
+    one = {f"{n}.{w}": ((48, 48) if w == "weight" else (48,)) for n in ("query", "key", "value") for w in ("weight", "bias")}
+    close(C.net_reference_attention_layer(sd_for(one, "ref_layer."), seeded_randn((2, 6, 48), 63),
+                                          seeded_randn((2, 1, 48), 64)), g["ref_layer/out"])
+    sd = sd_for({"frame_proj.weight": (64, 64), "frame_proj.bias": (64,), "audio_proj.weight": (64, 768),
+                 "audio_proj.bias": (64,), "out_proj.weight": (64, 64), "out_proj.bias": (64,)}, "stage2_audio.")
+    close(C.stage2_audio_attention(sd, seeded_randn((2, 12, 64), 65), seeded_randn((2, 5, 768), 66)), g["stage2_audio/out"])
+    sd = sd_for({"temperature": (8, 1, 1), "qkv.weight": (192, 64), "proj.weight": (64, 64), "proj.bias": (64,)}, "stage2_temporal.")
+    close(C.stage2_temporal_attention(sd, seeded_randn((2, 12, 64), 67)), g["stage2_temporal/out"])
+
+
+# ------------------------------------------------------------------ BASELINE config 1 (860 M params; ~1 min)
+def test_cfg1_unet_config_yaml_shape():
+    path = os.path.join(G, "cfg1.safetensors")
+    if not os.path.exists(path):
+        pytest.skip("cfg1 golden not generated")
+    from emote_hack_amd.spec import build_spec, param_shapes
+    cfg = dict(cases.SD15, norm_num_groups=4)  # configs/unet-config.yaml:default
+    sd = synth_state_dict(param_shapes(build_spec(cfg)))
+    y = U.unet_forward(sd, cfg, seeded_randn((1, 4, 1, 32, 32), 1), 981, seeded_randn((1, 77, 768), 2))
+    close(y, load_file(path)["cfg1/out"])

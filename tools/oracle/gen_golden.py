@@ -1,0 +1,325 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by running the REFERENCE's own in-tree code (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/oracle/gen_golden.py [--skip-cfg1]
+
+Imports /root/reference through the plumbing-only diffusers shim (diffusers_shim.py), loads
+name-keyed synthetic weights (emote_hack_amd/synth.py) into the reference modules, feeds seeded
+inputs (tests/cases.py) and stores ONLY tensors / integers: no reference source, bytecode or
+module travels to the GPU box.  The fixtures pin oracle/ (tests/test_oracle_golden.py) and are the
+end-to-end targets of the HIP path (tests/test_gpu_*.py).
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+import torch  # noqa: E402
+from safetensors.torch import save_file  # noqa: E402
+
+import diffusers_shim as shim  # noqa: E402
+
+shim.install()
+
+from magicanimate.models import attention as ref_attention  # noqa: E402
+from magicanimate.models import embeddings as ref_emb  # noqa: E402
+from magicanimate.models import motion_module as ref_mm  # noqa: E402
+from magicanimate.models import orig_attention as ref_oa  # noqa: E402
+from magicanimate.models import resnet as ref_resnet  # noqa: E402
+from magicanimate.models.mutual_self_attention import ReferenceAttentionControl  # noqa: E402
+from magicanimate.models.unet_controlnet import UNet3DConditionModel  # noqa: E402
+from magicanimate.pipelines.context import uniform as ref_uniform  # noqa: E402
+
+from emote_hack_amd.synth import seeded_randn, synth_state_dict  # noqa: E402
+from tests import cases  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+GOLD = cases.GOLDEN_DIR
+os.makedirs(GOLD, exist_ok=True)
+
+
+def load_synth(module, prefix=""):
+    sd = module.state_dict()
+    params = {k for k, _ in module.named_parameters()}
+    new = synth_state_dict({k: tuple(v.shape) for k, v in sd.items() if k in params}, prefix=prefix)
+    for k, v in sd.items():  # buffers (pos_encoder.pe, SpeedController.centers/radii) keep the module's own value
+        if k not in params:
+            new[k] = v
+    module.load_state_dict(new, strict=True)
+    return module.eval()
+
+
+def key_listing(module):
+    return {k: list(v.shape) for k, v in module.state_dict().items()}
+
+
+def listing_digest(listing):
+    canon = "\n".join(f"{k}:{','.join(map(str, listing[k]))}" for k in sorted(listing))
+    return hashlib.sha256(canon.encode()).hexdigest()
+
+
+def sorted_blocks(unet, fusion="midup"):
+    """BasicTransformerBlocks in the reference's own pairing order (mutual_self_attention.py:532-537)."""
+    from magicanimate.models.stable_diffusion_controlnet_reference import torch_dfs
+    mods = torch_dfs(unet.mid_block) + torch_dfs(unet.up_blocks) if fusion == "midup" else torch_dfs(unet)
+    mods = [m for m in mods if isinstance(m, ref_attention.BasicTransformerBlock)]
+    return sorted(mods, key=lambda x: -x.norm1.normalized_shape[0])
+
+
+def module_names(unet, mods):
+    rev = {id(m): n for n, m in unet.named_modules()}
+    return [rev[id(m)] for m in mods]
+
+
+# =============================================================================== ints
+def gen_ints():
+    out = {}
+    out["windows"] = [dict(args=list(c), windows=[list(map(int, w)) for w in
+                      ref_uniform(0, 50, c[0], c[1], c[2], c[3])]) for c in cases.WINDOW_CASES]
+    out["windows_step"] = [dict(step=s, args=[24, 16, 2, 4], windows=[list(map(int, w)) for w in
+                           ref_uniform(s, 50, 24, 16, 2, 4)]) for s in (1, 2, 3, 7)]
+    # SpeedController buckets (train_stage_3_speedlayers.py) via AST-extracted class
+    S3 = shim.extract_classes("/root/reference/train_stage_3_speedlayers.py", ["SpeedController", "FaceRegionController"])
+    sc = S3["SpeedController"](9, 16)
+    out["speed_buckets"] = dict(speeds=cases.SPEEDS,
+                                buckets=sc.map_speed_to_bucket(torch.tensor(cases.SPEEDS)).tolist())
+    # state-dict key listings
+    tiny = UNet3DConditionModel(**cases.TINY_MOTION)
+    out["tiny_motion_keys"] = key_listing(tiny)
+    tiny_lin = UNet3DConditionModel(**cases.TINY_LINEAR)
+    out["tiny_linear_keys"] = key_listing(tiny_lin)
+    with torch.device("meta"):
+        full = UNet3DConditionModel(**cases.SD15_MOTION)
+        full_mid = UNet3DConditionModel(**dict(cases.SD15_MOTION, motion_module_mid_block=True))
+        full_plain = UNet3DConditionModel(**cases.SD15)
+    for name, m in (("sd15_motion", full), ("sd15_motion_mid", full_mid), ("sd15", full_plain)):
+        lst = key_listing(m)
+        out[name + "_digest"] = dict(n_keys=len(lst), sha256=listing_digest(lst),
+                                     n_params=int(sum(p.numel() for p in m.parameters())))
+    # pairing order of the reference-attention banks
+    out["bank_order_tiny_midup"] = module_names(tiny, sorted_blocks(tiny, "midup"))
+    out["bank_order_tiny_full"] = module_names(tiny, sorted_blocks(tiny, "full"))
+    out["bank_order_sd15_midup"] = module_names(full, sorted_blocks(full, "midup"))
+    json.dump(out, open(os.path.join(GOLD, "ints.json"), "w"), indent=1, sort_keys=True)
+    print("ints.json", {k: (len(v) if hasattr(v, "__len__") else v) for k, v in out.items()})
+
+
+# =============================================================================== modules
+def gen_modules():
+    T = {}
+    # A5 timestep embedding
+    ts = torch.tensor([981, 1, 500, 0, 999])
+    T["temb/sinusoid320"] = ref_emb.Timesteps(320, True, 0)(ts)
+    T["temb/sinusoid32_noflip_shift1"] = ref_emb.Timesteps(32, False, 1)(ts)
+    te = load_synth(ref_emb.TimestepEmbedding(32, 128), "time_embedding.")
+    T["temb/mlp_out"] = te(ref_emb.Timesteps(32, True, 0)(ts))
+    # A7 resnet (with and without shortcut)
+    for name, cin, cout in (("resnet_sc", 32, 64), ("resnet_id", 64, 64)):
+        m = load_synth(ref_resnet.ResnetBlock3D(in_channels=cin, out_channels=cout, temb_channels=128, groups=8,
+                                                eps=1e-5, non_linearity="silu"), name + ".")
+        x, emb = seeded_randn((2, cin, 4, 8, 8), 11), seeded_randn((2, 128), 12)
+        T[f"{name}/out"] = m(x, emb)
+    # A8 samplers
+    m = load_synth(ref_resnet.Downsample3D(64, use_conv=True, padding=1, name="op"), "down.")
+    T["down/out"] = m(seeded_randn((1, 64, 3, 8, 8), 13))
+    m = load_synth(ref_resnet.Upsample3D(64, use_conv=True), "up.")
+    T["up/out"] = m(seeded_randn((1, 64, 3, 4, 4), 14))
+    # A12 attention at the real head dims (8 heads x 40 / 80 / 160), self + cross
+    for d in (40, 80, 160):
+        c = 8 * d
+        m = load_synth(ref_oa.CrossAttention(query_dim=c, heads=8, dim_head=d), f"attn{d}.")
+        T[f"attn{d}/self_out"] = m(seeded_randn((1, 64, c), 20 + d))
+        m = load_synth(ref_oa.CrossAttention(query_dim=c, cross_attention_dim=768, heads=8, dim_head=d), f"xattn{d}.")
+        T[f"attn{d}/cross_out"] = m(seeded_randn((1, 64, c), 20 + d), seeded_randn((1, 7, 768), 21 + d))
+    # A13 feed-forward
+    m = load_synth(ref_oa.FeedForward(64, activation_fn="geglu"), "ff.")
+    T["ff/out"] = m(seeded_randn((2, 16, 64), 30))
+    # A10/A11 Transformer3DModel (conv and linear projection)
+    for name, lin in (("tf3d", False), ("tf3d_lin", True)):
+        m = load_synth(ref_attention.Transformer3DModel(4, 16, in_channels=64, num_layers=1, cross_attention_dim=32,
+                                                        norm_num_groups=8, use_linear_projection=lin,
+                                                        unet_use_cross_frame_attention=False,
+                                                        unet_use_temporal_attention=False), name + ".")
+        T[f"{name}/out"] = m(seeded_randn((2, 64, 3, 4, 4), 40), seeded_randn((2, 5, 32), 41)).sample
+        # per-frame context (B*F rows) passes through un-repeated (attention.py:118-119)
+        T[f"{name}/out_perframe_ctx"] = m(seeded_randn((2, 64, 3, 4, 4), 40), seeded_randn((6, 5, 32), 42)).sample
+    # A16 motion module
+    m = load_synth(ref_mm.VanillaTemporalModule(in_channels=64, **cases.MOTION_KW_TINY), "motion.")
+    T["motion/out"] = m(seeded_randn((2, 64, 4, 4, 4), 50), None, None)
+    m = load_synth(ref_mm.VanillaTemporalModule(in_channels=320, **cases.MOTION_KW_FULL), "motion320.")
+    T["motion320/out"] = m(seeded_randn((1, 320, 12, 4, 4), 51), None, None)
+    save_file({k: v.contiguous() for k, v in T.items()}, os.path.join(GOLD, "modules.safetensors"))
+    print("modules.safetensors", len(T), "tensors", sum(v.numel() for v in T.values()) * 4 / 1e6, "MB")
+
+
+# =============================================================================== tiny UNet end to end
+def run_writer(ref_unet, ref_lat, t, ctx):
+    """ReferenceNet pass = the no-motion 3-D UNet at F=1 in 'write' mode."""
+    ctl = ReferenceAttentionControl(ref_unet, do_classifier_free_guidance=True, mode="write", batch_size=1)
+    ref_unet(ref_lat.unsqueeze(2), t, ctx)
+    blocks = sorted_blocks(ref_unet, "midup")
+    banks = [b.bank[0].clone() for b in blocks]
+    ctl.clear()
+    for b in blocks:  # un-hook
+        b.forward = b._original_inner_forward
+    return banks
+
+
+def run_reader(unet, x, t, ctx, banks, **kw):
+    ctl = ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", batch_size=1)
+    blocks = sorted_blocks(unet, "midup")
+    for b, v in zip(blocks, banks):  # what update() does (mutual_self_attention.py:588)
+        b.bank = [v.clone().to(torch.float16)]
+    y = unet(x, t, ctx, **kw).sample
+    ctl.clear()
+    for b in blocks:
+        b.forward = b._original_inner_forward
+    return y
+
+
+def gen_unet_tiny():
+    T = {}
+    x, ctx = cases.tiny_inputs(2, 4)
+    # (a) no motion module, F=2
+    u0 = load_synth(UNet3DConditionModel(**cases.TINY))
+    T["plain/out"] = u0(x[:, :, :2], 981, ctx).sample
+    # (b) motion modules on, F=4, tensor timestep
+    u1 = load_synth(UNet3DConditionModel(**cases.TINY_MOTION))
+    T["motion/out"] = u1(x, torch.tensor(961), ctx).sample
+    # (b2) linear projection + upcast + per-level heads
+    u2 = load_synth(UNet3DConditionModel(**cases.TINY_LINEAR))
+    T["linear/out"] = u2(x, 500, ctx).sample
+    # (b3) ControlNet-style additive residuals (unet_controlnet.py:430-447)
+    res_shapes = [(2, 32, 4, 16, 16)] * 3 + [(2, 32, 4, 8, 8)] + [(2, 64, 4, 8, 8)] * 2 + [(2, 64, 4, 4, 4)] * 3 + \
+                 [(2, 64, 4, 2, 2)] * 3
+    down_res = tuple(0.1 * seeded_randn(s, 100 + i) for i, s in enumerate(res_shapes))
+    mid_res = 0.1 * seeded_randn((2, 64, 4, 2, 2), 99)
+    T["motion/out_ctrl"] = u1(x, 961, ctx, down_block_additional_residuals=down_res,
+                              mid_block_additional_residual=mid_res).sample
+    # (c) ReferenceNet write -> banks -> Backbone read with CFG batch 2
+    ref = load_synth(UNet3DConditionModel(**cases.TINY), cases.REF_PREFIX)
+    ref_lat = seeded_randn((1, 4, 16, 16), 3).repeat(2, 1, 1, 1)
+    banks = run_writer(ref, ref_lat, 961, ctx)
+    for i, b in enumerate(banks):
+        T[f"banks/{i}"] = b
+    T["read/out"] = run_reader(u1, x, 961, ctx, banks)
+    save_file({k: v.contiguous() for k, v in T.items()}, os.path.join(GOLD, "unet_tiny.safetensors"))
+    print("unet_tiny.safetensors", {k: tuple(v.shape) for k, v in T.items() if not k.startswith("banks")})
+    return u1, ref
+
+
+# =============================================================================== loop re-enactment
+def gen_loop(u1, ref):
+    """Re-enact EMOAnimationPipeline.py:698-823 around the reference's own UNet (the file itself
+    cannot be imported: `animated_diff`, diffusers pipelines).  Scheduler = oracle/scheduler_ref.py
+    (diffusers absent => parity unpinned there)."""
+    import math as _m
+
+    from oracle.scheduler_ref import SchedulerRef
+    T = {}
+    for kind in ("ddim", "ddpm"):
+        sch = SchedulerRef(kind)
+        steps, gs = 3, 7.5
+        timesteps = sch.set_timesteps(steps)
+        f_tot, cf, ov, cbs = 8, 4, 2, 1
+        latents = seeded_randn((1, 4, f_tot, 16, 16), 5)
+        ref_lat = seeded_randn((1, 4, 16, 16), 3)
+        text = seeded_randn((2, 5, 32), 2)
+        from oracle.scheduler_ref import counter_normal
+        for si, t in enumerate(timesteps):
+            noise_pred = torch.zeros(2, *latents.shape[1:])
+            counter = torch.zeros(1, 1, f_tot, 1, 1)
+            banks = run_writer(ref, ref_lat.repeat(2 * cbs, 1, 1, 1), t, text)              # :711-716
+            queue = list(ref_uniform(0, steps, f_tot, cf, 1, ov))                             # :748-750
+            nb = _m.ceil(len(queue) / cbs)
+            for i in range(nb):
+                context = queue[i * cbs:(i + 1) * cbs]
+                lmi = torch.cat([latents[:, :, c] for c in context]).repeat(2, 1, 1, 1, 1)   # :759-763
+                b = lmi.shape[0]
+                pred = run_reader(u1, lmi, t, text[:b], banks)                               # :774-788
+                pred_uc, pred_c = pred.chunk(2)
+                pred = torch.cat([pred_uc.unsqueeze(0), pred_c.unsqueeze(0)])
+                for j, c in enumerate(context):
+                    noise_pred[:, :, c] = noise_pred[:, :, c] + pred[:, j]                   # :792-794
+                    counter[:, :, c] = counter[:, :, c] + 1
+            uc, cc = (noise_pred / counter).chunk(2)                                          # :813
+            eps = uc + gs * (cc - uc)                                                         # :814
+            T[f"{kind}/eps{si}"] = eps.clone()
+            z = counter_normal(0, si, latents.numel()).reshape(latents.shape) if kind == "ddpm" else None
+            latents = sch.step(eps, t, latents, noise=z)
+        T[f"{kind}/latents"] = latents
+    save_file({k: v.contiguous() for k, v in T.items()}, os.path.join(GOLD, "loop_tiny.safetensors"))
+    print("loop_tiny.safetensors", list(T))
+
+
+# =============================================================================== conditioning (A17/A18)
+def gen_conditioning():
+    import torch.nn as nn
+    T = {}
+    N = shim.extract_classes("/root/reference/Net.py",
+                             ["SpeedEncoder", "CrossAttentionLayer", "AudioAttentionLayers", "ReferenceAttentionLayer"])
+    S2 = shim.extract_classes("/root/reference/train_stage_2_temporal_audio.py", ["TemporalAttention", "AudioAttention"])
+    S3 = shim.extract_classes("/root/reference/train_stage_3_speedlayers.py", ["SpeedController", "FaceRegionController"])
+    speeds = torch.tensor(cases.SPEEDS, dtype=torch.float32)
+    se = load_synth(N["SpeedEncoder"](9, 64), "speed_encoder.")
+    T["speed_encoder/encode"] = se.encode_speed(speeds)
+    T["speed_encoder/out"] = se(speeds)
+    sc = load_synth(S3["SpeedController"](9, 64), "speed_controller.")
+    T["speed_controller/out"] = sc(speeds)
+    fr = load_synth(S3["FaceRegionController"](1, 32), "face_region.")
+    T["face_region/out"] = fr(seeded_randn((2, 1, 8, 8), 60))
+    al = load_synth(N["AudioAttentionLayers"](48, 2), "audio_layers.")
+    T["audio_layers/out"] = al(seeded_randn((2, 6, 48), 61), seeded_randn((2, 6, 48), 62))
+    rl = load_synth(N["ReferenceAttentionLayer"](48), "ref_layer.")
+    T["ref_layer/out"] = rl(seeded_randn((2, 6, 48), 63), seeded_randn((2, 1, 48), 64))
+    aa = load_synth(S2["AudioAttention"](64, 768, 8), "stage2_audio.")
+    T["stage2_audio/out"] = aa(seeded_randn((2, 12, 64), 65), seeded_randn((2, 5, 768), 66))
+    ta = load_synth(S2["TemporalAttention"](64, 8), "stage2_temporal.")
+    T["stage2_temporal/out"] = ta(seeded_randn((2, 12, 64), 67))
+    save_file({k: v.contiguous() for k, v in T.items()}, os.path.join(GOLD, "conditioning.safetensors"))
+    print("conditioning.safetensors", list(T))
+
+
+# =============================================================================== cfg1 (BASELINE config 1)
+def gen_cfg1():
+    """BASELINE.json configs[0]: UNet built literally from configs/unet-config.yaml:default
+    (norm_num_groups: 4), (1,4,1,32,32), timestep 981, ctx (1,77,768), no motion, random weights."""
+    from emote_hack_amd.config import unet_config_from_yaml
+    cfg = unet_config_from_yaml("/root/reference/configs/unet-config.yaml")
+    t0 = time.time()
+    u = load_synth(UNet3DConditionModel(**{k: v for k, v in cfg.items() if k != "motion_module_kwargs"}))
+    x = seeded_randn((1, 4, 1, 32, 32), 1)
+    ctx = seeded_randn((1, 77, 768), 2)
+    y = u(x, 981, ctx).sample
+    save_file({"cfg1/out": y.contiguous()}, os.path.join(GOLD, "cfg1.safetensors"))
+    print("cfg1.safetensors", tuple(y.shape), float(y.abs().mean()), f"{time.time() - t0:.1f}s")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-cfg1", action="store_true")
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    todo = a.only.split(",") if a.only else ["ints", "modules", "unet", "cond", "cfg1"]
+    if "ints" in todo:
+        gen_ints()
+    if "modules" in todo:
+        gen_modules()
+    if "unet" in todo:
+        u1, ref = gen_unet_tiny()
+        gen_loop(u1, ref)
+    if "cond" in todo:
+        gen_conditioning()
+    if "cfg1" in todo and not a.skip_cfg1:
+        gen_cfg1()
