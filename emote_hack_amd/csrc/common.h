@@ -1,0 +1,99 @@
+// common.h - shared device/host helpers for the gfx950 kernels (wave64, MFMA 32x32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/emo_hip.h"
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+extern thread_local char emo_err_buf[256];
+int emo_fail(int code, const char* fmt, ...);
+
+#define EMO_CHECK(cond, code, ...) \
+  do { if (!(cond)) return emo_fail((code), __VA_ARGS__); } while (0)
+
+#define EMO_LAUNCH_CHECK()                                                        \
+  do { hipError_t e_ = hipGetLastError();                                         \
+       if (e_ != hipSuccess) return emo_fail(EMO_ERR_HIP, "%s:%d hip launch: %s", \
+                                             __FILE__, __LINE__, hipGetErrorString(e_)); } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                          // round to nearest even
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+template <typename T> struct TT;
+template <> struct TT<float> {
+  static constexpr int VEC = 4;
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct TT<bf16_t> {
+  static constexpr int VEC = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// unpack a 16-byte vector of T into floats (VEC of them)
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& v, float* out);
+template <> __device__ __forceinline__ void unpack16<float>(const uint4& v, float* o) {
+  o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& v, float* o) {
+  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+  o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+  o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ uint4 pack16(const float* in);
+template <> __device__ __forceinline__ uint4 pack16<float>(const float* i) {
+  return make_uint4(__float_as_uint(i[0]), __float_as_uint(i[1]), __float_as_uint(i[2]), __float_as_uint(i[3]));
+}
+template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* i) {
+  return make_uint4(pack_bf2(i[0], i[1]), pack_bf2(i[2], i[3]), pack_bf2(i[4], i[5]), pack_bf2(i[6], i[7]));
+}
+
+// One "mma16" step: A and B fragments are 16 bytes per lane (bf16: 8 k-values, f32: 4 k-values) of the
+// rows/cols (lane&31), k-half (lane>>5).  bf16 -> one v_mfma_f32_32x32x16_bf16 (K=16);
+// f32 -> four v_mfma_f32_32x32x2_f32 (K=8, exact f32 fma chain).  Any k<->lane assignment is valid as
+// long as A and B agree, which they do because both fragments come from the same chunk index.
+template <typename T> __device__ __forceinline__ f32x16 mma16(const uint4& a, const uint4& b, f32x16 c);
+template <> __device__ __forceinline__ f32x16 mma16<bf16_t>(const uint4& a, const uint4& b, f32x16 c) {
+  union { uint4 u; s16x8 s; } ua, ub; ua.u = a; ub.u = b;
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, ua.s),
+                                                 __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, ub.s), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16 mma16<float>(const uint4& a, const uint4& b, f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  return c;
+}
+// k-values consumed by one mma16 step
+template <typename T> struct MmaK { static constexpr int value = 2 * TT<T>::VEC; };
+
+// C/D layout of the 32x32 MFMA: lane l, reg r -> col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
+__device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

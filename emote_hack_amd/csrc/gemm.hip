@@ -1,0 +1,211 @@
+// gemm.hip - MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950 (wave64, 32x32 MFMA tiles).
+//
+//   C[M,N] = epilogue( A[M,K] . W[N,K]^T )        A: NHWC activation rows, W: torch Linear layout
+//
+// One kernel template serves every GEMM-shaped op on the hot path: Linear q/k/v/out/FF
+// (orig_attention.py:566-575,776,817), 1x1 conv proj_in/out + shortcuts (attention.py:82,110;
+// resnet.py:175) and - with the conv A-loader - the per-frame 3x3 convs (resnet.py:30-38), stride 2
+// (resnet.py:98) and nearest-x2-upsample-folded (resnet.py:74-82: the interpolate is folded into the
+// load indexing, the upsampled tensor never exists).
+//
+// Structure (v1): 128x128 block tile, 64 BYTES of K per stage (bf16: 32, f32: 16 k-values), 4 waves in
+// 2x2 each owning 64x64 = 2x2 MFMA 32x32 accumulators (64 acc VGPRs); global -> registers -> LDS staging
+// with the next stage's loads issued before the MFMAs of the current one (double-buffered LDS, one
+// barrier per stage).  LDS rows are 64 B + 16 B pad = 80 B (5 x 16 B, odd) so the ds_read_b128 fragment
+// reads of a 16-lane group land on 16 distinct 16-byte slots (conflict-free).
+//   bf16: v_mfma_f32_32x32x16_bf16, f32 accumulate.   f32: v_mfma_f32_32x32x2_f32 (exact f32 fma chain).
+// Epilogue fused: bias, per-batch row bias (temb), GEGLU, residual, scale, row-major or V^T store.
+#include "common.h"
+
+static constexpr int BM = 128, BN = 128, KBYTES = 64, ROWB = KBYTES + 16;
+static constexpr int GEMM_THREADS = 256;
+
+struct ConvRow { int img, iy0, ix0; };
+
+template <typename T, bool CONV>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const emo_gemm_params p) {
+  constexpr int V = TT<T>::VEC;          // elements per 16 B
+  constexpr int BK = KBYTES / (int)sizeof(T);
+  constexpr int NL = BM * 4 / GEMM_THREADS;  // 16-byte vectors per thread per operand (=2)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][BM * ROWB];  // [buf][A|B]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int64_t bm = (int64_t)(blockIdx.x / tiles_n) * BM;
+  const int bn = (blockIdx.x % tiles_n) * BN;
+
+  const T* __restrict__ A = (const T*)p.A;
+  const T* __restrict__ W = (const T*)p.W;
+
+  // per-thread load slots
+  int a_row[NL], a_chunk[NL];
+  ConvRow a_cr[NL];
+  bool a_ok[NL];
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    int v = tid + i * GEMM_THREADS;
+    a_row[i] = v >> 2; a_chunk[i] = v & 3;
+    int64_t m = bm + a_row[i];
+    a_ok[i] = m < p.M;
+    if (CONV) {
+      int hw = p.Ho * p.Wo;
+      int img = (int)(m / hw); int rem = (int)(m % hw);
+      int oy = rem / p.Wo, ox = rem % p.Wo;
+      a_cr[i].img = img; a_cr[i].iy0 = oy * p.stride - 1; a_cr[i].ix0 = ox * p.stride - 1;
+    }
+  }
+
+  uint4 ra[NL], rb[NL];
+  auto load_global = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int k0 = kt * BK + a_chunk[i] * V;
+      uint4 va = make_uint4(0, 0, 0, 0);
+      if (a_ok[i] && k0 < p.K) {
+        if (!CONV) {
+          va = *(const uint4*)(A + (bm + a_row[i]) * p.lda + k0);
+        } else {
+          const int tap = k0 / p.Cin, ci = k0 - tap * p.Cin;
+          const int ky = tap / 3, kx = tap - ky * 3;
+          int iy = a_cr[i].iy0 + ky, ix = a_cr[i].ix0 + kx;
+          const int Hin = p.upsample2x ? 2 * p.H : p.H, Win = p.upsample2x ? 2 * p.W_ : p.W_;
+          if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
+            if (p.upsample2x) { iy >>= 1; ix >>= 1; }
+            va = *(const uint4*)(A + (((int64_t)a_cr[i].img * p.H + iy) * p.W_ + ix) * p.lda + ci);
+          }
+        }
+      }
+      ra[i] = va;
+      const int n = bn + a_row[i];
+      uint4 vb = make_uint4(0, 0, 0, 0);
+      if (n < p.N && k0 < p.K) vb = *(const uint4*)(W + (int64_t)n * p.K + k0);
+      rb[i] = vb;
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      *(uint4*)(&lds[buf][0][a_row[i] * ROWB + a_chunk[i] * 16]) = ra[i];
+      *(uint4*)(&lds[buf][1][a_row[i] * ROWB + a_chunk[i] * 16]) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int nk = (p.K + BK - 1) / BK;
+  load_global(0);
+  store_lds(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_global(kt + 1);
+    const unsigned char* la = &lds[cur][0][(wm * 64 + l31) * ROWB + half * 16];
+    const unsigned char* lb = &lds[cur][1][(wn * 64 + l31) * ROWB + half * 16];
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      uint4 fa0 = *(const uint4*)(la + kk * 32);
+      uint4 fa1 = *(const uint4*)(la + 32 * ROWB + kk * 32);
+      uint4 fb0 = *(const uint4*)(lb + kk * 32);
+      uint4 fb1 = *(const uint4*)(lb + 32 * ROWB + kk * 32);
+      acc[0][0] = mma16<T>(fa0, fb0, acc[0][0]);
+      acc[0][1] = mma16<T>(fa0, fb1, acc[0][1]);
+      acc[1][0] = mma16<T>(fa1, fb0, acc[1][0]);
+      acc[1][1] = mma16<T>(fa1, fb1, acc[1][1]);
+    }
+    if (kt + 1 < nk) store_lds(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  T* __restrict__ C = (T*)p.C;
+  const T* __restrict__ R = (const T*)p.residual;
+  const int n_out_total = p.geglu ? p.N / 2 : p.N;
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      if (p.geglu && j == 1) continue;  // gate tile is consumed together with the value tile
+      const int ncol_w = bn + wn * 64 + j * 32 + l31;  // column in W-row space
+      if (ncol_w >= p.N) continue;
+      const int ncol = p.geglu ? ((bn + wn * 64) >> 1) + l31 : ncol_w;  // output column
+      const float bias_v = p.bias ? p.bias[ncol_w] : 0.f;
+      const float bias_g = (p.geglu && p.bias) ? p.bias[ncol_w + 32] : 0.f;
+      float o[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int64_t m = bm + wm * 64 + i * 32 + mfma_row(r, half);
+        float v = acc[i][j][r] + bias_v;
+        if (p.rowbias && m < p.M) v += p.rowbias[(m / p.rows_per_batch) * p.ld_rowbias + ncol_w];
+        if (p.geglu) v = v * gelu_erf_f(acc[i][1][r] + bias_g);
+        if (R && m < p.M) v += TT<T>::ld(R + m * p.ldr + ncol);
+        o[r] = v * p.out_scale;
+      }
+      if (!p.transpose_out) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int64_t m = bm + wm * 64 + i * 32 + mfma_row(r, half);
+          if (m < p.M) TT<T>::st(C + m * p.ldc + ncol, o[r]);
+        }
+      } else {
+        // V^T store: Ct[m / t_rows][ncol][m % t_rows]; a lane's 4 consecutive rows are contiguous there.
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int64_t m0 = bm + wm * 64 + i * 32 + q * 8 + 4 * half;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const int64_t m = m0 + e;
+            if (m < p.M) {
+              const int64_t b = m / p.t_rows, ml = m % p.t_rows;
+              TT<T>::st(C + b * p.t_batch_stride + (int64_t)ncol * p.t_ld + ml, o[q * 4 + e]);
+            }
+          }
+        }
+      }
+    }
+  }
+  (void)n_out_total;
+}
+
+extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
+  EMO_CHECK(pp, EMO_ERR_NULL, "emo_gemm: null params");
+  const emo_gemm_params& p = *pp;
+  EMO_CHECK(p.A && p.W && p.C, EMO_ERR_NULL, "emo_gemm: null pointer");
+  EMO_CHECK(p.dtype == EMO_F32 || p.dtype == EMO_BF16, EMO_ERR_BAD_DTYPE, "emo_gemm: dtype %d", p.dtype);
+  const int V = p.dtype == EMO_F32 ? 4 : 8;
+  EMO_CHECK(p.M > 0 && p.N > 0 && p.K > 0, EMO_ERR_BAD_SHAPE, "emo_gemm: M=%lld N=%d K=%d", (long long)p.M, p.N, p.K);
+  EMO_CHECK(p.K % V == 0 && p.lda % V == 0, EMO_ERR_BAD_SHAPE, "emo_gemm: K=%d lda=%lld must be multiples of %d", p.K,
+            (long long)p.lda, V);
+  EMO_CHECK(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0, EMO_ERR_BAD_SHAPE, "emo_gemm: A/W must be 16-byte aligned");
+  if (p.geglu) EMO_CHECK(p.N % 64 == 0, EMO_ERR_BAD_SHAPE, "emo_gemm: GEGLU needs N %% 64 == 0 (N=%d)", p.N);
+  if (p.rowbias) EMO_CHECK(p.rows_per_batch > 0 && p.ld_rowbias >= p.N, EMO_ERR_BAD_SHAPE, "emo_gemm: rowbias geometry");
+  if (p.transpose_out) EMO_CHECK(p.t_rows > 0 && p.t_ld >= p.t_rows && !p.geglu, EMO_ERR_BAD_SHAPE, "emo_gemm: transpose geometry");
+  const bool conv = p.conv_taps != 0;
+  if (conv) {
+    EMO_CHECK(p.conv_taps == 9, EMO_ERR_UNSUPPORTED, "emo_gemm: conv_taps=%d (only 3x3)", p.conv_taps);
+    EMO_CHECK(p.Cin > 0 && p.Cin % V == 0 && p.K == 9 * p.Cin && p.lda >= p.Cin, EMO_ERR_BAD_SHAPE,
+              "emo_gemm: conv needs Cin %% %d == 0 and K == 9*Cin (Cin=%d K=%d)", V, p.Cin, p.K);
+    EMO_CHECK(p.H > 0 && p.W_ > 0 && p.Ho > 0 && p.Wo > 0 && (p.stride == 1 || p.stride == 2), EMO_ERR_BAD_SHAPE, "emo_gemm: conv geometry");
+    EMO_CHECK(p.M % ((int64_t)p.Ho * p.Wo) == 0, EMO_ERR_BAD_SHAPE, "emo_gemm: conv M not a multiple of Ho*Wo");
+    const int He = p.upsample2x ? 2 * p.H : p.H, We = p.upsample2x ? 2 * p.W_ : p.W_;
+    EMO_CHECK(p.Ho == (He + 2 - 3) / p.stride + 1 && p.Wo == (We + 2 - 3) / p.stride + 1, EMO_ERR_BAD_SHAPE, "emo_gemm: conv output size");
+  }
+  const int64_t tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  EMO_CHECK(tiles < (1ll << 31), EMO_ERR_BAD_SHAPE, "emo_gemm: too many tiles");
+  hipStream_t st = as_stream(stream);
+  if (p.dtype == EMO_F32) {
+    if (conv) gemm_kernel<float, true><<<(int)tiles, GEMM_THREADS, 0, st>>>(p);
+    else gemm_kernel<float, false><<<(int)tiles, GEMM_THREADS, 0, st>>>(p);
+  } else {
+    if (conv) gemm_kernel<bf16_t, true><<<(int)tiles, GEMM_THREADS, 0, st>>>(p);
+    else gemm_kernel<bf16_t, false><<<(int)tiles, GEMM_THREADS, 0, st>>>(p);
+  }
+  EMO_LAUNCH_CHECK();
+  return EMO_OK;
+}

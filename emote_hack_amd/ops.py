@@ -1,0 +1,252 @@
+"""Thin host wrappers: torch tensors (device memory, streams = plumbing) -> raw pointers -> C ABI.
+
+Every function launches hand-written HIP kernels from libemo_hip.so on torch's current stream.
+Nothing here computes with torch; tensors are only allocated (`torch.empty`) and addressed.
+Activations are 2-D "rows x channels" tensors (NHWC rows), possibly views with a leading
+dimension (`.stride(0)`) larger than their width.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import EMO_BF16, EMO_F32, AttentionParams, GemmParams, check
+
+_DT = {torch.float32: EMO_F32, torch.bfloat16: EMO_BF16}
+
+
+def dt(t_or_dtype) -> int:
+    d = t_or_dtype if isinstance(t_or_dtype, torch.dtype) else t_or_dtype.dtype
+    try:
+        return _DT[d]
+    except KeyError:
+        raise _lib.EmoHipError(f"unsupported compute dtype {d} (float32 | bfloat16)")
+
+
+def vec(dtype) -> int:
+    return 4 if dtype == torch.float32 else 8
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.EmoHipError("emote_hack_amd ops need device tensors (no CPU fallback on the product path)")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _rows(t):
+    """(ptr, ld) of a 2-D row-major view."""
+    assert t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
+    return _ptr(t), t.stride(0)
+
+
+# ----------------------------------------------------------------------------- layout / elementwise
+def ncfhw_to_rows(x5d: torch.Tensor, dtype, cpad=None) -> torch.Tensor:
+    _need_cuda(x5d)
+    B, Cc, F, H, W = x5d.shape
+    x5d = x5d.contiguous().float()
+    cpad = cpad or Cc
+    y = torch.empty(B * F * H * W, cpad, device=x5d.device, dtype=dtype)
+    check(_lib.load().emo_ncfhw_to_rows(_ptr(x5d), _ptr(y), B, Cc, F, H, W, cpad, cpad, dt(dtype), _stream()), "emo_ncfhw_to_rows")
+    return y
+
+
+def rows_to_ncfhw(x: torch.Tensor, B, Cc, F, H, W) -> torch.Tensor:
+    _need_cuda(x)
+    p, ld = _rows(x)
+    y = torch.empty(B, Cc, F, H, W, device=x.device, dtype=torch.float32)
+    check(_lib.load().emo_rows_to_ncfhw(p, _ptr(y), B, Cc, F, H, W, ld, dt(x), _stream()), "emo_rows_to_ncfhw")
+    return y
+
+
+def copy_cols(x: torch.Tensor, y: torch.Tensor, coff: int):
+    px, ldx = _rows(x)
+    py, ldy = _rows(y)
+    check(_lib.load().emo_copy_cols(px, ldx, py, ldy, coff, x.shape[0], x.shape[1], dt(x), _stream()), "emo_copy_cols")
+
+
+def concat_cols(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """torch.cat([a, b], dim=channels) (unet_3d_blocks.py:629,731) as two strided row copies."""
+    y = torch.empty(a.shape[0], a.shape[1] + b.shape[1], device=a.device, dtype=a.dtype)
+    copy_cols(a, y, 0)
+    copy_cols(b, y, a.shape[1])
+    return y
+
+
+def add(a: torch.Tensor, b: torch.Tensor, alpha=1.0, out=None) -> torch.Tensor:
+    out = torch.empty_like(a) if out is None else out
+    pa, lda = _rows(a)
+    pb, ldb = _rows(b)
+    po, ldo = _rows(out)
+    check(_lib.load().emo_add(pa, lda, pb, ldb, float(alpha), po, ldo, a.shape[0], a.shape[1], dt(a), _stream()), "emo_add")
+    return out
+
+
+def convert(src: torch.Tensor, dtype, fp16_round=False) -> torch.Tensor:
+    _need_cuda(src)
+    src = src.contiguous()
+    dst = torch.empty(src.shape, device=src.device, dtype=dtype)
+    check(_lib.load().emo_convert(_ptr(src), dt(src), _ptr(dst), dt(dtype), src.numel(), int(fp16_round), _stream()), "emo_convert")
+    return dst
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    check(_lib.load().emo_silu(_ptr(x), _ptr(y), x.numel(), dt(x), _stream()), "emo_silu")
+    return y
+
+
+def timestep_embedding(timesteps: torch.Tensor, freqs: torch.Tensor, dim: int, flip: bool, dtype) -> torch.Tensor:
+    _need_cuda(timesteps, freqs)
+    assert timesteps.dtype == torch.int64 and freqs.dtype == torch.float32
+    B = timesteps.shape[0]
+    out = torch.empty(B, dim, device=timesteps.device, dtype=dtype)
+    check(_lib.load().emo_timestep_embedding(_ptr(timesteps), _ptr(freqs), _ptr(out), B, dim, int(flip), dt(dtype), _stream()),
+          "emo_timestep_embedding")
+    return out
+
+
+# ----------------------------------------------------------------------------- norms
+def group_norm(x: torch.Tensor, gamma, beta, n_inst: int, groups: int, eps: float, silu_: bool, out=None) -> torch.Tensor:
+    """GroupNorm over NHWC rows; x (n_inst*S, C).  n_inst=B -> joint 5-D statistics (resnet.py:180),
+    n_inst=B*F -> per frame (attention.py:124)."""
+    _need_cuda(x)
+    lib = _lib.load()
+    M, Cc = x.shape
+    S = M // n_inst
+    px, ldx = _rows(x)
+    ws = lib.emo_groupnorm_workspace_bytes(n_inst, S, Cc, groups)
+    part = torch.empty(max(ws // 4, 1), device=x.device, dtype=torch.float32)
+    stats = torch.empty(n_inst * groups * 2, device=x.device, dtype=torch.float32)
+    check(lib.emo_groupnorm_stats(px, ldx, _ptr(stats), _ptr(part), n_inst, S, Cc, groups, float(eps), dt(x), _stream()),
+          "emo_groupnorm_stats")
+    y = torch.empty(M, Cc, device=x.device, dtype=x.dtype) if out is None else out
+    py, ldy = _rows(y)
+    check(lib.emo_groupnorm_apply(px, ldx, _ptr(stats), _ptr(gamma), _ptr(beta), py, ldy, n_inst, S, Cc, groups, int(silu_),
+                                  dt(x), _stream()), "emo_groupnorm_apply")
+    return y
+
+
+def layer_norm(x: torch.Tensor, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0) -> torch.Tensor:
+    _need_cuda(x)
+    M, Cc = x.shape
+    px, ldx = _rows(x)
+    y = torch.empty(M, Cc, device=x.device, dtype=x.dtype)
+    check(_lib.load().emo_layernorm(px, ldx, _ptr(gamma), _ptr(beta), _ptr(y), Cc, M, Cc, float(eps), _ptr(pe), rows_per_frame,
+                                    frames, dt(x), _stream()), "emo_layernorm")
+    return y
+
+
+# ----------------------------------------------------------------------------- GEMM / conv
+def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, geglu=False,
+         out_scale=1.0, out=None, transpose_rows=0, transpose_ld=0, conv=None) -> torch.Tensor:
+    """out = epilogue(a @ w.T).  a (M, K) rows view; w (N, K) contiguous in the compute dtype.
+    conv = dict(H, W, Cin, stride, upsample2x, Ho, Wo) selects the implicit 3x3 conv loader (then a is
+    the (B*F*H*W, >=Cin) NHWC input and M = B*F*Ho*Wo).
+    transpose_rows=L stores V^T per batch of L rows: out (M/L, N, transpose_ld)."""
+    _need_cuda(a, w)
+    p = GemmParams()
+    pa, lda = _rows(a)
+    N, K = w.shape
+    assert w.is_contiguous() and w.dtype == a.dtype, (w.dtype, a.dtype)
+    if conv is None:
+        M = a.shape[0]
+        assert a.shape[1] == K, (a.shape, w.shape)
+    else:
+        M = (a.shape[0] // (conv["H"] * conv["W"])) * conv["Ho"] * conv["Wo"]
+    n_out = N // 2 if geglu else N
+    if transpose_rows:
+        nb = M // transpose_rows
+        if out is None:
+            out = torch.zeros(nb, n_out, transpose_ld, device=a.device, dtype=a.dtype)
+        p.transpose_out, p.t_rows, p.t_ld, p.t_batch_stride = 1, transpose_rows, transpose_ld, n_out * transpose_ld
+        p.C, p.ldc = out.data_ptr(), 0
+    else:
+        if out is None:
+            out = torch.empty(M, n_out, device=a.device, dtype=a.dtype)
+        pc, ldc = _rows(out)
+        p.C, p.ldc = pc.value, ldc
+    p.A, p.lda, p.W = pa.value, lda, w.data_ptr()
+    p.bias = bias.data_ptr() if bias is not None else None
+    if rowbias is not None:
+        assert rowbias.dtype == torch.float32 and rowbias.stride(1) == 1
+        p.rowbias, p.rows_per_batch, p.ld_rowbias = rowbias.data_ptr(), rows_per_batch, rowbias.stride(0)
+    if residual is not None:
+        pr, ldr = _rows(residual)
+        p.residual, p.ldr = pr.value, ldr
+    p.M, p.N, p.K = M, N, K
+    p.geglu, p.out_scale = int(geglu), float(out_scale)
+    if conv is not None:
+        p.conv_taps, p.H, p.W_, p.Cin = 9, conv["H"], conv["W"], conv["Cin"]
+        p.stride, p.upsample2x, p.Ho, p.Wo = conv["stride"], int(conv["upsample2x"]), conv["Ho"], conv["Wo"]
+    p.dtype = dt(a)
+    check(_lib.load().emo_gemm(C.byref(p), _stream()), "emo_gemm")
+    return out
+
+
+def conv3x3(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, H: int, W: int, *, stride=1, upsample2x=False, **kw):
+    """Per-frame 3x3 conv, pad 1 (resnet.py:30-38), as an implicit GEMM over NHWC rows.
+    w is the re-laid (Cout, 9*Cin_pad) weight."""
+    cin = w.shape[1] // 9
+    He, We = (2 * H, 2 * W) if upsample2x else (H, W)
+    Ho, Wo = (He + 2 - 3) // stride + 1, (We + 2 - 3) // stride + 1
+    assert x.shape[0] == n_img * H * W
+    return gemm(x, w, bias, conv=dict(H=H, W=W, Cin=cin, stride=stride, upsample2x=upsample2x, Ho=Ho, Wo=Wo), **kw), Ho, Wo
+
+
+# ----------------------------------------------------------------------------- attention
+def attention(q, k0, v0t, Lk0, *, B, Lq, heads, d, scale, seg0_div=1, k1=None, v1t=None, Lk1=0, seg1_div=1,
+              seg1_first_batch=0) -> torch.Tensor:
+    """q (B*Lq, >=heads*d) rows view; k0 rows view; v0t (Bk, heads*d, ld) V^T tensors."""
+    _need_cuda(q, k0, v0t)
+    p = AttentionParams()
+    pq, ldq = _rows(q)
+    pk, ldk = _rows(k0)
+    out = torch.empty(B * Lq, heads * d, device=q.device, dtype=q.dtype)
+    p.q, p.ldq = pq.value, ldq
+    p.k0, p.ldk0, p.v0t, p.ldv0t, p.Lk0 = pk.value, ldk, v0t.data_ptr(), v0t.stride(1), Lk0
+    p.seg0_div = seg0_div
+    if k1 is not None:
+        pk1, ldk1 = _rows(k1)
+        p.k1, p.ldk1, p.v1t, p.ldv1t, p.Lk1 = pk1.value, ldk1, v1t.data_ptr(), v1t.stride(1), Lk1
+        p.seg1_div, p.seg1_first_batch = seg1_div, seg1_first_batch
+    else:
+        p.seg1_div = 1
+    p.out, p.ldo = out.data_ptr(), out.stride(0)
+    p.B, p.Lq, p.heads, p.d, p.scale, p.dtype = B, Lq, heads, d, float(scale), dt(q)
+    check(_lib.load().emo_attention(C.byref(p), _stream()), "emo_attention")
+    return out
+
+
+def temporal_attention(qkv: torch.Tensor, B, F, HW, heads, d, scale) -> torch.Tensor:
+    _need_cuda(qkv)
+    pq, ld = _rows(qkv)
+    out = torch.empty(B * F * HW, heads * d, device=qkv.device, dtype=qkv.dtype)
+    check(_lib.load().emo_temporal_attention(pq, ld, _ptr(out), out.stride(0), B, F, HW, heads, d, float(scale), dt(qkv), _stream()),
+          "emo_temporal_attention")
+    return out
+
+
+# ----------------------------------------------------------------------------- sampler
+def cfg_step(noise_pred, counter, latents, *, C_, F, HW, guidance_scale, c_x, c_eps, c_noise, seed, step, eps_out=None):
+    _need_cuda(noise_pred, counter, latents)
+    assert noise_pred.dtype == counter.dtype == latents.dtype == torch.float32
+    check(_lib.load().emo_cfg_step(_ptr(noise_pred), _ptr(counter), _ptr(latents), _ptr(eps_out), C_, F, HW, float(guidance_scale),
+                                   float(c_x), float(c_eps), float(c_noise), int(seed) & 0xFFFFFFFF, int(step) & 0xFFFFFFFF,
+                                   _stream()), "emo_cfg_step")
+
+
+def accumulate_window(pred_rows, noise_pred_branch, counter, frames_i32, *, C_, F, HW, add_counter):
+    pp, ld = _rows(pred_rows)
+    check(_lib.load().emo_accumulate_window(pp, ld, _ptr(noise_pred_branch), _ptr(counter), _ptr(frames_i32), frames_i32.numel(),
+                                            C_, F, HW, int(add_counter), dt(pred_rows), _stream()), "emo_accumulate_window")

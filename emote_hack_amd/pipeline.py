@@ -1,0 +1,245 @@
+"""EMOAnimationPipeline - the sampling loop of the reference (EMOAnimationPipeline.py:543-840) on
+MI355X.  Same `__call__` signature; the hot loop (`:698-823`) is re-designed:
+
+  * per step: ReferenceNet write pass -> per window-batch Backbone read pass -> window average + CFG +
+    scheduler step fused in ONE HIP kernel (emo_cfg_step) on f32 master latents;
+  * ReferenceNet banks depend on the timestep only (never on the latents), so with world_size>1 the
+    `num_inference_steps` write passes are dealt round-robin over the ranks BEFORE the loop and exchanged
+    with one RCCL all_gather (north_star: "all-gather over xGMI to broadcast ReferenceNet features");
+    288 GB HBM holds every step's banks (50 x 28 MB at 512^2).  world_size==1 keeps the reference's
+    per-step order;
+  * windows are sharded `global_context[rank::world_size]` exactly like the reference (:757); the
+    reference's gather-to-root + broadcast (:796-821) is replaced by one all_reduce of the f32 window
+    accumulators, after which every rank runs the (deterministic, counter-based-noise) sampler step
+    redundantly - no broadcast, identical latents on all ranks.
+
+Out of scope here: CLIP text encoder, VAE, ControlNet, wav2vec.  They are
+accepted as caller-supplied callables / precomputed tensors (`text_embeddings=`, `ref_image_latents=`,
+`audio_features=`, `speed_embeddings=` keyword arguments).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Union
+
+import torch
+
+from . import ops
+from .context import get_context_scheduler
+from .reference_control import ReferenceAttentionControl
+from .scheduler import DDIMScheduler, DDPMScheduler
+
+
+@dataclass
+class AnimationPipelineOutput:  # EMOAnimationPipeline.py:79-81
+    videos: Union[torch.Tensor, "object"]
+
+
+class EMOAnimationPipeline:
+    def __init__(self, vae=None, text_encoder=None, tokenizer=None, unet=None, controlnet=None, scheduler=None):
+        """EMOAnimationPipeline.py:87-130.  The ctor forces steps_offset=1 / clip_sample=False on the
+        scheduler it is given, like the reference."""
+        if unet is None or scheduler is None:
+            raise ValueError("unet and scheduler are required")
+        self.vae, self.text_encoder, self.tokenizer = vae, text_encoder, tokenizer
+        self.unet, self.controlnet, self.scheduler = unet, controlnet, scheduler
+        if isinstance(scheduler, DDIMScheduler) and scheduler.config.steps_offset != 1:
+            scheduler.config.steps_offset = 1
+        if getattr(scheduler.config, "clip_sample", False):
+            scheduler.config.clip_sample = False
+        self.vae_scale_factor = 8
+        self.device = unet.device
+
+    @property
+    def _execution_device(self):
+        return self.unet.device
+
+    def check_inputs(self, prompt, height, width, callback_steps):  # EMOAnimationPipeline.py:326-339
+        if not isinstance(prompt, str) and not isinstance(prompt, list):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if (callback_steps is None) or (not isinstance(callback_steps, int) or callback_steps <= 0):
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type {type(callback_steps)}.")
+
+    # ------------------------------------------------------------------ ReferenceNet banks
+    def _write_banks(self, appearance_encoder, writer, ref_lat_rep, t, text_embeddings):
+        writer.clear()
+        appearance_encoder(ref_lat_rep.unsqueeze(2), t, encoder_hidden_states=text_embeddings, return_dict=False)
+        return writer
+
+    def _pack_banks(self, writer):
+        """All bank tensors of one step in one contiguous buffer (one collective instead of ten)."""
+        flat = [writer.bank[p][0].reshape(-1) for p in writer.order]
+        return torch.cat(flat)  # device copy (plumbing)
+
+    def _unpack_banks(self, buf, writer, shapes):
+        off = 0
+        for p, shp in zip(writer.order, shapes):
+            n = shp[0] * shp[1] * shp[2]
+            writer.bank[p] = [buf[off:off + n].view(shp)]
+            off += n
+
+    # ------------------------------------------------------------------ the hot loop
+    @torch.no_grad()
+    def denoise(self, latents, ref_image_latents, text_embeddings, *, appearance_encoder, num_inference_steps=50,
+                guidance_scale=7.5, eta=0.0, context_frames=16, context_stride=1, context_overlap=4, context_batch_size=1,
+                context_schedule="uniform", audio_features=None, speed_embeddings=None, seed=0, fusion_blocks="midup",
+                dist=False, rank=0, world_size=1, num_actual_inference_steps=None, callback=None, callback_steps=1,
+                return_eps=False):
+        """EMOAnimationPipeline.py:698-823.  latents f32 (1,4,F_tot,h,w) on device (updated in place and
+        returned); ref_image_latents (1,4,h,w); text_embeddings (2,L,D) = [uncond, cond]."""
+        unet, sch = self.unet, self.scheduler
+        dev = unet.device
+        do_cfg = guidance_scale > 1.0
+        if not do_cfg:
+            raise NotImplementedError("guidance_scale <= 1 (no CFG) is not on the benchmarked path")
+        if latents.shape[0] != 1:
+            raise ValueError("batch_size must be 1 (EMOAnimationPipeline.py:641-642); run clips as separate calls")
+        cbs = context_batch_size
+        latents = latents.to(dev).float().contiguous()
+        _, C4, f_tot, h, w = latents.shape
+        HW = h * w
+        text = torch.cat([text_embeddings] * cbs).to(dev)  # :631
+        writer = ReferenceAttentionControl(appearance_encoder, do_classifier_free_guidance=True, mode="write",
+                                           batch_size=cbs, fusion_blocks=fusion_blocks)   # :633
+        reader = ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", batch_size=cbs,
+                                           fusion_blocks=fusion_blocks)                   # :634
+        timesteps = sch.set_timesteps(num_inference_steps)
+        ref_rep = ref_image_latents.to(dev).float().repeat(cbs * 2, 1, 1, 1)              # :712
+        scheduler_fn = get_context_scheduler(context_schedule)
+        noise_pred = torch.empty(2, C4, f_tot, HW, device=dev, dtype=torch.float32)
+        counter = torch.empty(f_tot, device=dev, dtype=torch.float32)
+        eps_trace = []
+
+        # --- multi-GPU: deal the write passes over ranks, all_gather the packed banks (one collective)
+        bank_cache = None
+        if dist and world_size > 1:
+            import torch.distributed as td
+            mine = list(range(rank, len(timesteps), world_size))
+            n_slots = math.ceil(len(timesteps) / world_size)
+            local, shapes = [], None
+            for si in mine:
+                self._write_banks(appearance_encoder, writer, ref_rep, timesteps[si], text)
+                shapes = [tuple(writer.bank[p][0].shape) for p in writer.order]
+                local.append(self._pack_banks(writer))
+            while len(local) < n_slots:
+                local.append(torch.zeros_like(local[0]))
+            send = torch.stack(local)                                   # (n_slots, total)
+            recv = torch.empty(world_size, *send.shape, device=dev, dtype=send.dtype)
+            td.all_gather_into_tensor(recv, send)
+            bank_cache = (recv, shapes)                                 # step si -> recv[si % world, si // world]
+
+        for si, t in enumerate(timesteps):
+            if num_actual_inference_steps is not None and si < num_inference_steps - num_actual_inference_steps:
+                continue
+            noise_pred.zero_()
+            counter.zero_()
+            if bank_cache is None:
+                self._write_banks(appearance_encoder, writer, ref_rep, t, text)          # :711-716
+            else:
+                self._unpack_banks(bank_cache[0][si % world_size, si // world_size], writer, bank_cache[1])
+            context_queue = list(scheduler_fn(0, num_inference_steps, f_tot, context_frames, context_stride, context_overlap))
+            nb = math.ceil(len(context_queue) / cbs)
+            global_context = [context_queue[i * cbs:(i + 1) * cbs] for i in range(nb)]   # :752-755
+            for context in global_context[rank::world_size]:                             # :757
+                x = torch.cat([latents[:, :, c] for c in context]).repeat(2, 1, 1, 1, 1)  # :759-763 (index/copy only)
+                x = sch.scale_model_input(x, t)
+                b = x.shape[0]
+                reader.update(writer)                                                      # :774
+                af = None
+                if audio_features is not None:   # per-frame audio context; uc rows get a zero context
+                    cond = torch.cat([audio_features[c] for c in context]).to(dev)
+                    af = torch.cat([torch.zeros_like(cond), cond])
+                rows = unet(x, t, encoder_hidden_states=text[:b], audio_features=af, speed_embeddings=speed_embeddings,
+                            return_dict=False, _return_rows=True)                          # :777-786
+                reader.clear()                                                             # :788
+                nf = len(context[0])
+                for j, c in enumerate(context):                                            # :790-794
+                    fr = torch.tensor(c, dtype=torch.int32, device=dev)
+                    for branch in (0, 1):
+                        bi = branch * len(context) + j
+                        ops.accumulate_window(rows[bi * nf * HW:(bi + 1) * nf * HW], noise_pred[branch], counter, fr,
+                                              C_=C4, F=f_tot, HW=HW, add_counter=(branch == 0))
+            if dist and world_size > 1:                                                    # replaces :796-809 + :819-821
+                import torch.distributed as td
+                td.all_reduce(noise_pred)
+                td.all_reduce(counter)
+            c_x, c_eps, c_n = sch.coefficients(t, eta) if isinstance(sch, DDIMScheduler) else sch.coefficients(t)
+            eps_out = torch.empty(C4 * f_tot * HW, device=dev, dtype=torch.float32) if return_eps else None
+            ops.cfg_step(noise_pred, counter, latents, C_=C4, F=f_tot, HW=HW, guidance_scale=guidance_scale, c_x=c_x,
+                         c_eps=c_eps, c_noise=c_n, seed=seed, step=si, eps_out=eps_out)   # :812-817 fused
+            if return_eps:
+                eps_trace.append(eps_out.view(1, C4, f_tot, h, w))
+            writer.clear()                                                                 # :823
+            if callback is not None and si % callback_steps == 0:
+                callback(si, t, latents)
+        return (latents, eps_trace) if return_eps else latents
+
+    # ------------------------------------------------------------------ reference-compatible entry point
+    @torch.no_grad()
+    def __call__(self, prompt: Union[str, List[str]], video_length: Optional[int], height: Optional[int] = None,
+                 width: Optional[int] = None, num_inference_steps: int = 50, guidance_scale: float = 7.5,
+                 negative_prompt=None, num_videos_per_prompt: Optional[int] = 1, eta: float = 0.0, generator=None,
+                 latents=None, output_type: Optional[str] = "tensor", return_dict: bool = True,
+                 callback: Optional[Callable] = None, callback_steps: Optional[int] = 1, controlnet_condition: list = None,
+                 controlnet_conditioning_scale: float = 1.0, context_frames: int = 16, context_stride: int = 1,
+                 context_overlap: int = 4, context_batch_size: int = 1, context_schedule: str = "uniform",
+                 init_latents=None, num_actual_inference_steps: Optional[int] = None, appearance_encoder=None,
+                 reference_control_writer=None, reference_control_reader=None, source_image=None,
+                 decoder_consistency=None, audio=None, head_rotation_speeds=None, **kwargs):
+        """Signature = EMOAnimationPipeline.py:544-578.  Extra keyword inputs for the parts that are out of
+        scope here: text_embeddings=(2,L,D), ref_image_latents=(1,4,h,w), audio_features=(F,L_a,D),
+        speed_embeddings=(1,4*C0), seed=int; dist/rank/world_size as in the reference (:636-638)."""
+        height = height or self.unet.config.sample_size * self.vae_scale_factor
+        width = width or self.unet.config.sample_size * self.vae_scale_factor
+        self.check_inputs(prompt, height, width, callback_steps)
+        assert num_videos_per_prompt == 1   # :641
+        if isinstance(prompt, list) and len(prompt) != 1:
+            raise AssertionError("batch_size == 1")  # :642
+        if self.controlnet is not None or controlnet_condition is not None:
+            raise NotImplementedError("ControlNet branch is SURVEY.md section 8(f) 'next' - not built yet")
+        if appearance_encoder is None:
+            raise ValueError("appearance_encoder (ReferenceNet) is required")
+        text_embeddings = kwargs.get("text_embeddings")
+        if text_embeddings is None:
+            if self.text_encoder is None:
+                raise ValueError("pass text_embeddings=(2,L,D) [uncond, cond] (no CLIP text encoder in this build)")
+            text_embeddings = self.text_encoder(prompt, negative_prompt)
+        ref_lat = kwargs.get("ref_image_latents")
+        if ref_lat is None:
+            if self.vae is None or source_image is None:
+                raise ValueError("pass ref_image_latents=(1,4,h,w) (no VAE in this build)")
+            ref_lat = self.vae.encode(source_image).latent_dist.mean * 0.18215   # :402-414
+        if audio is not None and kwargs.get("audio_features") is None:
+            raise NotImplementedError("wav2vec feature extraction is out of scope: pass audio_features=")
+        if head_rotation_speeds is not None and kwargs.get("speed_embeddings") is None:
+            raise NotImplementedError("pass speed_embeddings= (see emote_hack_amd.conditioning.SpeedEncoder)")
+        if init_latents is not None:   # (b f) c h w -> b c f h w  (:657-658)
+            bf, c4, hh, ww = init_latents.shape
+            lat = init_latents.reshape(bf // video_length, video_length, c4, hh, ww).permute(0, 2, 1, 3, 4)
+        elif latents is not None:
+            lat = latents
+        else:
+            # prepare_latents draws clip_length=16 frames and tiles them video_length//16 times (:341-360)
+            if video_length < 16:
+                raise ValueError("video_length < 16 needs init_latents (prepare_latents tiles 16-frame noise, :341-360)")
+            g = generator if isinstance(generator, torch.Generator) else None
+            base = torch.randn(1, self.unet.in_channels, 16, height // 8, width // 8, generator=g)
+            lat = base.repeat(1, 1, video_length // 16, 1, 1) * self.scheduler.init_noise_sigma
+        lat = self.denoise(lat, ref_lat, text_embeddings, appearance_encoder=appearance_encoder,
+                           num_inference_steps=num_inference_steps, guidance_scale=guidance_scale, eta=eta,
+                           context_frames=context_frames, context_stride=context_stride, context_overlap=context_overlap,
+                           context_batch_size=context_batch_size, context_schedule=context_schedule,
+                           audio_features=kwargs.get("audio_features"), speed_embeddings=kwargs.get("speed_embeddings"),
+                           seed=kwargs.get("seed", 0), dist=kwargs.get("dist", False), rank=kwargs.get("rank", 0),
+                           world_size=kwargs.get("world_size", 1), num_actual_inference_steps=num_actual_inference_steps,
+                           callback=callback, callback_steps=callback_steps)
+        if self.vae is not None and output_type != "latent":
+            video = self.vae.decode_video(lat)   # caller-supplied (:291-307)
+        else:
+            video = lat
+        if not return_dict:
+            return video
+        return AnimationPipelineOutput(videos=video)

@@ -1,0 +1,451 @@
+"""UNet3DConditionModel - the Backbone denoising UNet (and, at F=1 without motion modules, the
+ReferenceNet) on MI355X.  Host-side mirror of the reference class
+(magicanimate/models/unet_controlnet.py:54-525): same ctor kwargs, `.config`, forward signature,
+`UNet3DConditionOutput.sample`, state-dict keys, `from_pretrained_2d`.
+
+Underneath there is no torch arithmetic: forward() is a sequence of hand-written HIP kernel launches
+(emote_hack_amd/csrc via the C ABI in include/emo_hip.h) over NHWC "rows x channels" activations.
+The (b f) h w token layout of the transformers and the NHWC layout of the convs are the same memory,
+so conv -> attention -> temporal attention transitions move no data.
+
+Weights are re-laid once at load (SURVEY.md section 7 "hard parts"):
+  conv 3x3  OIHW -> [Cout][ky][kx][Cin]      1x1 / Linear -> [N][K]
+  GEGLU proj rows interleaved (32 value, 32 gate) so the gate is applied in the GEMM epilogue
+  attn1 to_q|to_k fused; motion-module to_q|to_k|to_v fused; all 22 time_emb_proj fused into one GEMM.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from dataclasses import dataclass
+from typing import Optional, Tuple, Union
+
+import torch
+
+from . import ops
+from ._lib import EmoHipError
+from .config import FrozenConfig, normalize_unet_config
+from .spec import UNetSpec, build_spec, param_shapes, reference_block_order
+
+
+@dataclass
+class UNet3DConditionOutput:  # unet_controlnet.py:49-51
+    sample: torch.Tensor
+
+    def __getitem__(self, i):
+        return (self.sample,)[i]
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class _Ctx:
+    """Per-forward geometry + reference-attention state."""
+
+    def __init__(self, B, F, H, W):
+        self.B, self.F, self.H, self.W = B, F, H, W
+        self.bank_mode = None       # None | 'write' | 'read'
+        self.banks = {}             # prefix -> rows tensor (B_ref*L, C) in compute dtype
+        self.bank_rows = 0          # B_ref
+        self.written = {}
+        self.uc_batches = 0         # number of leading (b f) batches that skip the bank
+        self.active = ()
+
+
+class UNet3DConditionModel:
+    def __init__(self, **kwargs):
+        self._has_out = kwargs.pop("_has_out", True)
+        self.config: FrozenConfig = normalize_unet_config(kwargs)
+        self.spec: UNetSpec = build_spec(self.config, has_out=self._has_out)
+        self.sample_size = self.config["sample_size"]
+        self.in_channels = self.config["in_channels"]
+        self.num_upsamplers = len(self.config["block_out_channels"]) - 1
+        self.dtype = torch.float32
+        self.device = torch.device("cpu")
+        self._shapes = param_shapes(self.spec)
+        self._master = None   # reference-layout fp32 tensors (device)
+        self._w = None        # packed tensors
+        self._reference_control = None
+
+    # ------------------------------------------------------------------ torch-module-like surface
+    def eval(self):
+        return self
+
+    def requires_grad_(self, *_):
+        return self
+
+    def parameters(self):
+        return iter(self._master.values()) if self._master else iter(())
+
+    def state_dict(self):
+        if self._master is None:
+            raise EmoHipError("no weights loaded")
+        return {k: v.detach().cpu() for k, v in self._master.items()}
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self._shapes if k not in sd]
+        unexpected = [k for k in sd if k not in self._shapes]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
+        for k, shp in self._shapes.items():
+            if k in sd and tuple(sd[k].shape) != tuple(shp):
+                raise RuntimeError(f"size mismatch for {k}: {tuple(sd[k].shape)} vs {tuple(shp)}")
+        master = dict(self._master or {})
+        for k in self._shapes:
+            if k in sd:
+                master[k] = sd[k].detach().to(torch.float32)
+        self._master = master
+        if not missing:
+            self._pack()
+        return missing, unexpected
+
+    def to(self, *args, **kwargs):
+        device, dtype = kwargs.get("device"), kwargs.get("dtype")
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
+            else:
+                device = torch.device(a)
+        if dtype is not None:
+            if dtype not in (torch.float32, torch.bfloat16):
+                raise EmoHipError(f"compute dtype {dtype} not supported (float32 | bfloat16)")
+            self.dtype = dtype
+        if device is not None:
+            self.device = torch.device(device)
+        if self._master is not None:
+            self._pack()
+        return self
+
+    def cuda(self):
+        return self.to("cuda")
+
+    @classmethod
+    def from_config(cls, config, **extra):
+        from .config import UNET_DEFAULTS
+        kw = {k: v for k, v in dict(config).items() if k in UNET_DEFAULTS}
+        kw.update({k: v for k, v in extra.items() if k in UNET_DEFAULTS})
+        return cls(**kw)
+
+    @classmethod
+    def from_pretrained_2d(cls, pretrained_model_path, subfolder=None, unet_additional_kwargs=None):
+        """unet_controlnet.py:485-525: config.json + diffusion_pytorch_model.bin, 2D->3D block names,
+        strict=False load, prints missing/unexpected counts."""
+        if subfolder is not None:
+            pretrained_model_path = os.path.join(pretrained_model_path, subfolder)
+        config_file = os.path.join(pretrained_model_path, "config.json")
+        if not os.path.isfile(config_file):
+            raise RuntimeError(f"{config_file} does not exist")
+        with open(config_file) as f:
+            config = json.load(f)
+        config["down_block_types"] = ["CrossAttnDownBlock3D"] * 3 + ["DownBlock3D"]
+        config["up_block_types"] = ["UpBlock3D"] + ["CrossAttnUpBlock3D"] * 3
+        model = cls.from_config(config, **(unet_additional_kwargs or {}))
+        model_file = os.path.join(pretrained_model_path, "diffusion_pytorch_model.bin")
+        if not os.path.isfile(model_file):
+            raise RuntimeError(f"{model_file} does not exist")
+        state_dict = torch.load(model_file, map_location="cpu")
+        m, u = model.load_state_dict(state_dict, strict=False)
+        print(f"### missing keys: {len(m)}; \n### unexpected keys: {len(u)};")
+        return model
+
+    # ------------------------------------------------------------------ weight packing
+    def _pack(self):
+        if self.device.type != "cuda":
+            return  # packed on the first .to('cuda'); the product path has no CPU execution
+        dev, dtp = self.device, self.dtype
+        m = {k: v.to(dev) for k, v in self._master.items()}
+        self._master = m
+        w = {}
+        V = ops.vec(dtp)
+
+        def lin(key):  # [N][K]
+            t = m[key]
+            return t.reshape(t.shape[0], -1).to(dtp).contiguous()
+
+        def f32(key):
+            return m[key].float().contiguous()
+
+        def conv3(key):  # OIHW -> [Cout][ky][kx][Cin_pad]
+            t = m[key]
+            co, ci = t.shape[0], t.shape[1]
+            cip = _round_up(ci, 8)
+            o = torch.zeros(co, 3, 3, cip, device=dev, dtype=torch.float32)
+            o[..., :ci] = t.permute(0, 2, 3, 1)
+            return o.reshape(co, 9 * cip).to(dtp).contiguous()
+
+        def geglu(prefix):  # interleave (32 value, 32 gate)
+            wt, b = m[prefix + ".weight"], m[prefix + ".bias"]
+            n = wt.shape[0] // 2
+            if n % 32:
+                raise EmoHipError("GEGLU width must be a multiple of 32")
+            wv, wg = wt[:n].reshape(n // 32, 32, -1), wt[n:].reshape(n // 32, 32, -1)
+            bv, bg = b[:n].reshape(n // 32, 32), b[n:].reshape(n // 32, 32)
+            return (torch.cat([wv, wg], 1).reshape(2 * n, -1).to(dtp).contiguous(),
+                    torch.cat([bv, bg], 1).reshape(2 * n).float().contiguous())
+
+        spec = self.spec
+        w["conv_in.w"], w["conv_in.b"] = conv3("conv_in.weight"), f32("conv_in.bias")
+        for n_ in ("linear_1", "linear_2"):
+            w[f"time_embedding.{n_}.w"], w[f"time_embedding.{n_}.b"] = lin(f"time_embedding.{n_}.weight"), f32(f"time_embedding.{n_}.bias")
+        half = spec.cfg["block_out_channels"][0] // 2
+        expo = -math.log(10000) * torch.arange(half, dtype=torch.float32) / (half - spec.cfg["freq_shift"])  # embeddings.py:47-51
+        w["time_freqs"] = torch.exp(expo).to(dev)
+        temb_w, temb_b, off = [], [], 0
+        self._temb_off = {}
+        for blk in spec.down + [spec.mid] + spec.up:
+            for r in blk.resnets:
+                p = r.prefix
+                w[p + ".norm1.g"], w[p + ".norm1.b"] = f32(p + ".norm1.weight"), f32(p + ".norm1.bias")
+                w[p + ".norm2.g"], w[p + ".norm2.b"] = f32(p + ".norm2.weight"), f32(p + ".norm2.bias")
+                w[p + ".conv1.w"], w[p + ".conv1.b"] = conv3(p + ".conv1.weight"), f32(p + ".conv1.bias")
+                w[p + ".conv2.w"], w[p + ".conv2.b"] = conv3(p + ".conv2.weight"), f32(p + ".conv2.bias")
+                if r.has_shortcut:
+                    w[p + ".sc.w"], w[p + ".sc.b"] = lin(p + ".conv_shortcut.weight"), f32(p + ".conv_shortcut.bias")
+                temb_w.append(m[p + ".time_emb_proj.weight"])
+                temb_b.append(m[p + ".time_emb_proj.bias"])
+                self._temb_off[p] = off
+                off += r.cout
+            for a in blk.attentions:
+                if a is None:
+                    continue
+                p = a.prefix
+                tb = p + ".transformer_blocks.0"
+                w[p + ".norm.g"], w[p + ".norm.b"] = f32(p + ".norm.weight"), f32(p + ".norm.bias")
+                w[p + ".proj_in.w"], w[p + ".proj_in.b"] = lin(p + ".proj_in.weight"), f32(p + ".proj_in.bias")
+                w[p + ".proj_out.w"], w[p + ".proj_out.b"] = lin(p + ".proj_out.weight"), f32(p + ".proj_out.bias")
+                for n_ in ("norm1", "norm2", "norm3"):
+                    w[f"{tb}.{n_}.g"], w[f"{tb}.{n_}.b"] = f32(f"{tb}.{n_}.weight"), f32(f"{tb}.{n_}.bias")
+                w[tb + ".attn1.qk"] = torch.cat([m[tb + ".attn1.to_q.weight"], m[tb + ".attn1.to_k.weight"]], 0).to(dtp).contiguous()
+                w[tb + ".attn1.k"] = lin(tb + ".attn1.to_k.weight")
+                w[tb + ".attn1.v"] = lin(tb + ".attn1.to_v.weight")
+                w[tb + ".attn1.o.w"], w[tb + ".attn1.o.b"] = lin(tb + ".attn1.to_out.0.weight"), f32(tb + ".attn1.to_out.0.bias")
+                w[tb + ".attn2.q"] = lin(tb + ".attn2.to_q.weight")
+                w[tb + ".attn2.k"] = lin(tb + ".attn2.to_k.weight")
+                w[tb + ".attn2.v"] = lin(tb + ".attn2.to_v.weight")
+                w[tb + ".attn2.o.w"], w[tb + ".attn2.o.b"] = lin(tb + ".attn2.to_out.0.weight"), f32(tb + ".attn2.to_out.0.bias")
+                w[tb + ".ff1.w"], w[tb + ".ff1.b"] = geglu(tb + ".ff.net.0.proj")
+                w[tb + ".ff2.w"], w[tb + ".ff2.b"] = lin(tb + ".ff.net.2.weight"), f32(tb + ".ff.net.2.bias")
+            for mo in blk.motions:
+                if mo is None:
+                    continue
+                p = mo.prefix + ".temporal_transformer"
+                tb = p + ".transformer_blocks.0"
+                w[p + ".norm.g"], w[p + ".norm.b"] = f32(p + ".norm.weight"), f32(p + ".norm.bias")
+                w[p + ".proj_in.w"], w[p + ".proj_in.b"] = lin(p + ".proj_in.weight"), f32(p + ".proj_in.bias")
+                w[p + ".proj_out.w"], w[p + ".proj_out.b"] = lin(p + ".proj_out.weight"), f32(p + ".proj_out.bias")
+                for k in range(mo.n_attn):
+                    ab = f"{tb}.attention_blocks.{k}"
+                    w[ab + ".qkv"] = torch.cat([m[ab + ".to_q.weight"], m[ab + ".to_k.weight"], m[ab + ".to_v.weight"]], 0).to(dtp).contiguous()
+                    w[ab + ".o.w"], w[ab + ".o.b"] = lin(ab + ".to_out.0.weight"), f32(ab + ".to_out.0.bias")
+                    w[f"{tb}.norms.{k}.g"], w[f"{tb}.norms.{k}.b"] = f32(f"{tb}.norms.{k}.weight"), f32(f"{tb}.norms.{k}.bias")
+                    if mo.pe_len:
+                        w[ab + ".pe"] = m[ab + ".pos_encoder.pe"][0].float().contiguous()
+                w[tb + ".ff_norm.g"], w[tb + ".ff_norm.b"] = f32(tb + ".ff_norm.weight"), f32(tb + ".ff_norm.bias")
+                w[tb + ".ff1.w"], w[tb + ".ff1.b"] = geglu(tb + ".ff.net.0.proj")
+                w[tb + ".ff2.w"], w[tb + ".ff2.b"] = lin(tb + ".ff.net.2.weight"), f32(tb + ".ff.net.2.bias")
+            if blk.sampler:
+                w[blk.sampler + ".w"], w[blk.sampler + ".b"] = conv3(blk.sampler + ".conv.weight"), f32(blk.sampler + ".conv.bias")
+        w["temb_all.w"] = torch.cat(temb_w, 0).to(dtp).contiguous()
+        w["temb_all.b"] = torch.cat(temb_b, 0).float().contiguous()
+        if spec.has_out:
+            w["conv_norm_out.g"], w["conv_norm_out.b"] = f32("conv_norm_out.weight"), f32("conv_norm_out.bias")
+            w["conv_out.w"], w["conv_out.b"] = conv3("conv_out.weight"), f32("conv_out.bias")
+        self._w = w
+
+    # ------------------------------------------------------------------ blocks (all HIP launches)
+    def _resnet(self, r, x, temb_all, c: _Ctx, H, W, scale=1.0):
+        """resnet.py:177-207.  GN statistics are JOINT over the F frames of a batch row (5-D GroupNorm)."""
+        w, p = self._w, r.prefix
+        G, eps = self.config["norm_num_groups"], self.config["norm_eps"]
+        n_img = c.B * c.F
+        h = ops.group_norm(x, w[p + ".norm1.g"], w[p + ".norm1.b"], c.B, G, eps, True)
+        off = self._temb_off[p]
+        h, _, _ = ops.conv3x3(h, w[p + ".conv1.w"], w[p + ".conv1.b"], n_img, H, W,
+                              rowbias=temb_all[:, off:off + r.cout], rows_per_batch=c.F * H * W)
+        h = ops.group_norm(h, w[p + ".norm2.g"], w[p + ".norm2.b"], c.B, G, eps, True, out=h)
+        sc = ops.gemm(x, w[p + ".sc.w"], w[p + ".sc.b"]) if r.has_shortcut else x
+        out, _, _ = ops.conv3x3(h, w[p + ".conv2.w"], w[p + ".conv2.b"], n_img, H, W, residual=sc, out_scale=1.0 / scale)
+        return out
+
+    def _kv(self, rows, wk, wv, L):
+        """K rows and V^T (per batch of L rows) projections of `rows` (nb*L, Cin)."""
+        k = ops.gemm(rows, wk)
+        vt = ops.gemm(rows, wv, transpose_rows=L, transpose_ld=_round_up(L, 8))
+        return k, vt
+
+    def _transformer(self, a, x, ctx_rows, ctx_len, ctx_div, c: _Ctx, H, W):
+        """attention.py:112-161 + 276-320, and the write/read hooks of mutual_self_attention.py:199-284."""
+        w, p = self._w, a.prefix
+        tb = p + ".transformer_blocks.0"
+        C_, heads = a.channels, a.heads
+        d = C_ // heads
+        HW, nb = H * W, c.B * c.F
+        scale = d ** -0.5
+        h = ops.group_norm(x, w[p + ".norm.g"], w[p + ".norm.b"], nb, self.config["norm_num_groups"], 1e-6, False)
+        h = ops.gemm(h, w[p + ".proj_in.w"], w[p + ".proj_in.b"])
+        # --- self attention (+ reference bank)
+        n1 = ops.layer_norm(h, w[tb + ".norm1.g"], w[tb + ".norm1.b"])
+        if c.bank_mode == "write" and p in c.active:
+            c.written[p] = n1  # LN1 output (mutual_self_attention.py:230)
+        qk = ops.gemm(n1, w[tb + ".attn1.qk"])
+        vt = ops.gemm(n1, w[tb + ".attn1.v"], transpose_rows=HW, transpose_ld=_round_up(HW, 8))
+        kw = {}
+        if c.bank_mode == "read" and p in c.active and p in c.banks:
+            bank = c.banks[p]
+            Lb = bank.shape[0] // c.bank_rows
+            kb, vbt = self._kv(bank, w[tb + ".attn1.k"], w[tb + ".attn1.v"], Lb)
+            kw = dict(k1=kb, v1t=vbt, Lk1=Lb, seg1_div=c.F, seg1_first_batch=c.uc_batches)
+        att = ops.attention(qk[:, :C_], qk[:, C_:], vt, HW, B=nb, Lq=HW, heads=heads, d=d, scale=scale, **kw)
+        h = ops.gemm(att, w[tb + ".attn1.o.w"], w[tb + ".attn1.o.b"], residual=h)
+        # --- cross attention to the text / audio context
+        n2 = ops.layer_norm(h, w[tb + ".norm2.g"], w[tb + ".norm2.b"])
+        q2 = ops.gemm(n2, w[tb + ".attn2.q"])
+        kc, vct = self._kv(ctx_rows, w[tb + ".attn2.k"], w[tb + ".attn2.v"], ctx_len)
+        att = ops.attention(q2, kc, vct, ctx_len, B=nb, Lq=HW, heads=heads, d=d, scale=scale, seg0_div=ctx_div)
+        h = ops.gemm(att, w[tb + ".attn2.o.w"], w[tb + ".attn2.o.b"], residual=h)
+        # --- GEGLU feed-forward
+        n3 = ops.layer_norm(h, w[tb + ".norm3.g"], w[tb + ".norm3.b"])
+        g = ops.gemm(n3, w[tb + ".ff1.w"], w[tb + ".ff1.b"], geglu=True)
+        h = ops.gemm(g, w[tb + ".ff2.w"], w[tb + ".ff2.b"], residual=h)
+        return ops.gemm(h, w[p + ".proj_out.w"], w[p + ".proj_out.b"], residual=x)
+
+    def _motion(self, mo, x, c: _Ctx, H, W):
+        """motion_module.py:139-163,215-227,275-334 (VanillaTemporalModule)."""
+        w = self._w
+        p = mo.prefix + ".temporal_transformer"
+        tb = p + ".transformer_blocks.0"
+        C_, heads = mo.channels, mo.heads
+        d = C_ // heads
+        HW, nb = H * W, c.B * c.F
+        if mo.pe_len and c.F > mo.pe_len:
+            raise ValueError(f"video_length {c.F} exceeds temporal_position_encoding_max_len {mo.pe_len}")
+        h = ops.group_norm(x, w[p + ".norm.g"], w[p + ".norm.b"], nb, 32, 1e-6, False)  # norm_num_groups=32 default (:104)
+        h = ops.gemm(h, w[p + ".proj_in.w"], w[p + ".proj_in.b"])
+        for k in range(mo.n_attn):
+            ab = f"{tb}.attention_blocks.{k}"
+            n = ops.layer_norm(h, w[f"{tb}.norms.{k}.g"], w[f"{tb}.norms.{k}.b"], pe=w.get(ab + ".pe"), rows_per_frame=HW, frames=c.F)
+            qkv = ops.gemm(n, w[ab + ".qkv"])
+            att = ops.temporal_attention(qkv, c.B, c.F, HW, heads, d, d ** -0.5)
+            h = ops.gemm(att, w[ab + ".o.w"], w[ab + ".o.b"], residual=h)
+        n = ops.layer_norm(h, w[tb + ".ff_norm.g"], w[tb + ".ff_norm.b"])
+        g = ops.gemm(n, w[tb + ".ff1.w"], w[tb + ".ff1.b"], geglu=True)
+        h = ops.gemm(g, w[tb + ".ff2.w"], w[tb + ".ff2.b"], residual=h)
+        return ops.gemm(h, w[p + ".proj_out.w"], w[p + ".proj_out.b"], residual=x)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None,
+                down_block_additional_residuals: Optional[Tuple[torch.Tensor]] = None,
+                mid_block_additional_residual: Optional[torch.Tensor] = None, return_dict: bool = True,
+                audio_features=None, speed_embeddings=None, _bank_ctx=None, _return_rows=False) -> Union[UNet3DConditionOutput, Tuple]:
+        """unet_controlnet.py:328-483.  sample (B,C,F,h,w); timestep Tensor|int|float;
+        encoder_hidden_states (B|B*F, L, D).  EMO extension kwargs (EMOAnimationPipeline.py:783-784):
+        audio_features (B*F, L_a, D) per-frame attn2 context; speed_embeddings (B, 4*C0) added to emb."""
+        if self._w is None:
+            raise EmoHipError("UNet3DConditionModel: weights not loaded / model not on a HIP device "
+                              "(load_state_dict + .to('cuda')); there is no CPU execution path")
+        if attention_mask is not None:
+            raise NotImplementedError("attention_mask is outside the hot path (always None in the pipeline)")
+        if class_labels is not None:
+            raise NotImplementedError("class embeddings are outside the hot path")
+        if sample.dim() != 5:
+            raise ValueError(f"Expected sample to have ndim=5, but got ndim={sample.dim()}.")
+        cfg, w, spec, dtp = self.config, self._w, self.spec, self.dtype
+        B, Cin, F, H, W = sample.shape
+        if Cin != cfg["in_channels"]:
+            raise ValueError(f"sample has {Cin} channels, expected {cfg['in_channels']}")
+        up = 2 ** self.num_upsamplers
+        if H % up or W % up:
+            raise NotImplementedError("sample H/W must be multiples of 2**num_upsamplers (upsample_size forwarding is not built)")
+        dev = self.device
+        c = _bank_ctx if _bank_ctx is not None else _Ctx(B, F, H, W)
+        c.B, c.F, c.H, c.W = B, F, H, W
+        rc = self._reference_control
+        if _bank_ctx is None and rc is not None:
+            rc._prepare(c, self)
+        sample = sample.to(dev)
+        if cfg["center_input_sample"]:
+            raise NotImplementedError("center_input_sample=True is outside the hot path (False in every shipped config)")
+        # time (unet_controlnet.py:376-398)
+        if not torch.is_tensor(timestep):
+            timesteps = torch.tensor([timestep], dtype=torch.int64, device=dev)
+        else:
+            timesteps = timestep.reshape(-1).to(device=dev, dtype=torch.int64)
+        timesteps = timesteps.expand(B).contiguous()
+        t_emb = ops.timestep_embedding(timesteps, w["time_freqs"], cfg["block_out_channels"][0], cfg["flip_sin_to_cos"], dtp)
+        e = ops.gemm(t_emb, w["time_embedding.linear_1.w"], w["time_embedding.linear_1.b"])
+        emb = ops.gemm(ops.silu(e), w["time_embedding.linear_2.w"], w["time_embedding.linear_2.b"])
+        if speed_embeddings is not None:  # EMO extension: class-embedding slot (unet_controlnet.py:400-408)
+            se = ops.convert(speed_embeddings.to(dev).float().reshape(B, -1), dtp)
+            emb = ops.add(emb, se)
+        temb_all = ops.convert(ops.gemm(ops.silu(emb), w["temb_all.w"], w["temb_all.b"]), torch.float32)
+        # context rows
+        ctx = encoder_hidden_states if audio_features is None else audio_features
+        ctx = ctx.to(dev)
+        if ctx.shape[0] == B * F:
+            ctx_div = 1
+        elif ctx.shape[0] == B:
+            ctx_div = F
+        else:
+            raise ValueError(f"encoder_hidden_states batch {ctx.shape[0]} is neither B={B} nor B*F={B * F}")
+        ctx_len = ctx.shape[1]
+        ctx_rows = ops.convert(ctx.float().reshape(-1, ctx.shape[2]), dtp)
+
+        x = ops.ncfhw_to_rows(sample, dtp, cpad=_round_up(Cin, 8))
+        x, _, _ = ops.conv3x3(x, w["conv_in.w"], w["conv_in.b"], B * F, H, W)
+        skips = [x]
+        h_, w_ = H, W
+        for blk in spec.down:
+            for r, a, mo in zip(blk.resnets, blk.attentions, blk.motions):
+                x = self._resnet(r, x, temb_all, c, h_, w_)
+                if a is not None:
+                    x = self._transformer(a, x, ctx_rows, ctx_len, ctx_div, c, h_, w_)
+                if mo is not None:
+                    x = self._motion(mo, x, c, h_, w_)
+                skips.append(x)
+            if blk.sampler:
+                x, h_, w_ = ops.conv3x3(x, w[blk.sampler + ".w"], w[blk.sampler + ".b"], B * F, h_, w_, stride=2)
+                skips.append(x)
+        if down_block_additional_residuals is not None and mid_block_additional_residual is not None:
+            new = []
+            for s, r in zip(skips, down_block_additional_residuals):  # unet_controlnet.py:430-439
+                new.append(ops.add(s, ops.ncfhw_to_rows(r.to(dev), dtp)))
+            skips = new
+        sc = cfg["mid_block_scale_factor"]
+        x = self._resnet(spec.mid.resnets[0], x, temb_all, c, h_, w_, sc)
+        x = self._transformer(spec.mid.attentions[0], x, ctx_rows, ctx_len, ctx_div, c, h_, w_)
+        if spec.mid.motions[0] is not None:
+            x = self._motion(spec.mid.motions[0], x, c, h_, w_)
+        x = self._resnet(spec.mid.resnets[1], x, temb_all, c, h_, w_, sc)
+        if down_block_additional_residuals is not None and mid_block_additional_residual is not None:
+            x = ops.add(x, ops.ncfhw_to_rows(mid_block_additional_residual.to(dev), dtp))
+        for blk in spec.up:
+            for r, a, mo in zip(blk.resnets, blk.attentions, blk.motions):
+                x = ops.concat_cols(x, skips.pop())  # unet_3d_blocks.py:627-629
+                x = self._resnet(r, x, temb_all, c, h_, w_)
+                if a is not None:
+                    x = self._transformer(a, x, ctx_rows, ctx_len, ctx_div, c, h_, w_)
+                if mo is not None:
+                    x = self._motion(mo, x, c, h_, w_)
+            if blk.sampler:
+                x, h_, w_ = ops.conv3x3(x, w[blk.sampler + ".w"], w[blk.sampler + ".b"], B * F, h_, w_, upsample2x=True)
+        if _bank_ctx is None and rc is not None:
+            rc._finish(c, self)
+        if not spec.has_out:
+            out = None
+        else:
+            x = ops.group_norm(x, w["conv_norm_out.g"], w["conv_norm_out.b"], B, cfg["norm_num_groups"], cfg["norm_eps"], True)
+            x, _, _ = ops.conv3x3(x, w["conv_out.w"], w["conv_out.b"], B * F, h_, w_)
+            if _return_rows:  # the sampler consumes NHWC rows directly (no layout round trip)
+                return x
+            out = ops.rows_to_ncfhw(x, B, cfg["out_channels"], F, h_, w_)
+        if not return_dict:
+            return (out,)
+        return UNet3DConditionOutput(sample=out)
+
+    __call__ = forward
+
+    # bank plumbing used by ReferenceAttentionControl / the pipeline
+    def bank_order(self, fusion_blocks="midup"):
+        return reference_block_order(self.spec, fusion_blocks)

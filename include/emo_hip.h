@@ -1,0 +1,167 @@
+/* emo_hip.h - C ABI of the MI355X (gfx950) kernels behind the Emote-hack diffusion hot path.
+ *
+ * The reference is Python calling Python: it has NO FFI for this path.
+ * The drop-in boundary is therefore the Python surface (UNet3DConditionModel /
+ * ReferenceAttentionControl / EMOAnimationPipeline, mirrored in emote_hack_amd/), and this
+ * header is the C ABI underneath it.  Each entry point names the reference ATen/xformers op
+ * (file:line under /root/reference) it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - plain pointers + sizes; no C++/torch types; every pointer is a DEVICE pointer unless
+ *     the name ends in _host.  Buffers are caller-owned and must stay alive until `stream`
+ *     has passed the call.
+ *   - activations are "rows x channels" row-major (NHWC: row = ((b*F+f)*H + y)*W + x); `ld*`
+ *     are leading dimensions in ELEMENTS.  Weights are [N][K] row-major (torch Linear layout;
+ *     conv weights re-laid once at load to [Cout][ky][kx][Cin]).
+ *   - dtype: EMO_F32 (validation mode: f32 MFMA, exact-f32 accumulate) or EMO_BF16
+ *     (production: bf16 MFMA, f32 accumulate).  Statistics / softmax / latents are always f32.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), never allocates,
+ *     never synchronises, keeps no global mutable state (re-entrant per stream).
+ *   - returns EMO_OK (0) or a negative emo_status; emo_last_error_string() describes the last
+ *     failure on the calling thread.
+ */
+#ifndef EMO_HIP_H
+#define EMO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { EMO_F32 = 0, EMO_BF16 = 1 } emo_dtype;
+
+typedef enum {
+  EMO_OK = 0,
+  EMO_ERR_BAD_SHAPE = -1,
+  EMO_ERR_BAD_DTYPE = -2,
+  EMO_ERR_UNSUPPORTED = -3,
+  EMO_ERR_HIP = -4,
+  EMO_ERR_NULL = -5
+} emo_status;
+
+int emo_version(void);
+const char* emo_last_error_string(void);
+
+/* ---- layout / elementwise ------------------------------------------------------------------ */
+
+/* (B,C,F,H,W) f32 -> rows ((b f) h w, ldo>=C) in `dtype`; channels [C, Cpad) are written as 0.
+ * Replaces einops "b c f h w -> (b f) c h w" + channels-last (resnet.py:33, attention.py:115). */
+int emo_ncfhw_to_rows(const float* x, void* y, int B, int C, int F, int H, int W, int Cpad, int ldo,
+                      int dtype, void* stream);
+/* rows -> (B,C,F,H,W) f32 (the UNet output boundary, unet_controlnet.py:478-483). */
+int emo_rows_to_ncfhw(const void* x, float* y, int B, int C, int F, int H, int W, int ldi, int dtype,
+                      void* stream);
+/* y[m, coff:coff+C] = x[m, 0:C]   (torch.cat along channels, unet_3d_blocks.py:629,731). */
+int emo_copy_cols(const void* x, int ldx, void* y, int ldy, int coff, int64_t M, int C, int dtype, void* stream);
+/* y = a + alpha*b elementwise over M x C (ControlNet residual adds, unet_controlnet.py:430-447). */
+int emo_add(const void* a, int lda, const void* b, int ldb, float alpha, void* y, int ldy, int64_t M, int C,
+            int dtype, void* stream);
+/* dtype conversion of a contiguous buffer (src f32 <-> dst dtype); fp16_round!=0 rounds through IEEE
+ * half first (bank hand-off, mutual_self_attention.py:588 `.to(float16)`). */
+int emo_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, int fp16_round, void* stream);
+/* y = silu(x) over n contiguous elements (F.silu(temb), resnet.py:186). */
+int emo_silu(const void* x, void* y, int64_t n, int dtype, void* stream);
+
+/* sinusoidal timestep embedding (embeddings.py:28-68 get_timestep_embedding): out[b] =
+ * [sin | cos](t_b * freqs) (flipped to [cos | sin] if flip_sin_to_cos).  `freqs` f32 [dim/2] is the
+ * constant table exp(-ln(1e4)*arange(half)/(half - freq_shift)) built once by the host; the integer
+ * timestep is consumed bit-exactly. */
+int emo_timestep_embedding(const int64_t* timesteps, const float* freqs, void* out, int B, int dim,
+                           int flip_sin_to_cos, int dtype, void* stream);
+
+/* ---- normalisation ---------------------------------------------------------------------------
+ * GroupNorm over NHWC rows.  An "instance" is a contiguous run of S rows normalised together:
+ *   5-D joint statistics (resnet.py:180,191; unet_controlnet.py:476): N=B,   S=F*H*W
+ *   per-frame            (attention.py:124; motion_module.py:147)   : N=B*F, S=H*W
+ * emo_groupnorm_stats writes (mean, rstd) f32 pairs [N][G][2]; `partials` is a caller workspace of
+ * emo_groupnorm_workspace_bytes(N, S, C, G) bytes.  emo_groupnorm_apply normalises (+SiLU). */
+size_t emo_groupnorm_workspace_bytes(int N, int64_t S, int C, int G);
+int emo_groupnorm_stats(const void* x, int ldx, float* stats, void* partials, int N, int64_t S, int C, int G,
+                        float eps, int dtype, void* stream);
+int emo_groupnorm_apply(const void* x, int ldx, const float* stats, const float* gamma, const float* beta,
+                        void* y, int ldy, int N, int64_t S, int C, int G, int silu, int dtype, void* stream);
+
+/* LayerNorm over the last dim (attention.py:279-316, motion_module.py:216-224), eps 1e-5 default.
+ * Optional fused temporal positional-encoding add (motion_module.py:246-248,282-283):
+ * y[row] += pe[frame(row)] with frame(row) = (row / rows_per_frame) % frames, pe f32 [max_len][C]. */
+int emo_layernorm(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, int64_t M,
+                  int C, float eps, const float* pe, int rows_per_frame, int frames, int dtype, void* stream);
+
+/* ---- GEMM / convolution (MFMA) ----------------------------------------------------------------
+ * C[M,N] = epilogue( A[M,K] . W[N,K]^T ).  Replaces F.linear / 1x1 conv (orig_attention.py:566-575,
+ * 776,817; attention.py:82,110; resnet.py:175) and, with conv geometry, the per-frame 3x3 conv
+ * (resnet.py:30-38 InflatedConv3d).  Epilogue, in order:
+ *   + bias[N]  (f32, may be NULL)
+ *   + rowbias[(m / rows_per_batch)][N] (f32; the `+ temb[:, :, None, None, None]` of resnet.py:188)
+ *   GEGLU: W rows are interleaved (32 value rows, 32 gate rows) per 32 outputs -> out[m,j] = v*gelu_erf(g),
+ *          N_out = N/2 (orig_attention.py:825-827)
+ *   + residual[M, N_out] (resnet.py:205, attention.py:292-317)        * out_scale
+ *   store: row-major (ldc) or TRANSPOSED per batch: Ct[(m / t_rows)][n][m % t_rows] with ld t_ld
+ *          (the V^T layout the attention kernels consume). */
+typedef struct {
+  const void* A; int64_t lda;
+  const void* W;              /* [N][K] (K = taps*Cin for conv) */
+  const float* bias;
+  const float* rowbias; int rows_per_batch; int ld_rowbias;
+  const void* residual; int64_t ldr;
+  void* C; int64_t ldc;
+  int64_t M; int N; int K;
+  int geglu;
+  float out_scale;
+  int transpose_out; int t_rows; int64_t t_ld; int64_t t_batch_stride;
+  /* conv geometry (conv_taps==9 -> implicit 3x3 GEMM over NHWC A; 0 -> dense) */
+  int conv_taps; int H; int W_; int Cin; int stride; int upsample2x; int Ho; int Wo;
+  int dtype;
+} emo_gemm_params;
+int emo_gemm(const emo_gemm_params* p, void* stream);
+
+/* ---- attention -------------------------------------------------------------------------------
+ * Flash-style softmax(q k^T * scale) v, scores never leave the chip.  Replaces
+ * CrossAttention._attention (orig_attention.py:655-684) and xformers.memory_efficient_attention
+ * (models/motionmodule.py:300, models/videonet.py:62,117).
+ *   q  : [B*Lq][ldq] rows, head h at columns h*d
+ *   k0 : [B*Lk0][ldk0] rows (self / context keys of batch b)
+ *   v0t: V^T [B][heads*d][ldv0t] (keys contiguous, ldv0t >= Lk0, multiple of 8)
+ *   k1/v1t: optional second KV segment shared by `seg1_div` consecutive batches (the ReferenceNet
+ *           bank repeated over frames, mutual_self_attention.py:238-241): batch b reads bank row
+ *           b / seg1_div; batches b < seg1_first_batch skip it (uc rows, :243-256). */
+typedef struct {
+  const void* q; int64_t ldq;
+  const void* k0; int64_t ldk0; const void* v0t; int64_t ldv0t; int Lk0;
+  const void* k1; int64_t ldk1; const void* v1t; int64_t ldv1t; int Lk1;
+  int seg0_div;   /* batch b reads k0/v0t row-block b / seg0_div (1 = per-batch keys; F = a text context
+                     shared by the F frames of a clip, attention.py:118-119 without the repeat) */
+  int seg1_div; int seg1_first_batch;
+  void* out; int64_t ldo;
+  int B; int Lq; int heads; int d;
+  float scale;
+  int dtype;
+} emo_attention_params;
+int emo_attention(const emo_attention_params* p, void* stream);
+
+/* Temporal self-attention of the AnimateDiff motion module (motion_module.py:275-334): tokens
+ * "(b f) d c -> (b d) f c"; qkv rows are [(b*F+f)*HW + pix][3*C] (q|k|v), output [(b*F+f)*HW+pix][C].
+ * F <= 32.  The transposes are folded into the indexing. */
+int emo_temporal_attention(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, int B, int F, int HW,
+                           int heads, int d, float scale, int dtype, void* stream);
+
+/* ---- sampler -------------------------------------------------------------------------------
+ * Fused window-average + classifier-free guidance + scheduler step
+ * (EMOAnimationPipeline.py:812-817):  eps = uc + s*(c - uc) on noise_pred/counter;
+ * x <- c_x*x + c_eps*eps + c_noise*z,  z = counter-based N(0,1) keyed by (seed, step, element).
+ * noise_pred f32 [2][n] (uc, c), counter f32 per frame [F] broadcast over (C, H*W): element
+ * (c, f, p) has index (c*F + f)*HW + p.  latents f32 [n], updated in place; eps_out optional. */
+int emo_cfg_step(const float* noise_pred, const float* counter, float* latents, float* eps_out, int C, int F,
+                 int HW, float guidance_scale, float c_x, float c_eps, float c_noise, uint32_t seed, uint32_t step,
+                 void* stream);
+/* noise_pred[branch, :, frames[j]] += pred rows; counter[frames[j]] += 1 (EMOAnimationPipeline.py:790-794).
+ * pred: rows ((j) h w, ld) in dtype for ONE branch of ONE window; frames: device int32 [nf]. */
+int emo_accumulate_window(const void* pred, int ld, float* noise_pred_branch, float* counter, const int32_t* frames,
+                          int nf, int C, int F, int HW, int add_counter, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMO_HIP_H */

@@ -1,0 +1,281 @@
+"""GPU parity tests, kernel level: every C-ABI entry point vs a plain torch fp32 CPU statement of the
+same op (the oracle's primitives), f32 mode at rtol 1e-3 / atol 1e-4 (north_star) and bf16 mode at a
+measured, looser tolerance vs the SAME fp32 reference (bf16 has 8 mantissa bits; the reference's own
+bf16 path misses 1e-3 by >10x - SURVEY.md section 7).  Calls go through emote_hack_amd.ops -> ctypes ->
+libemo_hip.so."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from emote_hack_amd.synth import seeded_randn
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+TOL = {torch.float32: dict(rtol=1e-3, atol=1e-4), torch.bfloat16: dict(rtol=3e-2, atol=3e-2)}
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def ops():
+    from emote_hack_amd import ops as o
+    return o
+
+
+def q(t, dtype):
+    """quantise a CPU fp32 tensor to the compute dtype's grid (inputs are identical on both sides)."""
+    return t.to(dtype).float()
+
+
+def close(got, ref, dtype, scale=1.0):
+    tol = TOL[dtype]
+    torch.testing.assert_close(got.float().cpu(), ref, rtol=tol["rtol"], atol=tol["atol"] * scale)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layout_roundtrip_and_concat(dtype):
+    o = ops()
+    x = q(seeded_randn((2, 5, 3, 6, 10), 1), dtype)
+    rows = o.ncfhw_to_rows(x.to(DEV), dtype, cpad=8)
+    ref = x.permute(0, 2, 3, 4, 1).reshape(-1, 5)
+    close(rows[:, :5], ref, dtype)
+    assert float(rows[:, 5:].float().abs().max()) == 0.0
+    back = o.rows_to_ncfhw(rows[:, :5], 2, 5, 3, 6, 10)
+    close(back, x, dtype)
+    a, b = q(seeded_randn((37, 16), 2), dtype), q(seeded_randn((37, 24), 3), dtype)
+    cat = o.concat_cols(a.to(DEV).to(dtype), b.to(DEV).to(dtype))
+    close(cat, torch.cat([a, b], 1), dtype)
+    s = o.add(a.to(DEV).to(dtype), a.to(DEV).to(dtype), alpha=0.5)
+    close(s, a * 1.5, dtype)
+
+
+def test_convert_fp16_round_and_silu():
+    o = ops()
+    x = seeded_randn((1000,), 4) * 3
+    y = o.convert(x.to(DEV), torch.float32, fp16_round=True)
+    assert torch.equal(y.cpu(), x.half().float())  # bit-exact IEEE half rounding
+    yb = o.convert(x.to(DEV), torch.bfloat16)
+    assert torch.equal(yb.cpu().float(), x.bfloat16().float())
+    close(o.silu(x.to(DEV)), F.silu(x), torch.float32)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_timestep_embedding(dtype):
+    o = ops()
+    from oracle.unet_ref import timestep_embedding
+    ts = torch.tensor([981, 1, 500, 0, 999])
+    half = 160
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+    got = o.timestep_embedding(ts.to(DEV), freqs.to(DEV), 320, True, dtype)
+    close(got, timestep_embedding(ts, 320, True, 0), dtype, scale=0.5 if dtype == torch.float32 else 1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,S,C,G,silu", [(2, 4 * 64, 320, 32, True), (6, 100, 64, 8, False), (1, 12 * 16 * 16, 2560, 32, True),
+                                          (3, 33, 1280, 32, True)])
+def test_groupnorm(dtype, N, S, C, G, silu):
+    o = ops()
+    x = q(seeded_randn((N * S, C), 5) * 2 + 0.5, dtype)
+    g, b = 1 + 0.1 * seeded_randn((C,), 6), 0.1 * seeded_randn((C,), 7)
+    ref = F.group_norm(x.reshape(N, S, C).permute(0, 2, 1), G, g, b, 1e-5).permute(0, 2, 1).reshape(N * S, C)
+    if silu:
+        ref = F.silu(ref)
+    got = o.group_norm(x.to(DEV).to(dtype), g.to(DEV), b.to(DEV), N, G, 1e-5, silu)
+    close(got, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C,pe", [(100, 320, False), (2 * 3 * 16, 64, True), (77, 1280, False), (12 * 4, 640, True)])
+def test_layernorm(dtype, M, C, pe):
+    o = ops()
+    x = q(seeded_randn((M, C), 8) * 2 + 0.3, dtype)
+    g, b = 1 + 0.1 * seeded_randn((C,), 9), 0.1 * seeded_randn((C,), 10)
+    ref = F.layer_norm(x, (C,), g, b)
+    pe_t = None
+    if pe:
+        frames, rpf = 3, M // 6   # rows = 2 batches x 3 frames x rpf pixels
+        pe_t = seeded_randn((24, C), 11)
+        fr = (torch.arange(M) // rpf) % frames
+        ref = q(ref, dtype) + pe_t[fr]
+    got = o.layer_norm(x.to(DEV).to(dtype), g.to(DEV), b.to(DEV), pe=pe_t.to(DEV) if pe else None,
+                       rows_per_frame=rpf if pe else 0, frames=frames if pe else 0)
+    close(got, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (128, 128, 64), (77, 1280, 768), (2, 1280, 320), (1000, 96, 2560)])
+def test_gemm_bias_residual(dtype, M, N, K):
+    o = ops()
+    a, w = q(seeded_randn((M, K), 12), dtype), q(seeded_randn((N, K), 13) / math.sqrt(K), dtype)
+    bias, res = 0.1 * seeded_randn((N,), 14), q(seeded_randn((M, N), 15), dtype)
+    ref = (F.linear(a, w, bias) + res) * 0.5
+    got = o.gemm(a.to(DEV).to(dtype), w.to(DEV).to(dtype), bias.to(DEV), residual=res.to(DEV).to(dtype), out_scale=0.5)
+    close(got, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_asymmetric_identity(dtype):
+    """A = I with an asymmetric W catches a transposed C-write (guide: always A=I-check with asymmetric B)."""
+    o = ops()
+    K = 128
+    a = torch.eye(K)
+    w = q(seeded_randn((192, K), 16), dtype)
+    got = o.gemm(a.to(DEV).to(dtype), w.to(DEV).to(dtype))
+    close(got, w.t().contiguous(), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_rowbias_geglu_transpose(dtype):
+    o = ops()
+    M, K, No = 2 * 96, 64, 128
+    a = q(seeded_randn((M, K), 17), dtype)
+    w, bias = q(seeded_randn((2 * No, K), 18) / 8, dtype), 0.1 * seeded_randn((2 * No,), 19)
+    hv, gate = F.linear(a, w, bias).chunk(2, dim=-1)
+    ref = hv * F.gelu(gate)
+    wi = torch.cat([w[:No].reshape(No // 32, 32, K), w[No:].reshape(No // 32, 32, K)], 1).reshape(2 * No, K)
+    bi = torch.cat([bias[:No].reshape(No // 32, 32), bias[No:].reshape(No // 32, 32)], 1).reshape(2 * No)
+    got = o.gemm(a.to(DEV).to(dtype), wi.to(DEV).to(dtype).contiguous(), bi.to(DEV).contiguous(), geglu=True)
+    close(got, ref, dtype)
+    # row bias (temb) per batch of 96 rows
+    rb = seeded_randn((2, 2 * No), 20)
+    ref2 = F.linear(a, w) + rb.repeat_interleave(96, 0)
+    got2 = o.gemm(a.to(DEV).to(dtype), w.to(DEV).to(dtype), None, rowbias=rb.to(DEV), rows_per_batch=96)
+    close(got2, ref2, dtype)
+    # V^T store: (M/L, N, ld)
+    L = 48
+    got3 = o.gemm(a.to(DEV).to(dtype), w.to(DEV).to(dtype), transpose_rows=L, transpose_ld=48)
+    ref3 = F.linear(a, w).reshape(M // L, L, 2 * No).permute(0, 2, 1)
+    close(got3[:, :, :L], ref3, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,H,W,Cin,Cout,stride,up", [(3, 8, 8, 32, 64, 1, False), (2, 16, 12, 64, 32, 2, False),
+                                                      (2, 4, 6, 64, 64, 1, True), (1, 16, 16, 8, 320, 1, False),
+                                                      (2, 8, 8, 320, 4, 1, False), (1, 6, 6, 960, 320, 1, False)])
+def test_conv3x3(dtype, n, H, W, Cin, Cout, stride, up):
+    o = ops()
+    x = q(seeded_randn((n, Cin, H, W), 21), dtype)
+    wt, bias = q(seeded_randn((Cout, Cin, 3, 3), 22) / math.sqrt(9 * Cin), dtype), 0.1 * seeded_randn((Cout,), 23)
+    xi = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    ref = F.conv2d(xi, wt, bias, stride=stride, padding=1)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, Cin)
+    wp = wt.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)
+    got, Ho, Wo = o.conv3x3(rows.to(DEV).to(dtype), wp.to(DEV).to(dtype).contiguous(), bias.to(DEV), n, H, W, stride=stride,
+                            upsample2x=up)
+    assert (Ho, Wo) == tuple(ref.shape[-2:])
+    close(got, ref.permute(0, 2, 3, 1).reshape(-1, Cout), dtype)
+
+
+def attn_ref(qh, k, v, scale):
+    s = torch.matmul(qh, k.transpose(-1, -2)) * scale
+    return torch.matmul(s.softmax(-1), v)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,Lq,Lk,heads,d", [(2, 64, 64, 8, 40), (3, 100, 77, 4, 80), (2, 256, 256, 2, 160), (4, 16, 16, 4, 8),
+                                             (1, 200, 333, 8, 16), (2, 130, 5, 8, 64)])
+def test_attention_single_segment(dtype, B, Lq, Lk, heads, d):
+    o = ops()
+    C_ = heads * d
+    qq, kk, vv = (q(seeded_randn((B, L, C_), s), dtype) for L, s in ((Lq, 24), (Lk, 25), (Lk, 26)))
+    sp = lambda t: t.reshape(B, -1, heads, d).permute(0, 2, 1, 3)
+    ref = attn_ref(sp(qq), sp(kk), sp(vv), d ** -0.5).permute(0, 2, 1, 3).reshape(B * Lq, C_)
+    ld = (Lk + 7) // 8 * 8
+    vt = torch.full((B, C_, ld), float("nan"))
+    vt[:, :, :Lk] = vv.permute(0, 2, 1)
+    got = o.attention(qq.reshape(-1, C_).to(DEV).to(dtype), kk.reshape(-1, C_).to(DEV).to(dtype), vt.to(DEV).to(dtype), Lk, B=B,
+                      Lq=Lq, heads=heads, d=d, scale=d ** -0.5)
+    close(got, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_bank_segment_and_shared_context(dtype):
+    """Reference read path: K/V = cat([x, bank repeated over F]) for c rows, plain self-attention for
+    uc rows (mutual_self_attention.py:238-256); text context shared by the F frames (attention.py:118)."""
+    o = ops()
+    Bc, Fr, L, heads, d, Lb = 2, 3, 48, 4, 40, 80
+    C_ = heads * d
+    nb = Bc * Fr
+    qq, kk, vv = (q(seeded_randn((nb, L, C_), s), dtype) for s in (27, 28, 29))
+    bk, bv = q(seeded_randn((Bc, Lb, C_), 30), dtype), q(seeded_randn((Bc, Lb, C_), 31), dtype)
+    sp = lambda t: t.reshape(t.shape[0], -1, heads, d).permute(0, 2, 1, 3)
+    refs = []
+    for b in range(nb):
+        k_, v_ = kk[b:b + 1], vv[b:b + 1]
+        if b >= Fr:  # second half = conditional rows
+            k_ = torch.cat([k_, bk[b // Fr:b // Fr + 1]], 1)
+            v_ = torch.cat([v_, bv[b // Fr:b // Fr + 1]], 1)
+        refs.append(attn_ref(sp(qq[b:b + 1]), sp(k_), sp(v_), d ** -0.5).permute(0, 2, 1, 3).reshape(L, C_))
+    ref = torch.cat(refs)
+    dv = lambda t: t.to(DEV).to(dtype)
+    got = o.attention(dv(qq.reshape(-1, C_)), dv(kk.reshape(-1, C_)), dv(vv.permute(0, 2, 1).contiguous()), L, B=nb, Lq=L,
+                      heads=heads, d=d, scale=d ** -0.5, k1=dv(bk.reshape(-1, C_)), v1t=dv(bv.permute(0, 2, 1).contiguous()),
+                      Lk1=Lb, seg1_div=Fr, seg1_first_batch=Fr)
+    close(got, ref, dtype)
+    # shared context: batch b reads context row b // Fr
+    ck, cv = q(seeded_randn((Bc, 7, C_), 32), dtype), q(seeded_randn((Bc, 7, C_), 33), dtype)
+    ref2 = torch.cat([attn_ref(sp(qq[b:b + 1]), sp(ck[b // Fr:b // Fr + 1]), sp(cv[b // Fr:b // Fr + 1]), d ** -0.5)
+                      .permute(0, 2, 1, 3).reshape(L, C_) for b in range(nb)])
+    vt = torch.zeros(Bc, C_, 8)
+    vt[:, :, :7] = cv.permute(0, 2, 1)
+    got2 = o.attention(dv(qq.reshape(-1, C_)), dv(ck.reshape(-1, C_)), dv(vt), 7, B=nb, Lq=L, heads=heads, d=d, scale=d ** -0.5,
+                       seg0_div=Fr)
+    close(got2, ref2, dtype)
+
+
+def test_attention_online_softmax_rescale_forced():
+    """Spike one key late in the sequence so the running max jumps in a later KV tile (rescale branch)."""
+    o = ops()
+    B, L, heads, d = 1, 192, 1, 64
+    qq, kk, vv = seeded_randn((B, L, d), 34), seeded_randn((B, L, d), 35), seeded_randn((B, L, d), 36)
+    kk[0, 150] = qq[0, 10] * 4.0
+    ref = attn_ref(qq[:, None], kk[:, None], vv[:, None], d ** -0.5).reshape(L, d)
+    got = o.attention(qq.reshape(-1, d).to(DEV), kk.reshape(-1, d).to(DEV), vv.permute(0, 2, 1).contiguous().to(DEV), L, B=B, Lq=L,
+                      heads=heads, d=d, scale=d ** -0.5)
+    close(got, ref, torch.float32)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,Fr,HW,heads,d", [(2, 4, 16, 4, 16), (1, 12, 64, 8, 40), (2, 12, 4, 8, 160), (1, 24, 9, 8, 80)])
+def test_temporal_attention(dtype, B, Fr, HW, heads, d):
+    o = ops()
+    C_ = heads * d
+    qkv = q(seeded_randn((B * Fr * HW, 3 * C_), 37), dtype)
+    t = qkv.reshape(B, Fr, HW, 3, heads, d).permute(3, 0, 2, 4, 1, 5)  # (3, B, HW, heads, F, d)
+    ref = attn_ref(t[0], t[1], t[2], d ** -0.5)  # (B, HW, heads, F, d)
+    ref = ref.permute(0, 3, 1, 2, 4).reshape(B * Fr * HW, C_)
+    got = o.temporal_attention(qkv.to(DEV).to(dtype), B, Fr, HW, heads, d, d ** -0.5)
+    close(got, ref, dtype)
+
+
+def test_cfg_step_and_accumulate():
+    o = ops()
+    from oracle.scheduler_ref import SchedulerRef, counter_normal
+    C4, Ft, HW = 4, 6, 20
+    npred = seeded_randn((2, C4, Ft, HW), 38)
+    counter = torch.tensor([1.0, 2, 1, 3, 1, 2])
+    lat = seeded_randn((C4 * Ft * HW,), 39)
+    for kind, t in (("ddim", 501), ("ddpm", 500), ("ddpm", 0)):
+        sch = SchedulerRef(kind)
+        sch.set_timesteps(50)
+        cx, ce, cn = sch.coefficients(t)
+        avg = npred / counter.view(1, 1, Ft, 1)
+        eps = avg[0] + 7.5 * (avg[1] - avg[0])
+        z = counter_normal(3, 7, lat.numel())
+        ref = cx * lat + ce * eps.reshape(-1) + cn * z
+        l_dev, e_dev = lat.clone().to(DEV), torch.empty(lat.numel(), device=DEV)
+        o.cfg_step(npred.to(DEV), counter.to(DEV), l_dev, C_=C4, F=Ft, HW=HW, guidance_scale=7.5, c_x=cx, c_eps=ce, c_noise=cn,
+                   seed=3, step=7, eps_out=e_dev)
+        torch.testing.assert_close(e_dev.cpu(), eps.reshape(-1), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(l_dev.cpu(), ref, rtol=1e-4, atol=1e-4)
+    # window accumulate
+    pred = seeded_randn((3 * HW, C4), 40)
+    acc = torch.zeros(C4, Ft, HW, device=DEV)
+    cnt = torch.zeros(Ft, device=DEV)
+    frames = torch.tensor([4, 5, 0], dtype=torch.int32, device=DEV)
+    o.accumulate_window(pred.to(DEV), acc, cnt, frames, C_=C4, F=Ft, HW=HW, add_counter=True)
+    ref = torch.zeros(C4, Ft, HW)
+    ref[:, [4, 5, 0]] = pred.reshape(3, HW, C4).permute(2, 0, 1)
+    torch.testing.assert_close(acc.cpu(), ref)
+    assert cnt.cpu().tolist() == [1, 0, 0, 0, 1, 1]

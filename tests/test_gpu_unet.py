@@ -1,0 +1,154 @@
+"""GPU parity tests, model level: the HIP UNet / ReferenceNet / sampling loop vs (a) golden vectors
+captured from the reference (tests/golden) and (b) the CPU oracle on seeded inputs.
+f32 mode: rtol 1e-3 / atol 1e-4 (north_star).  bf16 mode: vs the same fp32 goldens with the measured
+yard-stick of SURVEY.md section 7 (reference's own bf16-vs-fp32: max-abs 1.9e-2, mean-abs 3.2e-3 at
+output mean-abs 0.32)."""
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from emote_hack_amd.synth import seeded_randn, synth_state_dict
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+G = cases.GOLDEN_DIR
+DEV = "cuda"
+
+
+def build(cfg, dtype, prefix="", cls=None, has_out=True):
+    from emote_hack_amd.unet import UNet3DConditionModel
+    from emote_hack_amd.spec import build_spec, param_shapes
+    cls = cls or UNet3DConditionModel
+    m = cls(**cfg) if has_out else cls(**cfg, _has_out=False)
+    sd = synth_state_dict(param_shapes(m.spec), prefix=prefix)
+    m.load_state_dict(sd)
+    return m.to(DEV, dtype)
+
+
+def check(got, ref, dtype):
+    got = got.float().cpu()
+    if dtype == torch.float32:
+        torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-4)
+    else:
+        err = (got - ref).abs()
+        assert float(err.max()) < 8e-2 and float(err.mean()) < 1e-2, (float(err.max()), float(err.mean()))
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    return load_file(os.path.join(G, "unet_tiny.safetensors"))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_unet_tiny_plain(tiny, dtype):
+    x, ctx = cases.tiny_inputs(2, 4)
+    m = build(cases.TINY, dtype)
+    check(m(x[:, :, :2].to(DEV), 981, ctx.to(DEV)).sample, tiny["plain/out"], dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_unet_tiny_motion(tiny, dtype):
+    x, ctx = cases.tiny_inputs(2, 4)
+    m = build(cases.TINY_MOTION, dtype)
+    check(m(x.to(DEV), torch.tensor(961), ctx.to(DEV)).sample, tiny["motion/out"], dtype)
+
+
+def test_unet_tiny_linear_projection(tiny):
+    x, ctx = cases.tiny_inputs(2, 4)
+    m = build(cases.TINY_LINEAR, torch.float32)
+    check(m(x.to(DEV), 500, ctx.to(DEV), return_dict=False)[0], tiny["linear/out"], torch.float32)
+
+
+def test_unet_tiny_controlnet_residuals(tiny):
+    from tests.test_oracle_golden import ctrl_residuals
+    x, ctx = cases.tiny_inputs(2, 4)
+    down_res, mid_res = ctrl_residuals()
+    m = build(cases.TINY_MOTION, torch.float32)
+    y = m(x.to(DEV), 961, ctx.to(DEV), down_block_additional_residuals=tuple(r.to(DEV) for r in down_res),
+          mid_block_additional_residual=mid_res.to(DEV)).sample
+    check(y, tiny["motion/out_ctrl"], torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_reference_write_read(tiny, dtype):
+    """ReferenceNet write -> fp16-rounded banks -> Backbone read with CFG batch 2."""
+    from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
+    from emote_hack_amd.reference_control import ReferenceAttentionControl
+    x, ctx = cases.tiny_inputs(2, 4)
+    ref = build(cases.TINY, dtype, cases.REF_PREFIX, cls=AppearanceEncoderModel, has_out=False)
+    unet = build(cases.TINY_MOTION, dtype)
+    writer = ReferenceAttentionControl(ref, do_classifier_free_guidance=True, mode="write", batch_size=1)
+    reader = ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", batch_size=1)
+    ref_lat = seeded_randn((1, 4, 16, 16), 3).repeat(2, 1, 1, 1)
+    ref(ref_lat.to(DEV), 961, encoder_hidden_states=ctx.to(DEV), return_dict=False)
+    for i, p in enumerate(writer.order):
+        check(writer.bank[p][0], tiny[f"banks/{i}"], dtype)
+    reader.update(writer)
+    y = unet(x.to(DEV), 961, ctx.to(DEV)).sample
+    reader.clear()
+    check(y, tiny["read/out"], dtype)
+    if dtype == torch.float32:  # uc rows equal the no-bank run
+        torch.testing.assert_close(y[:1].cpu(), tiny["motion/out"][:1], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("kind", ["ddim", "ddpm"])
+def test_denoise_loop_vs_golden(kind):
+    """3 steps, 8 frames in overlapping windows of 4 - the loop of EMOAnimationPipeline.py:698-823."""
+    from emote_hack_amd import DDIMScheduler, DDPMScheduler
+    from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
+    from emote_hack_amd.pipeline import EMOAnimationPipeline
+    g = load_file(os.path.join(G, "loop_tiny.safetensors"))
+    ref = build(cases.TINY, torch.float32, cases.REF_PREFIX, cls=AppearanceEncoderModel, has_out=False)
+    unet = build(cases.TINY_MOTION, torch.float32)
+    sch = DDIMScheduler() if kind == "ddim" else DDPMScheduler()
+    pipe = EMOAnimationPipeline(unet=unet, scheduler=sch)
+    lat, eps = pipe.denoise(seeded_randn((1, 4, 8, 16, 16), 5).to(DEV), seeded_randn((1, 4, 16, 16), 3), seeded_randn((2, 5, 32), 2),
+                            appearance_encoder=ref, num_inference_steps=3, guidance_scale=7.5, context_frames=4,
+                            context_stride=1, context_overlap=2, seed=0, return_eps=True)
+    for i in range(3):
+        torch.testing.assert_close(eps[i].cpu(), g[f"{kind}/eps{i}"], rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(lat.cpu(), g[f"{kind}/latents"], rtol=2e-3, atol=2e-4)
+
+
+def test_pipeline_call_signature_and_errors():
+    from emote_hack_amd import DDIMScheduler
+    from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
+    from emote_hack_amd.pipeline import EMOAnimationPipeline
+    ref = build(cases.TINY, torch.float32, cases.REF_PREFIX, cls=AppearanceEncoderModel, has_out=False)
+    unet = build(cases.TINY_MOTION, torch.float32)
+    pipe = EMOAnimationPipeline(None, None, None, unet, None, DDIMScheduler())
+    with pytest.raises(ValueError):
+        pipe("", 4, height=130, width=128, appearance_encoder=ref)
+    out = pipe("", 4, height=128, width=128, num_inference_steps=2, appearance_encoder=ref, context_frames=4,
+               init_latents=seeded_randn((4, 4, 16, 16), 5), text_embeddings=seeded_randn((2, 5, 32), 2),
+               ref_image_latents=seeded_randn((1, 4, 16, 16), 3), output_type="latent")
+    assert tuple(out.videos.shape) == (1, 4, 4, 16, 16) and bool(torch.isfinite(out.videos).all())
+
+
+def test_cfg1_baseline_config1():
+    """BASELINE.json configs[0]: UNet from configs/unet-config.yaml:default, (1,4,1,32,32), t=981."""
+    path = os.path.join(G, "cfg1.safetensors")
+    cfg = dict(cases.SD15, norm_num_groups=4)
+    m = build(cfg, torch.float32)
+    y = m(seeded_randn((1, 4, 1, 32, 32), 1).to(DEV), 981, seeded_randn((1, 77, 768), 2).to(DEV)).sample
+    check(y, load_file(path)["cfg1/out"], torch.float32)
+
+
+def test_unet_vs_oracle_medium_size_properties():
+    """A size the goldens do not hold (SD-1.5 widths at 16x16 latent, F=3, heads of 40/80/160): HIP f32
+    vs the CPU oracle on the same seeded inputs; plus frame-permutation equivariance without motion
+    modules is NOT expected (5-D GroupNorm couples frames) but batch rows must be independent."""
+    from oracle import unet_ref as U
+    from emote_hack_amd.spec import build_spec, param_shapes
+    cfg = dict(cases.SD15_MOTION, block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock3D", "DownBlock3D"),
+               up_block_types=("UpBlock3D", "CrossAttnUpBlock3D"), attention_head_dim=8, layers_per_block=1)
+    sd = synth_state_dict(param_shapes(build_spec(cfg)))
+    x, ctx = seeded_randn((2, 4, 3, 16, 16), 1), seeded_randn((2, 9, 768), 2)
+    ref = U.unet_forward(sd, cfg, x, 321, ctx)
+    m = build(cfg, torch.float32)
+    y = m(x.to(DEV), 321, ctx.to(DEV)).sample
+    check(y, ref, torch.float32)
+    y0 = m(x[:1].to(DEV), 321, ctx[:1].to(DEV)).sample
+    torch.testing.assert_close(y0.cpu(), y[:1].cpu(), rtol=1e-4, atol=1e-5)
