@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # keep libemo_hip.so in step with csrc/ (incremental; hipcc cross-compiles without a GPU)
+    from emote_hack_amd.build import HIPCC, build_extension
+    if os.path.exists(HIPCC):
+        build_extension(verbose=False)
 
 
 def pytest_collection_modifyitems(config, items):

@@ -159,7 +159,7 @@ def test_conv3x3(dtype, n, H, W, Cin, Cout, stride, up):
     wt, bias = q(seeded_randn((Cout, Cin, 3, 3), 22) / math.sqrt(9 * Cin), dtype), 0.1 * seeded_randn((Cout,), 23)
     xi = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
     ref = F.conv2d(xi, wt, bias, stride=stride, padding=1)
-    rows = x.permute(0, 2, 3, 1).reshape(-1, Cin)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous()
     wp = wt.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)
     got, Ho, Wo = o.conv3x3(rows.to(DEV).to(dtype), wp.to(DEV).to(dtype).contiguous(), bias.to(DEV), n, H, W, stride=stride,
                             upsample2x=up)

@@ -32,8 +32,11 @@ def check(got, ref, dtype):
     if dtype == torch.float32:
         torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-4)
     else:
+        # bf16 yard-stick relative to the tensor's own scale (UNet output mean-abs ~0.3, LN banks ~0.8):
+        # mean error < 3 % of mean |ref|, max error < 10 % of max |ref|
         err = (got - ref).abs()
-        assert float(err.max()) < 8e-2 and float(err.mean()) < 1e-2, (float(err.max()), float(err.mean()))
+        assert float(err.mean()) < 0.03 * float(ref.abs().mean()) + 1e-3, (float(err.mean()), float(ref.abs().mean()))
+        assert float(err.max()) < 0.10 * float(ref.abs().max()) + 1e-2, (float(err.max()), float(ref.abs().max()))
 
 
 @pytest.fixture(scope="module")
