@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py - denoised frames/s of the Emote-hack diffusion hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[1], "cfg2"): 512x512 -> latent 64x64, 12-frame window, 50-step DDPM,
+classifier-free guidance 7.5 (uncond + cond branch batched), ReferenceNet on (midup banks), AnimateDiff motion
+modules at every resolution, text context (1,77,768), bf16, synthetic latents + name-keyed random weights of
+the SD-1.5 architecture (1277 M-parameter Backbone + 860 M-parameter ReferenceNet).
+
+A "step" = ONE iteration of the sampling loop over one batch of synthetic input: ReferenceNet write pass, bank
+hand-off, Backbone UNet forward on the CFG-doubled window, window accumulate, fused CFG + scheduler step -
+i.e. everything EMOAnimationPipeline.py:698-823 does per timestep.  Inputs are resident in HBM when the timed
+region starts.  value = frames / (num_inference_steps * seconds_per_step)   [whole job, all GPUs].
+Weak scaling: every GPU owns one 12-frame window of a 12*N-frame clip (context_frames=12, overlap 0); per step
+the ranks all_reduce the window accumulators, and the ReferenceNet passes are dealt round-robin over ranks and
+exchanged with one all_gather per N steps.
+
+Adds to the JSON line:  "roofline" for the dominant kernel (live HIP-event timing of every launch of that
+kernel in the timed region; algorithmic FLOPs per launch = 2*M*N*K for the GEMM/conv kernel) and
+"cpu_baseline" (the CPU oracle timed on the host cores on a bounded sample, rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_PEAK_BF16_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+NUM_INFERENCE_STEPS = 50
+# algorithmic TFLOP per UNet forward at cfg2 (cond with ReferenceNet K/V, uncond, ReferenceNet image)
+TFLOP_COND, TFLOP_UNCOND, TFLOP_REFNET = 14.319, 13.251, 0.803
+
+
+def build_models(dev, dtype):
+    from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
+    from emote_hack_amd.spec import param_shapes
+    from emote_hack_amd.synth import synth_state_dict
+    from emote_hack_amd.unet import UNet3DConditionModel
+    from tests import cases
+    unet = UNet3DConditionModel(**cases.SD15_MOTION)
+    unet.load_state_dict(synth_state_dict(param_shapes(unet.spec), device=dev))
+    unet.to(dev, dtype)
+    ref = AppearanceEncoderModel(**cases.SD15)
+    ref.load_state_dict(synth_state_dict(param_shapes(ref.spec), prefix=cases.REF_PREFIX, device=dev))
+    ref.to(dev, dtype)
+    return unet, ref
+
+
+def cpu_baseline(unet, ref):
+    """The oracle (kind 'port': plain-PyTorch fp32 CPU restatement, pinned by the reference's goldens) on the
+    host cores, bounded sample: ONE uncond Backbone forward on a 2-frame 512^2 window + ONE ReferenceNet
+    forward (batch 1), extrapolated to the 50-step CFG loop: t_step = 2*t_unet + 2*t_ref."""
+    from oracle import unet_ref as U
+    from tests import cases
+    from emote_hack_amd.synth import seeded_randn
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd_u = {k: v.float().cpu() for k, v in unet.state_dict().items()}
+    sd_r = {k: v.float().cpu() for k, v in ref.state_dict().items()}
+    Fs = 2
+    x, ctx = seeded_randn((1, 4, Fs, 64, 64), 1), seeded_randn((1, 77, 768), 2)
+    with torch.no_grad():
+        t0 = time.time()
+        U.unet_forward(sd_u, cases.SD15_MOTION, x, 981, ctx)
+        t_unet = time.time() - t0
+        t0 = time.time()
+        U.unet_forward(sd_r, cases.SD15, x[:, :, :1], 981, ctx, bank_mode="write")
+        t_ref = time.time() - t0
+    t_step = 2 * t_unet + 2 * t_ref
+    return {"value": Fs / (NUM_INFERENCE_STEPS * t_step), "unit": "denoised frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32: 1 uncond UNet fwd on a {Fs}-frame 512x512 window ({t_unet:.1f}s) + 1 ReferenceNet fwd "
+                      f"({t_ref:.1f}s); step = 2*unet + 2*refnet, x{NUM_INFERENCE_STEPS} steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event instrumentation")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} != WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = world > 1
+    if dist:
+        import torch.distributed as td
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group("nccl", device_id=dev)
+
+    from emote_hack_amd import DDPMScheduler, ops
+    from emote_hack_amd.pipeline import EMOAnimationPipeline
+    from emote_hack_amd.synth import seeded_randn
+
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    unet, ref = build_models(dev, dtype)
+    F_WIN = 12
+    f_tot = F_WIN * world
+    pipe = EMOAnimationPipeline(unet=unet, scheduler=DDPMScheduler())
+    st = pipe.prepare_denoise(seeded_randn((1, 4, f_tot, 64, 64), 1).to(dev), seeded_randn((1, 4, 64, 64), 3),
+                              seeded_randn((2, 77, 768), 2), appearance_encoder=ref, num_inference_steps=NUM_INFERENCE_STEPS,
+                              guidance_scale=7.5, context_frames=F_WIN, context_stride=1, context_overlap=0, seed=0,
+                              dist=dist, rank=rank, world_size=world)
+    assert len(st.global_context) == world, (len(st.global_context), world)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist:
+            td.barrier()
+            torch.cuda.synchronize()
+
+    si = 0
+    for _ in range(a.warmup):
+        pipe.denoise_step(st, si % NUM_INFERENCE_STEPS)
+        si += 1
+    prof = None if a.no_profile else ops.KernelProfiler()
+    ops.PROFILER = prof
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        pipe.denoise_step(st, si % NUM_INFERENCE_STEPS)
+        si += 1
+    sync()
+    dt_s = time.perf_counter() - t0
+    ops.PROFILER = None
+    if dist:
+        t = torch.tensor([dt_s], device=dev, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt_s = float(t.item())
+    finite = bool(torch.isfinite(st.latents).all())
+    ms_per_step = dt_s / a.steps * 1e3
+    fps = f_tot / (NUM_INFERENCE_STEPS * dt_s / a.steps)
+
+    if rank == 0:
+        out = {
+            "metric": "denoised frames/s (512x512, 50-step DDPM)", "value": fps, "unit": "frames/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "cfg2: 512x512 latents 64x64, 12-frame window per GPU, 50-step DDPM, CFG 7.5 (uc+c batched), "
+                                   "ReferenceNet on (midup), motion modules res 1/2/4/8, ctx 77x768; 1 step = 1 loop iteration",
+                       "frames_total": f_tot, "num_inference_steps": NUM_INFERENCE_STEPS,
+                       "parallelism": f"window-sharded x{world} (all_reduce eps accumulators, all_gather ReferenceNet banks)",
+                       "latents_finite": finite},
+        }
+        # algorithmic work per step: cond + uncond Backbone + 2 x ReferenceNet per window
+        tflop_step = world * (TFLOP_COND + TFLOP_UNCOND) + 2 * TFLOP_REFNET * (1.0 if not dist else 1.0)
+        out["config"]["algorithmic_tflop_per_step"] = tflop_step
+        out["config"]["achieved_tflops_whole_path"] = tflop_step / (dt_s / a.steps)
+        if prof is not None:
+            summ = prof.summary()
+            dom = max((k for k in summ if summ[k]["flops"] > 0), key=lambda k: summ[k]["ms"])
+            d = summ[dom]
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": {"gemm_dense": "gemm_kernel<bf16,false>", "gemm_conv3x3": "gemm_kernel<bf16,true>",
+                                          "attention": "attention_kernel", "temporal_attention": "temporal_attention_kernel"}[dom],
+                               "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / MFMA_PEAK_BF16_TFLOPS, "traffic": None,
+                               "launches": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
+                               "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9}
+            out["kernels"] = {k: {"launches": v["launches"], "ms_per_step": v["ms"] / a.steps,
+                                  "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None,
+                                  "gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in sorted(summ.items())}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(unet, ref)
+        print(json.dumps(out))
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

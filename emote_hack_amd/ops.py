@@ -29,6 +29,43 @@ def vec(dtype) -> int:
     return 4 if dtype == torch.float32 else 8
 
 
+class KernelProfiler:
+    """Live per-kernel timing with HIP events on the launch stream (bench.py `roofline`).  Each profiled
+    launch is bracketed by two events recorded on the stream the kernel is launched on; durations and
+    the launch's ALGORITHMIC flops / bytes are summed per kernel class after a synchronise."""
+
+    def __init__(self):
+        self.records = []   # (name, flops, bytes, ev0, ev1)
+
+    def launch(self, name, flops, nbytes, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.records.append((name, flops, nbytes, e0, e1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, fl, nb, e0, e1 in self.records:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += nb
+        return out
+
+
+PROFILER = None  # set to a KernelProfiler to time launches
+
+
+def _launch(name, flops, nbytes, fn):
+    if PROFILER is None:
+        fn()
+    else:
+        PROFILER.launch(name, flops, nbytes, fn)
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -128,12 +165,15 @@ def group_norm(x: torch.Tensor, gamma, beta, n_inst: int, groups: int, eps: floa
     ws = lib.emo_groupnorm_workspace_bytes(n_inst, S, Cc, groups)
     part = torch.empty(max(ws // 4, 1), device=x.device, dtype=torch.float32)
     stats = torch.empty(n_inst * groups * 2, device=x.device, dtype=torch.float32)
-    check(lib.emo_groupnorm_stats(px, ldx, _ptr(stats), _ptr(part), n_inst, S, Cc, groups, float(eps), dt(x), _stream()),
-          "emo_groupnorm_stats")
     y = torch.empty(M, Cc, device=x.device, dtype=x.dtype) if out is None else out
     py, ldy = _rows(y)
-    check(lib.emo_groupnorm_apply(px, ldx, _ptr(stats), _ptr(gamma), _ptr(beta), py, ldy, n_inst, S, Cc, groups, int(silu_),
-                                  dt(x), _stream()), "emo_groupnorm_apply")
+
+    def run():
+        check(lib.emo_groupnorm_stats(px, ldx, _ptr(stats), _ptr(part), n_inst, S, Cc, groups, float(eps), dt(x), _stream()),
+              "emo_groupnorm_stats")
+        check(lib.emo_groupnorm_apply(px, ldx, _ptr(stats), _ptr(gamma), _ptr(beta), py, ldy, n_inst, S, Cc, groups, int(silu_),
+                                      dt(x), _stream()), "emo_groupnorm_apply")
+    _launch("groupnorm", 0.0, x.element_size() * 2.0 * M * Cc, run)   # algorithmic: one read + one write
     return y
 
 
@@ -142,8 +182,9 @@ def layer_norm(x: torch.Tensor, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0
     M, Cc = x.shape
     px, ldx = _rows(x)
     y = torch.empty(M, Cc, device=x.device, dtype=x.dtype)
-    check(_lib.load().emo_layernorm(px, ldx, _ptr(gamma), _ptr(beta), _ptr(y), Cc, M, Cc, float(eps), _ptr(pe), rows_per_frame,
-                                    frames, dt(x), _stream()), "emo_layernorm")
+    _launch("layernorm", 0.0, x.element_size() * 2.0 * M * Cc,
+            lambda: check(_lib.load().emo_layernorm(px, ldx, _ptr(gamma), _ptr(beta), _ptr(y), Cc, M, Cc, float(eps), _ptr(pe),
+                                                    rows_per_frame, frames, dt(x), _stream()), "emo_layernorm"))
     return y
 
 
@@ -190,7 +231,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
         p.conv_taps, p.H, p.W_, p.Cin = 9, conv["H"], conv["W"], conv["Cin"]
         p.stride, p.upsample2x, p.Ho, p.Wo = conv["stride"], int(conv["upsample2x"]), conv["Ho"], conv["Wo"]
     p.dtype = dt(a)
-    check(_lib.load().emo_gemm(C.byref(p), _stream()), "emo_gemm")
+    esz = a.element_size()
+    _launch("gemm_conv3x3" if conv is not None else "gemm_dense", 2.0 * M * N * K,
+            esz * (float(M) * (K if conv is None else conv["Cin"]) + float(N) * K + float(M) * n_out),
+            lambda: check(_lib.load().emo_gemm(C.byref(p), _stream()), "emo_gemm"))
     return out
 
 
@@ -224,7 +268,9 @@ def attention(q, k0, v0t, Lk0, *, B, Lq, heads, d, scale, seg0_div=1, k1=None, v
         p.seg1_div = 1
     p.out, p.ldo = out.data_ptr(), out.stride(0)
     p.B, p.Lq, p.heads, p.d, p.scale, p.dtype = B, Lq, heads, d, float(scale), dt(q)
-    check(_lib.load().emo_attention(C.byref(p), _stream()), "emo_attention")
+    esz = q.element_size()
+    _launch("attention", 4.0 * B * heads * Lq * (Lk0 + Lk1) * d, esz * float(B) * heads * d * (2 * Lq + 2 * (Lk0 + Lk1)),
+            lambda: check(_lib.load().emo_attention(C.byref(p), _stream()), "emo_attention"))
     return out
 
 
@@ -232,8 +278,9 @@ def temporal_attention(qkv: torch.Tensor, B, F, HW, heads, d, scale) -> torch.Te
     _need_cuda(qkv)
     pq, ld = _rows(qkv)
     out = torch.empty(B * F * HW, heads * d, device=qkv.device, dtype=qkv.dtype)
-    check(_lib.load().emo_temporal_attention(pq, ld, _ptr(out), out.stride(0), B, F, HW, heads, d, float(scale), dt(qkv), _stream()),
-          "emo_temporal_attention")
+    _launch("temporal_attention", 4.0 * B * HW * heads * F * F * d, qkv.element_size() * 4.0 * B * F * HW * heads * d,
+            lambda: check(_lib.load().emo_temporal_attention(pq, ld, _ptr(out), out.stride(0), B, F, HW, heads, d, float(scale),
+                                                             dt(qkv), _stream()), "emo_temporal_attention"))
     return out
 
 

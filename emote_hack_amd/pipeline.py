@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass
+from types import SimpleNamespace
 from typing import Callable, List, Optional, Union
 
 import torch
@@ -83,99 +84,120 @@ class EMOAnimationPipeline:
 
     # ------------------------------------------------------------------ the hot loop
     @torch.no_grad()
-    def denoise(self, latents, ref_image_latents, text_embeddings, *, appearance_encoder, num_inference_steps=50,
-                guidance_scale=7.5, eta=0.0, context_frames=16, context_stride=1, context_overlap=4, context_batch_size=1,
-                context_schedule="uniform", audio_features=None, speed_embeddings=None, seed=0, fusion_blocks="midup",
-                dist=False, rank=0, world_size=1, num_actual_inference_steps=None, callback=None, callback_steps=1,
-                return_eps=False):
-        """EMOAnimationPipeline.py:698-823.  latents f32 (1,4,F_tot,h,w) on device (updated in place and
-        returned); ref_image_latents (1,4,h,w); text_embeddings (2,L,D) = [uncond, cond]."""
+    def prepare_denoise(self, latents, ref_image_latents, text_embeddings, *, appearance_encoder, num_inference_steps=50,
+                        guidance_scale=7.5, eta=0.0, context_frames=16, context_stride=1, context_overlap=4,
+                        context_batch_size=1, context_schedule="uniform", audio_features=None, speed_embeddings=None, seed=0,
+                        fusion_blocks="midup", dist=False, rank=0, world_size=1, return_eps=False):
+        """Set up the loop state (EMOAnimationPipeline.py:628-696).  latents f32 (1,4,F_tot,h,w);
+        ref_image_latents (1,4,h,w); text_embeddings (2,L,D) = [uncond, cond]."""
         unet, sch = self.unet, self.scheduler
         dev = unet.device
-        do_cfg = guidance_scale > 1.0
-        if not do_cfg:
+        if not guidance_scale > 1.0:
             raise NotImplementedError("guidance_scale <= 1 (no CFG) is not on the benchmarked path")
         if latents.shape[0] != 1:
             raise ValueError("batch_size must be 1 (EMOAnimationPipeline.py:641-642); run clips as separate calls")
-        cbs = context_batch_size
-        latents = latents.to(dev).float().contiguous()
-        _, C4, f_tot, h, w = latents.shape
-        HW = h * w
-        text = torch.cat([text_embeddings] * cbs).to(dev)  # :631
-        writer = ReferenceAttentionControl(appearance_encoder, do_classifier_free_guidance=True, mode="write",
-                                           batch_size=cbs, fusion_blocks=fusion_blocks)   # :633
-        reader = ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", batch_size=cbs,
-                                           fusion_blocks=fusion_blocks)                   # :634
-        timesteps = sch.set_timesteps(num_inference_steps)
-        ref_rep = ref_image_latents.to(dev).float().repeat(cbs * 2, 1, 1, 1)              # :712
+        st = SimpleNamespace()
+        st.cbs = context_batch_size
+        st.latents = latents.to(dev).float().contiguous()
+        _, st.C4, st.f_tot, st.h, st.w = st.latents.shape
+        st.HW = st.h * st.w
+        st.text = torch.cat([text_embeddings] * st.cbs).to(dev)                               # :631
+        st.appearance_encoder = appearance_encoder
+        st.writer = ReferenceAttentionControl(appearance_encoder, do_classifier_free_guidance=True, mode="write",
+                                              batch_size=st.cbs, fusion_blocks=fusion_blocks)  # :633
+        st.reader = ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", batch_size=st.cbs,
+                                              fusion_blocks=fusion_blocks)                      # :634
+        st.num_inference_steps = num_inference_steps
+        st.timesteps = sch.set_timesteps(num_inference_steps)
+        st.ref_rep = ref_image_latents.to(dev).float().repeat(st.cbs * 2, 1, 1, 1)           # :712
         scheduler_fn = get_context_scheduler(context_schedule)
-        noise_pred = torch.empty(2, C4, f_tot, HW, device=dev, dtype=torch.float32)
-        counter = torch.empty(f_tot, device=dev, dtype=torch.float32)
-        eps_trace = []
+        # the reference recomputes the (step-independent: step arg is always 0) window list every step (:748-755)
+        queue = list(scheduler_fn(0, num_inference_steps, st.f_tot, context_frames, context_stride, context_overlap))
+        nb = math.ceil(len(queue) / st.cbs)
+        st.global_context = [queue[i * st.cbs:(i + 1) * st.cbs] for i in range(nb)]
+        st.frame_idx = {tuple(c): torch.tensor(c, dtype=torch.int32, device=dev) for ctx in st.global_context for c in ctx}
+        st.noise_pred = torch.empty(2, st.C4, st.f_tot, st.HW, device=dev, dtype=torch.float32)
+        st.counter = torch.empty(st.f_tot, device=dev, dtype=torch.float32)
+        st.guidance_scale, st.eta, st.seed = guidance_scale, eta, seed
+        st.audio_features, st.speed_embeddings = audio_features, speed_embeddings
+        st.dist, st.rank, st.world_size = bool(dist) and world_size > 1, rank, world_size
+        st.return_eps, st.eps_trace = return_eps, []
+        st.bank_group, st.bank_shapes, st.bank_group_start = None, None, -1
+        return st
 
-        # --- multi-GPU: deal the write passes over ranks, all_gather the packed banks (one collective)
-        bank_cache = None
-        if dist and world_size > 1:
+    def _exchange_banks(self, st, si):
+        """Multi-GPU ReferenceNet hand-off.  The write pass depends on the timestep only, so the ranks deal
+        the passes of the next `world_size` steps among themselves (rank r computes step si+r) and swap the
+        packed banks with ONE all_gather over xGMI - each rank runs the ReferenceNet once per world_size
+        steps instead of every step (the reference recomputes it on every rank, :711-716)."""
+        import torch.distributed as td
+        ws = st.world_size
+        mine = min(si + st.rank, len(st.timesteps) - 1)   # tail group: surplus ranks recompute the last step (unused)
+        self._write_banks(st.appearance_encoder, st.writer, st.ref_rep, st.timesteps[mine], st.text)
+        st.bank_shapes = [tuple(st.writer.bank[p][0].shape) for p in st.writer.order]
+        send = self._pack_banks(st.writer)
+        recv = torch.empty(ws, send.numel(), device=send.device, dtype=send.dtype)
+        td.all_gather_into_tensor(recv, send)
+        st.bank_group, st.bank_group_start = recv, si
+
+    @torch.no_grad()
+    def denoise_step(self, st, si):
+        """One iteration of the hot loop (EMOAnimationPipeline.py:698-823)."""
+        unet, sch = self.unet, self.scheduler
+        dev = unet.device
+        t = st.timesteps[si]
+        st.noise_pred.zero_()
+        st.counter.zero_()
+        if not st.dist:
+            self._write_banks(st.appearance_encoder, st.writer, st.ref_rep, t, st.text)       # :711-716
+        else:
+            if st.bank_group is None or si >= st.bank_group_start + st.world_size or si < st.bank_group_start:
+                self._exchange_banks(st, si)
+            self._unpack_banks(st.bank_group[si - st.bank_group_start], st.writer, st.bank_shapes)
+        for context in st.global_context[st.rank::st.world_size] if st.dist else st.global_context:   # :757
+            x = torch.cat([st.latents[:, :, c] for c in context]).repeat(2, 1, 1, 1, 1)       # :759-763 (index/copy only)
+            x = sch.scale_model_input(x, t)
+            b = x.shape[0]
+            st.reader.update(st.writer)                                                        # :774
+            af = None
+            if st.audio_features is not None:   # per-frame audio context; uc rows get a zero context
+                cond = torch.cat([st.audio_features[c] for c in context]).to(dev)
+                af = torch.cat([torch.zeros_like(cond), cond])
+            rows = unet(x, t, encoder_hidden_states=st.text[:b], audio_features=af, speed_embeddings=st.speed_embeddings,
+                        return_dict=False, _return_rows=True)                                  # :777-786
+            st.reader.clear()                                                                  # :788
+            nf = len(context[0])
+            for j, c in enumerate(context):                                                    # :790-794
+                fr = st.frame_idx[tuple(c)]
+                for branch in (0, 1):
+                    bi = branch * len(context) + j
+                    ops.accumulate_window(rows[bi * nf * st.HW:(bi + 1) * nf * st.HW], st.noise_pred[branch], st.counter, fr,
+                                          C_=st.C4, F=st.f_tot, HW=st.HW, add_counter=(branch == 0))
+        if st.dist:                                                                            # replaces :796-809 + :819-821
             import torch.distributed as td
-            mine = list(range(rank, len(timesteps), world_size))
-            n_slots = math.ceil(len(timesteps) / world_size)
-            local, shapes = [], None
-            for si in mine:
-                self._write_banks(appearance_encoder, writer, ref_rep, timesteps[si], text)
-                shapes = [tuple(writer.bank[p][0].shape) for p in writer.order]
-                local.append(self._pack_banks(writer))
-            while len(local) < n_slots:
-                local.append(torch.zeros_like(local[0]))
-            send = torch.stack(local)                                   # (n_slots, total)
-            recv = torch.empty(world_size, *send.shape, device=dev, dtype=send.dtype)
-            td.all_gather_into_tensor(recv, send)
-            bank_cache = (recv, shapes)                                 # step si -> recv[si % world, si // world]
+            td.all_reduce(st.noise_pred)
+            td.all_reduce(st.counter)
+        c_x, c_eps, c_n = sch.coefficients(t, st.eta) if isinstance(sch, DDIMScheduler) else sch.coefficients(t)
+        eps_out = torch.empty(st.C4 * st.f_tot * st.HW, device=dev, dtype=torch.float32) if st.return_eps else None
+        ops.cfg_step(st.noise_pred, st.counter, st.latents, C_=st.C4, F=st.f_tot, HW=st.HW, guidance_scale=st.guidance_scale,
+                     c_x=c_x, c_eps=c_eps, c_noise=c_n, seed=st.seed, step=si, eps_out=eps_out)  # :812-817 fused
+        if st.return_eps:
+            st.eps_trace.append(eps_out.view(1, st.C4, st.f_tot, st.h, st.w))
+        st.writer.clear()                                                                      # :823
 
-        for si, t in enumerate(timesteps):
-            if num_actual_inference_steps is not None and si < num_inference_steps - num_actual_inference_steps:
+    @torch.no_grad()
+    def denoise(self, latents, ref_image_latents, text_embeddings, *, num_actual_inference_steps=None, callback=None,
+                callback_steps=1, **kw):
+        """The whole loop; returns the denoised latents f32 (1,4,F_tot,h,w) (and the eps trace if asked)."""
+        st = self.prepare_denoise(latents, ref_image_latents, text_embeddings, **kw)
+        n = st.num_inference_steps
+        for si, t in enumerate(st.timesteps):
+            if num_actual_inference_steps is not None and si < n - num_actual_inference_steps:   # :699-700
                 continue
-            noise_pred.zero_()
-            counter.zero_()
-            if bank_cache is None:
-                self._write_banks(appearance_encoder, writer, ref_rep, t, text)          # :711-716
-            else:
-                self._unpack_banks(bank_cache[0][si % world_size, si // world_size], writer, bank_cache[1])
-            context_queue = list(scheduler_fn(0, num_inference_steps, f_tot, context_frames, context_stride, context_overlap))
-            nb = math.ceil(len(context_queue) / cbs)
-            global_context = [context_queue[i * cbs:(i + 1) * cbs] for i in range(nb)]   # :752-755
-            for context in global_context[rank::world_size]:                             # :757
-                x = torch.cat([latents[:, :, c] for c in context]).repeat(2, 1, 1, 1, 1)  # :759-763 (index/copy only)
-                x = sch.scale_model_input(x, t)
-                b = x.shape[0]
-                reader.update(writer)                                                      # :774
-                af = None
-                if audio_features is not None:   # per-frame audio context; uc rows get a zero context
-                    cond = torch.cat([audio_features[c] for c in context]).to(dev)
-                    af = torch.cat([torch.zeros_like(cond), cond])
-                rows = unet(x, t, encoder_hidden_states=text[:b], audio_features=af, speed_embeddings=speed_embeddings,
-                            return_dict=False, _return_rows=True)                          # :777-786
-                reader.clear()                                                             # :788
-                nf = len(context[0])
-                for j, c in enumerate(context):                                            # :790-794
-                    fr = torch.tensor(c, dtype=torch.int32, device=dev)
-                    for branch in (0, 1):
-                        bi = branch * len(context) + j
-                        ops.accumulate_window(rows[bi * nf * HW:(bi + 1) * nf * HW], noise_pred[branch], counter, fr,
-                                              C_=C4, F=f_tot, HW=HW, add_counter=(branch == 0))
-            if dist and world_size > 1:                                                    # replaces :796-809 + :819-821
-                import torch.distributed as td
-                td.all_reduce(noise_pred)
-                td.all_reduce(counter)
-            c_x, c_eps, c_n = sch.coefficients(t, eta) if isinstance(sch, DDIMScheduler) else sch.coefficients(t)
-            eps_out = torch.empty(C4 * f_tot * HW, device=dev, dtype=torch.float32) if return_eps else None
-            ops.cfg_step(noise_pred, counter, latents, C_=C4, F=f_tot, HW=HW, guidance_scale=guidance_scale, c_x=c_x,
-                         c_eps=c_eps, c_noise=c_n, seed=seed, step=si, eps_out=eps_out)   # :812-817 fused
-            if return_eps:
-                eps_trace.append(eps_out.view(1, C4, f_tot, h, w))
-            writer.clear()                                                                 # :823
+            self.denoise_step(st, si)
             if callback is not None and si % callback_steps == 0:
-                callback(si, t, latents)
-        return (latents, eps_trace) if return_eps else latents
+                callback(si, t, st.latents)
+        return (st.latents, st.eps_trace) if st.return_eps else st.latents
 
     # ------------------------------------------------------------------ reference-compatible entry point
     @torch.no_grad()

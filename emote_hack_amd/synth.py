@@ -32,12 +32,15 @@ def _pe(shape):
     return pe
 
 
-def synth_tensor(name: str, shape, gain: float = 1.0) -> torch.Tensor:
+def synth_tensor(name: str, shape, gain: float = 1.0, device="cpu") -> torch.Tensor:
+    """device='cpu' is the reproducible stream the golden fixtures were made with; a 'cuda' device draws
+    from the device generator instead (same distribution, different numbers) - used by bench.py, where
+    2.1 G parameters would take a minute on the host."""
     shape = tuple(int(s) for s in shape)
     if name.endswith("pos_encoder.pe"):
-        return _pe(shape)
-    g = torch.Generator().manual_seed(zlib.crc32(name.encode("utf-8")))
-    z = torch.randn(shape, generator=g, dtype=torch.float32)
+        return _pe(shape).to(device)
+    g = torch.Generator(device=device).manual_seed(zlib.crc32(name.encode("utf-8")))
+    z = torch.randn(shape, generator=g, dtype=torch.float32, device=device)
     if name.endswith(".bias"):
         return 0.1 * z
     if len(shape) == 1:
@@ -48,11 +51,11 @@ def synth_tensor(name: str, shape, gain: float = 1.0) -> torch.Tensor:
     return z * (gain / math.sqrt(fan_in))
 
 
-def synth_state_dict(shapes: dict, gain: float = 1.0, prefix: str = "") -> dict:
+def synth_state_dict(shapes: dict, gain: float = 1.0, prefix: str = "", device="cpu") -> dict:
     """shapes: {state_dict_key: shape}.  Returns fp32 CPU tensors keyed by the plain key; `prefix`
     only salts the seed (so a ReferenceNet and a Backbone with equal key names get different
     weights: prefix='reference_unet.')."""
-    return {k: synth_tensor(prefix + k, s, gain) for k, s in shapes.items()}
+    return {k: synth_tensor(prefix + k, s, gain, device) for k, s in shapes.items()}
 
 
 def seeded_randn(shape, seed: int) -> torch.Tensor:
