@@ -62,11 +62,11 @@ def cpu_baseline(unet, ref):
     from oracle import unet_ref as U
     from tests import cases
     from emote_hack_amd.synth import seeded_randn
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)   # threads actually used (oversubscribing a 256-thread host is 30x slower)
     torch.set_num_threads(cores)
     sd_u = {k: v.float().cpu() for k, v in unet.state_dict().items()}
     sd_r = {k: v.float().cpu() for k, v in ref.state_dict().items()}
-    Fs = 2
+    Fs = 1
     x, ctx = seeded_randn((1, 4, Fs, 64, 64), 1), seeded_randn((1, 77, 768), 2)
     with torch.no_grad():
         t0 = time.time()
@@ -178,6 +178,14 @@ def main():
             out["kernels"] = {k: {"launches": v["launches"], "ms_per_step": v["ms"] / a.steps,
                                   "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None,
                                   "gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in sorted(summ.items())}
+        if prof is not None and os.environ.get("EMO_BENCH_SHAPES"):
+            rows = sorted(prof.by_shape().items(), key=lambda kv: -kv[1]["ms"])
+            with open(os.environ["EMO_BENCH_SHAPES"], "w") as f:
+                f.write("| kernel | shape | launches/step | ms/step | TFLOP/s | GB/s (algorithmic) |\n|---|---|---|---|---|---|\n")
+                for (name, tag), v in rows[:60]:
+                    tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["flops"] else 0.0
+                    f.write(f"| {name} | {tag} | {v['launches'] / a.steps:.1f} | {v['ms'] / a.steps:.3f} | {tf:.0f} | "
+                            f"{v['bytes'] / (v['ms'] * 1e-3) / 1e9:.0f} |\n")
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(unet, ref)
         print(json.dumps(out))

@@ -32,6 +32,7 @@ class GemmParams(C.Structure):
         ("conv_taps", C.c_int), ("H", C.c_int), ("W_", C.c_int), ("Cin", C.c_int), ("stride", C.c_int),
         ("upsample2x", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
         ("dtype", C.c_int),
+        ("split_k", C.c_int), ("workspace", C.c_void_p),
     ]
 
 
@@ -66,6 +67,8 @@ SIGNATURES = {
     "emo_groupnorm_apply": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _i, _i, _p]),
     "emo_layernorm": (_i, [_p, _i, _p, _p, _p, _i, _i64, _i, _f, _p, _i, _i, _i, _p]),
     "emo_gemm": (_i, [C.POINTER(GemmParams), _p]),
+    "emo_gemm_suggest_split_k": (_i, [_i64, _i, _i, _i]),
+    "emo_gemm_workspace_bytes": (C.c_size_t, [_i64, _i, _i]),
     "emo_attention": (_i, [C.POINTER(AttentionParams), _p]),
     "emo_temporal_attention": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _i, _i, _f, _i, _p]),
     "emo_cfg_step": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _u32, _u32, _p]),

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const emo_gemm_param
   const int tiles_n = (p.N + BN - 1) / BN;
   const int64_t bm = (int64_t)(blockIdx.x / tiles_n) * BM;
   const int bn = (blockIdx.x % tiles_n) * BN;
+  const int nsplit = p.split_k > 1 ? p.split_k : 1;
 
   const T* __restrict__ A = (const T*)p.A;
   const T* __restrict__ W = (const T*)p.W;
@@ -99,13 +100,18 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const emo_gemm_param
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  const int nk = (p.K + BK - 1) / BK;
-  load_global(0);
-  store_lds(0);
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int nk_per = (nk_all + nsplit - 1) / nsplit;
+  const int kt0 = blockIdx.y * nk_per;
+  const int nk = (kt0 + nk_per <= nk_all ? nk_per : nk_all - kt0);   // may be <= 0 for a trailing empty slice
+  if (nk > 0) {
+    load_global(kt0);
+    store_lds(0);
+  }
   __syncthreads();
   for (int kt = 0; kt < nk; kt++) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) load_global(kt + 1);
+    if (kt + 1 < nk) load_global(kt0 + kt + 1);
     const unsigned char* la = &lds[cur][0][(wm * 64 + l31) * ROWB + half * 16];
     const unsigned char* lb = &lds[cur][1][(wn * 64 + l31) * ROWB + half * 16];
 #pragma unroll
@@ -123,6 +129,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const emo_gemm_param
     __syncthreads();
   }
 
+  // ------------------------------------------------------------------ split-K: raw f32 partial tile to the workspace
+  if (nsplit > 1) {
+    float* __restrict__ ws = (float*)p.workspace + (int64_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int n = bn + wn * 64 + j * 32 + l31;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int64_t m = bm + wm * 64 + i * 32 + mfma_row(r, half);
+          if (m < p.M) ws[m * p.N + n] = acc[i][j][r];
+        }
+      }
+    return;
+  }
   // ------------------------------------------------------------------ epilogue
   T* __restrict__ C = (T*)p.C;
   const T* __restrict__ R = (const T*)p.residual;
@@ -173,6 +196,49 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const emo_gemm_param
   (void)n_out_total;
 }
 
+// split-K second pass: fixed-order reduction of the f32 partials + the same fused epilogue
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(const emo_gemm_params p) {
+  const int n_out = p.geglu ? p.N / 2 : p.N;
+  const int64_t total = p.M * n_out;
+  const float* __restrict__ ws = (const float*)p.workspace;
+  const int64_t slab = p.M * (int64_t)p.N;
+  T* __restrict__ C = (T*)p.C;
+  const T* __restrict__ R = (const T*)p.residual;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / n_out;
+    const int no = (int)(i % n_out);
+    const int nw = p.geglu ? (no / 32) * 64 + (no % 32) : no;   // column in W-row space
+    float v = 0.f, g = 0.f;
+    for (int s = 0; s < p.split_k; s++) {
+      v += ws[s * slab + m * p.N + nw];
+      if (p.geglu) g += ws[s * slab + m * p.N + nw + 32];
+    }
+    if (p.bias) { v += p.bias[nw]; if (p.geglu) g += p.bias[nw + 32]; }
+    if (p.rowbias) v += p.rowbias[(m / p.rows_per_batch) * p.ld_rowbias + nw];
+    if (p.geglu) v = v * gelu_erf_f(g);
+    if (R) v += TT<T>::ld(R + m * p.ldr + no);
+    v *= p.out_scale;
+    if (!p.transpose_out) TT<T>::st(C + m * p.ldc + no, v);
+    else TT<T>::st(C + (m / p.t_rows) * p.t_batch_stride + (int64_t)no * p.t_ld + (m % p.t_rows), v);
+  }
+}
+
+extern "C" int emo_gemm_suggest_split_k(int64_t M, int N, int K, int dtype) {
+  const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  const int bk = dtype == EMO_F32 ? 16 : 32;
+  const int nk = (K + bk - 1) / bk;
+  if (tiles >= 192 || nk < 16) return 1;
+  int s = (int)((512 + tiles - 1) / tiles);       // aim at ~2 blocks per CU
+  const int max_by_k = nk / 8;                     // keep >= 8 k-steps per slice
+  if (s > max_by_k) s = max_by_k;
+  if (s > 32) s = 32;
+  return s < 2 ? 1 : s;
+}
+extern "C" size_t emo_gemm_workspace_bytes(int64_t M, int N, int split_k) {
+  return split_k > 1 ? (size_t)split_k * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
 extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
   EMO_CHECK(pp, EMO_ERR_NULL, "emo_gemm: null params");
   const emo_gemm_params& p = *pp;
@@ -198,14 +264,24 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
   }
   const int64_t tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   EMO_CHECK(tiles < (1ll << 31), EMO_ERR_BAD_SHAPE, "emo_gemm: too many tiles");
+  const int S = p.split_k > 1 ? p.split_k : 1;
+  if (S > 1) EMO_CHECK(p.workspace != nullptr && S <= 65535, EMO_ERR_NULL, "emo_gemm: split_k=%d needs a workspace", S);
   hipStream_t st = as_stream(stream);
+  dim3 grid((unsigned)tiles, (unsigned)S);
   if (p.dtype == EMO_F32) {
-    if (conv) gemm_kernel<float, true><<<(int)tiles, GEMM_THREADS, 0, st>>>(p);
-    else gemm_kernel<float, false><<<(int)tiles, GEMM_THREADS, 0, st>>>(p);
+    if (conv) gemm_kernel<float, true><<<grid, GEMM_THREADS, 0, st>>>(p);
+    else gemm_kernel<float, false><<<grid, GEMM_THREADS, 0, st>>>(p);
   } else {
-    if (conv) gemm_kernel<bf16_t, true><<<(int)tiles, GEMM_THREADS, 0, st>>>(p);
-    else gemm_kernel<bf16_t, false><<<(int)tiles, GEMM_THREADS, 0, st>>>(p);
+    if (conv) gemm_kernel<bf16_t, true><<<grid, GEMM_THREADS, 0, st>>>(p);
+    else gemm_kernel<bf16_t, false><<<grid, GEMM_THREADS, 0, st>>>(p);
   }
   EMO_LAUNCH_CHECK();
+  if (S > 1) {
+    const int64_t total = p.M * (p.geglu ? p.N / 2 : p.N);
+    int64_t g = (total + 255) / 256; if (g > 4096) g = 4096;
+    if (p.dtype == EMO_F32) gemm_splitk_epilogue_kernel<float><<<(int)g, 256, 0, st>>>(p);
+    else gemm_splitk_epilogue_kernel<bf16_t><<<(int)g, 256, 0, st>>>(p);
+    EMO_LAUNCH_CHECK();
+  }
   return EMO_OK;
 }

@@ -91,21 +91,26 @@ __global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(const T* __restr
   }
 }
 
-__global__ void gn_finalize_kernel(const float* __restrict__ partials, float* __restrict__ stats, int N, int G, int nsplit,
-                                   double count, float eps) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per (instance, group): lanes stride over the row-chunk partials, f64 accumulate, shuffle reduce
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partials, float* __restrict__ stats, int N, int G,
+                                                          int nsplit, double count, float eps) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= N * G) return;
-  int n = i / G, g = i % G;
+  const int n = i / G, g = i % G;
   double a = 0.0, b = 0.0;
-  for (int sp = 0; sp < nsplit; sp++) {
+  for (int sp = lane; sp < nsplit; sp += 64) {
     const float* p = partials + (((int64_t)n * nsplit + sp) * G + g) * 2;
     a += (double)p[0]; b += (double)p[1];
   }
-  double mean = a / count;
-  double var = b / count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  stats[2 * i] = (float)mean;
-  stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+  if (lane == 0) {
+    double mean = a / count;
+    double var = b / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * i] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 template <typename T>
@@ -184,7 +189,7 @@ extern "C" int emo_groupnorm_stats(const void* x, int ldx, float* stats, void* p
   if (dtype == EMO_F32) gn_partial_kernel<float><<<N * nsplit, GN_THREADS, lds, st>>>((const float*)x, ldx, (float*)partials, S, C, G, nsplit);
   else gn_partial_kernel<bf16_t><<<N * nsplit, GN_THREADS, lds, st>>>((const bf16_t*)x, ldx, (float*)partials, S, C, G, nsplit);
   EMO_LAUNCH_CHECK();
-  gn_finalize_kernel<<<(N * G + 127) / 128, 128, 0, st>>>((const float*)partials, stats, N, G, nsplit, (double)S * (C / G), eps);
+  gn_finalize_kernel<<<(N * G + 3) / 4, 256, 0, st>>>((const float*)partials, stats, N, G, nsplit, (double)S * (C / G), eps);
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
@@ -207,55 +212,70 @@ extern "C" int emo_groupnorm_apply(const void* x, int ldx, const float* stats, c
 }
 
 // ------------------------------------------------------------------------------------------ LayerNorm
-// One wavefront per row, the row lives in registers (<= LN_MAXV 16-byte vectors per lane), two-pass
-// mean / variance like torch (no E[x^2]-mean^2 cancellation), wave64 shuffle reductions, optional fused
-// temporal positional-encoding add (motion_module.py:246-248 applied after the norm, :282-283).
+// A wavefront normalises 64/LPR rows at once: LPR lanes (a power of two) share a row, each lane holds up to
+// LN_MAXV 16-byte vectors of it in registers (lane-strided, so a row group reads contiguous 16*LPR-byte runs).
+// Two-pass mean / variance like torch (no E[x^2]-mean^2 cancellation); reductions are log2(LPR) shuffles.
+// Optional fused temporal positional-encoding add (motion_module.py:246-248 applied after the norm, :282-283).
 static constexpr int LN_MAXV = 5;
 
-template <typename T>
+template <typename T, int LPR>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ y, int ldy, int64_t M, int C,
                                                         float eps, const float* __restrict__ pe, int rows_per_frame, int frames) {
   constexpr int V = TT<T>::VEC;
+  constexpr int RPW = 64 / LPR;  // rows per wavefront
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, rsel = lane / LPR;
   const int CV = C / V;
-  for (int64_t m = (int64_t)blockIdx.x * 4 + wave; m < M; m += (int64_t)gridDim.x * 4) {
+  const float invC = 1.0f / (float)C;
+  for (int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * RPW; m0 < M; m0 += (int64_t)gridDim.x * 4 * RPW) {
+    const int64_t m = m0 + rsel;
+    const bool ok = m < M;
     float f[LN_MAXV][V];
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < LN_MAXV; j++) {
-      int cv = lane + 64 * j;
-      if (cv < CV) {
+      const int cv = sub + LPR * j;
+      if (ok && cv < CV) {
         unpack16<T>(*(const uint4*)(x + m * ldx + cv * V), f[j]);
 #pragma unroll
         for (int e = 0; e < V; e++) s += f[j][e];
       }
     }
-    const float mean = wave_sum(s) / (float)C;
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * invC;
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < LN_MAXV; j++) {
-      int cv = lane + 64 * j;
-      if (cv < CV) {
+      const int cv = sub + LPR * j;
+      if (ok && cv < CV) {
 #pragma unroll
         for (int e = 0; e < V; e++) { float d = f[j][e] - mean; q += d * d; }
       }
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-    const float* pe_row = pe ? pe + (int64_t)((m / rows_per_frame) % frames) * C : nullptr;
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q * invC + eps);
+    const float* pe_row = (pe && ok) ? pe + (int64_t)((m / rows_per_frame) % frames) * C : nullptr;
 #pragma unroll
     for (int j = 0; j < LN_MAXV; j++) {
-      int cv = lane + 64 * j;
-      if (cv < CV) {
-        float o[V];
+      const int cv = sub + LPR * j;
+      if (ok && cv < CV) {
+        float g[V], b[V], o[V];
+        *(float4*)&g[0] = *(const float4*)(gamma + cv * V);
+        *(float4*)&b[0] = *(const float4*)(beta + cv * V);
+        if constexpr (V == 8) {
+          *(float4*)&g[4] = *(const float4*)(gamma + cv * V + 4);
+          *(float4*)&b[4] = *(const float4*)(beta + cv * V + 4);
+        }
 #pragma unroll
         for (int e = 0; e < V; e++) {
-          int c = cv * V + e;
-          float v = (f[j][e] - mean) * rstd * gamma[c] + beta[c];
+          float v = (f[j][e] - mean) * rstd * g[e] + b[e];
           if (pe_row) {
             // the reference adds pe to the LN output tensor (in compute dtype) => round first in bf16 mode
             if constexpr (sizeof(T) == 2) v = bf2f(f2bf(v));
-            v += pe_row[c];
+            v += pe_row[cv * V + e];
           }
           o[e] = v;
         }
@@ -263,6 +283,27 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
       }
     }
   }
+}
+
+template <typename T>
+static void launch_layernorm(const T* x, int ldx, const float* gamma, const float* beta, T* y, int ldy, int64_t M, int C, float eps,
+                             const float* pe, int rpf, int frames, hipStream_t st) {
+  const int CV = C / TT<T>::VEC;
+  int lpr = 1;
+  while (lpr * LN_MAXV < CV) lpr *= 2;
+  const int rpw = 64 / lpr;
+  int64_t g = (M + 4 * rpw - 1) / (4 * rpw); if (g > 256 * 16) g = 256 * 16;
+#define EMO_LN(L) layernorm_kernel<T, L><<<(int)g, 256, 0, st>>>(x, ldx, gamma, beta, y, ldy, M, C, eps, pe, rpf, frames)
+  switch (lpr) {
+    case 1: EMO_LN(1); break;
+    case 2: EMO_LN(2); break;
+    case 4: EMO_LN(4); break;
+    case 8: EMO_LN(8); break;
+    case 16: EMO_LN(16); break;
+    case 32: EMO_LN(32); break;
+    default: EMO_LN(64); break;
+  }
+#undef EMO_LN
 }
 
 extern "C" int emo_layernorm(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, int64_t M, int C,
@@ -274,10 +315,10 @@ extern "C" int emo_layernorm(const void* x, int ldx, const float* gamma, const f
             "emo_layernorm: M=%lld C=%d ldx=%d ldy=%d", (long long)M, C, ldx, ldy);
   EMO_CHECK(C / V <= 64 * LN_MAXV, EMO_ERR_UNSUPPORTED, "emo_layernorm: C=%d too wide", C);
   EMO_CHECK(!pe || (rows_per_frame > 0 && frames > 0), EMO_ERR_BAD_SHAPE, "emo_layernorm: pe needs rows_per_frame/frames");
-  int64_t g = (M + 3) / 4; if (g > 256 * 16) g = 256 * 16;
+  EMO_CHECK(((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0, EMO_ERR_BAD_SHAPE, "emo_layernorm: gamma/beta alignment");
   hipStream_t st = as_stream(stream);
-  if (dtype == EMO_F32) layernorm_kernel<float><<<(int)g, 256, 0, st>>>((const float*)x, ldx, gamma, beta, (float*)y, ldy, M, C, eps, pe, rows_per_frame, frames);
-  else layernorm_kernel<bf16_t><<<(int)g, 256, 0, st>>>((const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, M, C, eps, pe, rows_per_frame, frames);
+  if (dtype == EMO_F32) launch_layernorm<float>((const float*)x, ldx, gamma, beta, (float*)y, ldy, M, C, eps, pe, rows_per_frame, frames, st);
+  else launch_layernorm<bf16_t>((const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, M, C, eps, pe, rows_per_frame, frames, st);
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }

@@ -37,18 +37,29 @@ class KernelProfiler:
     def __init__(self):
         self.records = []   # (name, flops, bytes, ev0, ev1)
 
-    def launch(self, name, flops, nbytes, fn):
+    def launch(self, name, flops, nbytes, fn, tag=""):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
-        self.records.append((name, flops, nbytes, e0, e1))
+        self.records.append((name, flops, nbytes, e0, e1, tag))
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, fl, nb, e0, e1 in self.records:
+        for name, fl, nb, e0, e1, _tag in self.records:
             d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += nb
+        return out
+
+    def by_shape(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, fl, nb, e0, e1, tag in self.records:
+            d = out.setdefault((name, tag), dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["flops"] += fl
@@ -59,11 +70,11 @@ class KernelProfiler:
 PROFILER = None  # set to a KernelProfiler to time launches
 
 
-def _launch(name, flops, nbytes, fn):
+def _launch(name, flops, nbytes, fn, tag=""):
     if PROFILER is None:
         fn()
     else:
-        PROFILER.launch(name, flops, nbytes, fn)
+        PROFILER.launch(name, flops, nbytes, fn, tag)
 
 
 def _stream():
@@ -190,7 +201,7 @@ def layer_norm(x: torch.Tensor, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0
 
 # ----------------------------------------------------------------------------- GEMM / conv
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, geglu=False,
-         out_scale=1.0, out=None, transpose_rows=0, transpose_ld=0, conv=None) -> torch.Tensor:
+         out_scale=1.0, out=None, transpose_rows=0, transpose_ld=0, conv=None, split_k=None) -> torch.Tensor:
     """out = epilogue(a @ w.T).  a (M, K) rows view; w (N, K) contiguous in the compute dtype.
     conv = dict(H, W, Cin, stride, upsample2x, Ho, Wo) selects the implicit 3x3 conv loader (then a is
     the (B*F*H*W, >=Cin) NHWC input and M = B*F*Ho*Wo).
@@ -231,10 +242,18 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
         p.conv_taps, p.H, p.W_, p.Cin = 9, conv["H"], conv["W"], conv["Cin"]
         p.stride, p.upsample2x, p.Ho, p.Wo = conv["stride"], int(conv["upsample2x"]), conv["Ho"], conv["Wo"]
     p.dtype = dt(a)
+    lib = _lib.load()
+    sk = lib.emo_gemm_suggest_split_k(M, N, K, p.dtype) if split_k is None else split_k
+    ws = None
+    if sk > 1:
+        ws = torch.empty(lib.emo_gemm_workspace_bytes(M, N, sk) // 4, device=a.device, dtype=torch.float32)
+        p.split_k, p.workspace = sk, ws.data_ptr()
     esz = a.element_size()
     _launch("gemm_conv3x3" if conv is not None else "gemm_dense", 2.0 * M * N * K,
             esz * (float(M) * (K if conv is None else conv["Cin"]) + float(N) * K + float(M) * n_out),
-            lambda: check(_lib.load().emo_gemm(C.byref(p), _stream()), "emo_gemm"))
+            lambda: check(_lib.load().emo_gemm(C.byref(p), _stream()), "emo_gemm"),
+            tag=f"M={M} N={N} K={K}" + (" geglu" if geglu else "") + (" T" if transpose_rows else "") +
+                (f" s{conv['stride']}{'u' if conv['upsample2x'] else ''}" if conv is not None else "") + (f" sk{sk}" if sk > 1 else ""))
     return out
 
 
@@ -270,7 +289,8 @@ def attention(q, k0, v0t, Lk0, *, B, Lq, heads, d, scale, seg0_div=1, k1=None, v
     p.B, p.Lq, p.heads, p.d, p.scale, p.dtype = B, Lq, heads, d, float(scale), dt(q)
     esz = q.element_size()
     _launch("attention", 4.0 * B * heads * Lq * (Lk0 + Lk1) * d, esz * float(B) * heads * d * (2 * Lq + 2 * (Lk0 + Lk1)),
-            lambda: check(_lib.load().emo_attention(C.byref(p), _stream()), "emo_attention"))
+            lambda: check(_lib.load().emo_attention(C.byref(p), _stream()), "emo_attention"),
+            tag=f"B={B} Lq={Lq} Lk={Lk0}+{Lk1} h={heads} d={d}")
     return out
 
 

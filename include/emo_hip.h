@@ -114,8 +114,16 @@ typedef struct {
   /* conv geometry (conv_taps==9 -> implicit 3x3 GEMM over NHWC A; 0 -> dense) */
   int conv_taps; int H; int W_; int Cin; int stride; int upsample2x; int Ho; int Wo;
   int dtype;
+  /* split-K for problems with too few output tiles to fill 256 CUs (small M at the 8x8 / 16x16 levels):
+   * split_k > 1 slices K over grid.y, f32 partial tiles go to `workspace` ([split_k][M][N] floats, at least
+   * emo_gemm_workspace_bytes(p) bytes) and a second kernel reduces them in a fixed order (deterministic)
+   * and applies the epilogue.  split_k <= 1: single pass, workspace unused. */
+  int split_k; void* workspace;
 } emo_gemm_params;
 int emo_gemm(const emo_gemm_params* p, void* stream);
+/* heuristic split factor for (M, N, K) and the workspace it needs */
+int emo_gemm_suggest_split_k(int64_t M, int N, int K, int dtype);
+size_t emo_gemm_workspace_bytes(int64_t M, int N, int split_k);
 
 /* ---- attention -------------------------------------------------------------------------------
  * Flash-style softmax(q k^T * scale) v, scores never leave the chip.  Replaces

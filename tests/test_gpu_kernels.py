@@ -279,3 +279,35 @@ def test_cfg_step_and_accumulate():
     ref[:, [4, 5, 0]] = pred.reshape(3, HW, C4).permute(2, 0, 1)
     torch.testing.assert_close(acc.cpu(), ref)
     assert cnt.cpu().tolist() == [1, 0, 0, 0, 1, 1]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sk", [2, 5])
+def test_gemm_split_k_matches_single_pass(dtype, sk):
+    """split-K (small-M levels) must reproduce the fused single-pass epilogue: bias, rowbias, GEGLU,
+    residual, scale and the V^T store, with a deterministic fixed-order reduction."""
+    o = ops()
+    M, K, No = 2 * 48, 640, 64
+    a = q(seeded_randn((M, K), 41), dtype)
+    w, bias = q(seeded_randn((2 * No, K), 42) / 25, dtype), 0.1 * seeded_randn((2 * No,), 43)
+    res = q(seeded_randn((M, 2 * No), 44), dtype)
+    rb = seeded_randn((2, 2 * No), 45)
+    dv = lambda t: t.to(DEV).to(dtype)
+    ref = (F.linear(a, w, bias) + rb.repeat_interleave(48, 0) + res) * 0.5
+    got = o.gemm(dv(a), dv(w), bias.to(DEV), rowbias=rb.to(DEV), rows_per_batch=48, residual=dv(res), out_scale=0.5, split_k=sk)
+    close(got, ref, dtype)
+    got_b = o.gemm(dv(a), dv(w), bias.to(DEV), rowbias=rb.to(DEV), rows_per_batch=48, residual=dv(res), out_scale=0.5, split_k=sk)
+    assert torch.equal(got, got_b)  # deterministic
+    hv, gate = F.linear(a, w, bias).chunk(2, dim=-1)
+    wi = torch.cat([w[:No].reshape(No // 32, 32, K), w[No:].reshape(No // 32, 32, K)], 1).reshape(2 * No, K)
+    bi = torch.cat([bias[:No].reshape(No // 32, 32), bias[No:].reshape(No // 32, 32)], 1).reshape(2 * No)
+    close(o.gemm(dv(a), dv(wi).contiguous(), bi.to(DEV).contiguous(), geglu=True, split_k=sk), hv * F.gelu(gate), dtype)
+    got3 = o.gemm(dv(a), dv(w), transpose_rows=48, transpose_ld=48, split_k=sk)
+    close(got3, F.linear(a, w).reshape(2, 48, 2 * No).permute(0, 2, 1), dtype)
+    # conv with split-K (8x8 level of the ReferenceNet: M=128)
+    x = q(seeded_randn((2, 64, 8, 8), 46), dtype)
+    wt = q(seeded_randn((96, 64, 3, 3), 47) / 24, dtype)
+    refc = F.conv2d(x, wt, None, padding=1).permute(0, 2, 3, 1).reshape(-1, 96)
+    gotc, _, _ = o.conv3x3(dv(x.permute(0, 2, 3, 1).reshape(-1, 64).contiguous()), dv(wt.permute(0, 2, 3, 1).reshape(96, 576)).contiguous(),
+                           None, 2, 8, 8, split_k=sk)
+    close(gotc, refc, dtype)
