@@ -8,64 +8,133 @@
 // (resnet.py:98) and nearest-x2-upsample-folded (resnet.py:74-82: the interpolate is folded into the
 // load indexing, the upsampled tensor never exists).
 //
-// Structure (v1): 128x128 block tile, 64 BYTES of K per stage (bf16: 32, f32: 16 k-values), 4 waves in
-// 2x2 each owning 64x64 = 2x2 MFMA 32x32 accumulators (64 acc VGPRs); global -> registers -> LDS staging
-// with the next stage's loads issued before the MFMAs of the current one (double-buffered LDS, one
-// barrier per stage).  LDS rows are 64 B + 16 B pad = 80 B (5 x 16 B, odd) so the ds_read_b128 fragment
-// reads of a 16-lane group land on 16 distinct 16-byte slots (conflict-free).
+// Structure (v3):
+//   * block = 4 waves; a wave owns WTM x WTN MFMA 32x32 tiles: 2x2 waves of 64x64 (BM=BN=128) or 4x1 waves of
+//     32x160 (BM=128, BN=160: every channel count of the SD-1.5 UNet is a multiple of 160, so N=320 is two
+//     full tiles instead of 2.5 of 128).
+//   * K is streamed in 64-BYTE stages (bf16: 32, f32: 16 k-values) through a 4-deep LDS ring filled by
+//     ASYNCHRONOUS direct-to-LDS loads (global_load_lds_dwordx4, no VGPR round trip): three stages are in
+//     flight while the fourth is consumed, `s_waitcnt vmcnt(N)` is COUNTED (never 0 in steady state) and there
+//     is one raw s_barrier per stage.  The HBM-bound level-0 GEMMs (K = 320) need that many bytes in flight;
+//     the compute-bound ones get their MFMAs fed without a drain per stage.
+//   * the LDS image of a stage is lane-linear (a glds writes wave-base + lane*16), rows are 64 B, so the
+//     16-byte chunk position is XOR-swizzled with (row>>2)&3 on the SOURCE address and on the fragment read:
+//     the ds_read_b128 of a 16-lane group then hits 16 distinct 16-byte slots (conflict-free).
+//   * fragment reads are inline-asm ds_read_b128 with hand-counted lgkmcnt: hipcc drains vmcnt(0) in front of
+//     every C++-level LDS read while a glds is in flight, which would serialise the ring.
+//   * out-of-range rows / K tails / conv zero padding source a 16-byte zero page instead of branching.
+//   * row-major store: the MFMA is issued with the operands SWAPPED (acc = W_frag x A_frag), so a lane ends up
+//     with 4 consecutive output COLUMNS of one row per register quad -> 8-byte (bf16) / 16-byte (f32)
+//     row-per-lane stores instead of 2-byte column-per-lane stores.  V^T store (TRANS): operands unswapped,
+//     a lane holds 4 consecutive ROWS of one column.
+//   * XCD-aware tile order: block b runs on XCD b%8; tiles are dealt so that each XCD walks a contiguous run
+//     of tiles (n fastest) and the A rows it re-reads stay in that XCD's L2.
 //   bf16: v_mfma_f32_32x32x16_bf16, f32 accumulate.   f32: v_mfma_f32_32x32x2_f32 (exact f32 fma chain).
 // Epilogue fused: bias, per-batch row bias (temb), GEGLU, residual, scale, row-major or V^T store.
+// Split-K (small M): f32 partial slabs + a fixed-order reduce/epilogue kernel (deterministic).
 #include "common.h"
 
-static constexpr int BM = 128, BN = 128, KBYTES = 64, ROWB = KBYTES + 16;
+static constexpr int KBYTES = 64;
 static constexpr int GEMM_THREADS = 256;
+static constexpr int NS = 4;   // LDS ring depth
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0, 0, 0, 0};
+
+template <int WTM, int WTN, int WVM, int WVN> struct GemmTile {
+  static_assert(WVM * WVN == 4, "4 waves");
+  static constexpr int BM = 32 * WTM * WVM, BN = 32 * WTN * WVN;
+  static constexpr int A_ROWS = (BM + 63) / 64 * 64, B_ROWS = (BN + 63) / 64 * 64;
+  static constexpr int A_BYTES = A_ROWS * KBYTES, B_BYTES = B_ROWS * KBYTES;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int LDS_BYTES = NS * STAGE_BYTES;
+  static constexpr int LA = A_ROWS / 64, LB = B_ROWS / 64, LPS = LA + LB;   // glds per wave per stage
+};
+
+#define EMO_GLDS16(gptr, lptr) \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ uint4 lds_read16(unsigned addr) {
+  uint4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
 
 struct ConvRow { int img, iy0, ix0; };
 
-template <typename T, bool CONV>
+template <typename T, bool CONV, bool TRANS, int WTM, int WTN, int WVM, int WVN>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const emo_gemm_params p) {
+  using Tile = GemmTile<WTM, WTN, WVM, WVN>;
   constexpr int V = TT<T>::VEC;          // elements per 16 B
   constexpr int BK = KBYTES / (int)sizeof(T);
-  constexpr int NL = BM * 4 / GEMM_THREADS;  // 16-byte vectors per thread per operand (=2)
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][BM * ROWB];  // [buf][A|B]
+  constexpr int BM = Tile::BM, BN = Tile::BN, LA = Tile::LA, LB = Tile::LB, LPS = Tile::LPS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wvm = wave / WVN, wvn = wave % WVN;
+  const int half = lane >> 5, l31 = lane & 31;
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int64_t bm = (int64_t)(blockIdx.x / tiles_n) * BM;
-  const int bn = (blockIdx.x % tiles_n) * BN;
+  // XCD-aware tile order (bijective): XCD x = b % 8 owns a contiguous run of tiles
+  int tile;
+  {
+    const int nt_all = gridDim.x, b = blockIdx.x;
+    const int qn = nt_all >> 3, rn = nt_all & 7, x = b & 7, idx = b >> 3;
+    tile = (x < rn ? x * (qn + 1) : rn * (qn + 1) + (x - rn) * qn) + idx;
+  }
+  const int64_t bm = (int64_t)(tile / tiles_n) * BM;
+  const int bn = (tile % tiles_n) * BN;
   const int nsplit = p.split_k > 1 ? p.split_k : 1;
 
   const T* __restrict__ A = (const T*)p.A;
   const T* __restrict__ W = (const T*)p.W;
+  const T* zero = (const T*)g_zero_page;
 
-  // per-thread load slots
-  int a_row[NL], a_chunk[NL];
-  ConvRow a_cr[NL];
-  bool a_ok[NL];
+  // ---- loader geometry: glds #i of this wave fills LDS rows (i*4 + wave)*16 .. +16 of the operand; lane l
+  // writes physical chunk (l&3) of row (l>>2), which holds LOGICAL chunk (l&3) ^ ((row>>2)&3)
+  const int lrow = lane >> 2;
+  int a_klog[LA];
+  const T* a_base[LA];    // dense: row pointer (k added per stage); conv: unused
+  ConvRow a_cr[LA];
+  bool a_ok[LA];
 #pragma unroll
-  for (int i = 0; i < NL; i++) {
-    int v = tid + i * GEMM_THREADS;
-    a_row[i] = v >> 2; a_chunk[i] = v & 3;
-    int64_t m = bm + a_row[i];
-    a_ok[i] = m < p.M;
+  for (int i = 0; i < LA; i++) {
+    const int row = (i * 4 + wave) * 16 + lrow;
+    a_klog[i] = (lane & 3) ^ ((row >> 2) & 3);
+    const int64_t m = bm + row;
+    a_ok[i] = row < BM && m < p.M;
+    a_base[i] = A + (a_ok[i] ? m : 0) * p.lda;
     if (CONV) {
-      int hw = p.Ho * p.Wo;
-      int img = (int)(m / hw); int rem = (int)(m % hw);
-      int oy = rem / p.Wo, ox = rem % p.Wo;
+      const int hw = p.Ho * p.Wo;
+      const int64_t mm = a_ok[i] ? m : 0;
+      const int img = (int)(mm / hw), rem = (int)(mm % hw);
+      const int oy = rem / p.Wo, ox = rem % p.Wo;
       a_cr[i].img = img; a_cr[i].iy0 = oy * p.stride - 1; a_cr[i].ix0 = ox * p.stride - 1;
     }
   }
-
-  uint4 ra[NL], rb[NL];
-  auto load_global = [&](int kt) {
+  int b_klog[LB];
+  const T* b_base[LB];
+  bool b_ok[LB];
 #pragma unroll
-    for (int i = 0; i < NL; i++) {
-      const int k0 = kt * BK + a_chunk[i] * V;
-      uint4 va = make_uint4(0, 0, 0, 0);
+  for (int i = 0; i < LB; i++) {
+    const int row = (i * 4 + wave) * 16 + lrow;
+    b_klog[i] = (lane & 3) ^ ((row >> 2) & 3);
+    const int n = bn + row;
+    b_ok[i] = row < BN && n < p.N;
+    b_base[i] = W + (int64_t)(b_ok[i] ? n : 0) * p.K;
+  }
+
+  auto issue = [&](int kt, int slot) {   // kt: absolute k-stage index
+    unsigned char* sa = lds + slot * Tile::STAGE_BYTES;
+    unsigned char* sb = sa + Tile::A_BYTES;
+#pragma unroll
+    for (int i = 0; i < LA; i++) {
+      const int k0 = kt * BK + a_klog[i] * V;
+      const T* src = zero;
       if (a_ok[i] && k0 < p.K) {
         if (!CONV) {
-          va = *(const uint4*)(A + (bm + a_row[i]) * p.lda + k0);
+          src = a_base[i] + k0;
         } else {
           const int tap = k0 / p.Cin, ci = k0 - tap * p.Cin;
           const int ky = tap / 3, kx = tap - ky * 3;
@@ -73,30 +142,25 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const emo_gemm_param
           const int Hin = p.upsample2x ? 2 * p.H : p.H, Win = p.upsample2x ? 2 * p.W_ : p.W_;
           if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
             if (p.upsample2x) { iy >>= 1; ix >>= 1; }
-            va = *(const uint4*)(A + (((int64_t)a_cr[i].img * p.H + iy) * p.W_ + ix) * p.lda + ci);
+            src = A + (((int64_t)a_cr[i].img * p.H + iy) * p.W_ + ix) * p.lda + ci;
           }
         }
       }
-      ra[i] = va;
-      const int n = bn + a_row[i];
-      uint4 vb = make_uint4(0, 0, 0, 0);
-      if (n < p.N && k0 < p.K) vb = *(const uint4*)(W + (int64_t)n * p.K + k0);
-      rb[i] = vb;
+      EMO_GLDS16(src, sa + (i * 4 + wave) * 1024);
     }
-  };
-  auto store_lds = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < NL; i++) {
-      *(uint4*)(&lds[buf][0][a_row[i] * ROWB + a_chunk[i] * 16]) = ra[i];
-      *(uint4*)(&lds[buf][1][a_row[i] * ROWB + a_chunk[i] * 16]) = rb[i];
+    for (int i = 0; i < LB; i++) {
+      const int k0 = kt * BK + b_klog[i] * V;
+      const T* src = (b_ok[i] && k0 < p.K) ? b_base[i] + k0 : zero;
+      EMO_GLDS16(src, sb + (i * 4 + wave) * 1024);
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[WTM][WTN];
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < WTM; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < WTN; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
@@ -104,96 +168,164 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const emo_gemm_param
   const int nk_per = (nk_all + nsplit - 1) / nsplit;
   const int kt0 = blockIdx.y * nk_per;
   const int nk = (kt0 + nk_per <= nk_all ? nk_per : nk_all - kt0);   // may be <= 0 for a trailing empty slice
-  if (nk > 0) {
-    load_global(kt0);
-    store_lds(0);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < nk; kt++) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_global(kt0 + kt + 1);
-    const unsigned char* la = &lds[cur][0][(wm * 64 + l31) * ROWB + half * 16];
-    const unsigned char* lb = &lds[cur][1][(wn * 64 + l31) * ROWB + half * 16];
+
+  // fragment read addresses (LDS byte offsets, stage-relative), swizzled
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  unsigned fa_off[WTM][2], fb_off[WTN][2];
 #pragma unroll
-    for (int kk = 0; kk < 2; kk++) {
-      uint4 fa0 = *(const uint4*)(la + kk * 32);
-      uint4 fa1 = *(const uint4*)(la + 32 * ROWB + kk * 32);
-      uint4 fb0 = *(const uint4*)(lb + kk * 32);
-      uint4 fb1 = *(const uint4*)(lb + 32 * ROWB + kk * 32);
-      acc[0][0] = mma16<T>(fa0, fb0, acc[0][0]);
-      acc[0][1] = mma16<T>(fa0, fb1, acc[0][1]);
-      acc[1][0] = mma16<T>(fa1, fb0, acc[1][0]);
-      acc[1][1] = mma16<T>(fa1, fb1, acc[1][1]);
-    }
-    if (kt + 1 < nk) store_lds(cur ^ 1);
-    __syncthreads();
+  for (int i = 0; i < WTM; i++) {
+    const int r = wvm * 32 * WTM + i * 32 + l31;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) fa_off[i][kk] = r * KBYTES + (((kk * 2 + half) ^ ((r >> 2) & 3)) * 16);
+  }
+#pragma unroll
+  for (int j = 0; j < WTN; j++) {
+    const int r = wvn * 32 * WTN + j * 32 + l31;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) fb_off[j][kk] = Tile::A_BYTES + r * KBYTES + (((kk * 2 + half) ^ ((r >> 2) & 3)) * 16);
   }
 
-  // ------------------------------------------------------------------ split-K: raw f32 partial tile to the workspace
-  if (nsplit > 1) {
-    float* __restrict__ ws = (float*)p.workspace + (int64_t)blockIdx.y * p.M * p.N;
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+  for (int s = 0; s < NS - 1; s++)
+    if (s < nk) issue(kt0 + s, s);
+  for (int kt = 0; kt < nk; kt++) {
+    // stage kt must have landed; up to min(NS-2, nk-1-kt) younger stages may still be in flight
+    const int rem = nk - 1 - kt;
+    if (rem >= NS - 2) wait_vmcnt<(NS - 2) * LPS>();
+    else if (rem == 1) wait_vmcnt<LPS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // everyone's part of stage kt landed; everyone finished reading slot (kt-1)%NS
+    if (kt + NS - 1 < nk) issue(kt0 + kt + NS - 1, (kt + NS - 1) % NS);
+    const unsigned st = lds_base + (kt % NS) * Tile::STAGE_BYTES;
+    uint4 fa[2][WTM], fb[2][WTN];
 #pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const int n = bn + wn * 64 + j * 32 + l31;
-        if (n >= p.N) continue;
+    for (int kk = 0; kk < 2; kk++) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int64_t m = bm + wm * 64 + i * 32 + mfma_row(r, half);
-          if (m < p.M) ws[m * p.N + n] = acc[i][j][r];
-        }
+      for (int i = 0; i < WTM; i++) fa[kk][i] = lds_read16(st + fa_off[i][kk]);
+#pragma unroll
+      for (int j = 0; j < WTN; j++) fb[kk][j] = lds_read16(st + fb_off[j][kk]);
+    }
+    wait_lgkmcnt<WTM + WTN>();            // the kk=0 fragments
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < WTM; i++)
+#pragma unroll
+      for (int j = 0; j < WTN; j++) {
+        if constexpr (TRANS) acc[i][j] = mma16<T>(fa[0][i], fb[0][j], acc[i][j]);   // rows = m, lane = n
+        else acc[i][j] = mma16<T>(fb[0][j], fa[0][i], acc[i][j]);                   // rows = n, lane = m
       }
-    return;
+    wait_lgkmcnt<0>();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < WTM; i++)
+#pragma unroll
+      for (int j = 0; j < WTN; j++) {
+        if constexpr (TRANS) acc[i][j] = mma16<T>(fa[1][i], fb[1][j], acc[i][j]);
+        else acc[i][j] = mma16<T>(fb[1][j], fa[1][i], acc[i][j]);
+      }
   }
-  // ------------------------------------------------------------------ epilogue
+
   T* __restrict__ C = (T*)p.C;
   const T* __restrict__ R = (const T*)p.residual;
-  const int n_out_total = p.geglu ? p.N / 2 : p.N;
+  const int64_t wm0 = bm + wvm * 32 * WTM;
+  const int wn0 = bn + wvn * 32 * WTN;
+
+  if constexpr (!TRANS) {
+    // lane <-> output row m; register quad g of tile j <-> columns j*32 + 8*g + 4*half + {0..3}
 #pragma unroll
-  for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < WTM; i++) {
+      const int64_t m = wm0 + i * 32 + l31;
+      const bool m_ok = m < p.M;
+      if (nsplit > 1) {
+        float* __restrict__ ws = (float*)p.workspace + ((int64_t)blockIdx.y * p.M + (m_ok ? m : 0)) * p.N;
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      if (p.geglu && j == 1) continue;  // gate tile is consumed together with the value tile
-      const int ncol_w = bn + wn * 64 + j * 32 + l31;  // column in W-row space
-      if (ncol_w >= p.N) continue;
-      const int ncol = p.geglu ? ((bn + wn * 64) >> 1) + l31 : ncol_w;  // output column
-      const float bias_v = p.bias ? p.bias[ncol_w] : 0.f;
-      const float bias_g = (p.geglu && p.bias) ? p.bias[ncol_w + 32] : 0.f;
-      float o[16];
+        for (int j = 0; j < WTN; j++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int64_t m = bm + wm * 64 + i * 32 + mfma_row(r, half);
-        float v = acc[i][j][r] + bias_v;
-        if (p.rowbias && m < p.M) v += p.rowbias[(m / p.rows_per_batch) * p.ld_rowbias + ncol_w];
-        if (p.geglu) v = v * gelu_erf_f(acc[i][1][r] + bias_g);
-        if (R && m < p.M) v += TT<T>::ld(R + m * p.ldr + ncol);
-        o[r] = v * p.out_scale;
+          for (int g = 0; g < 4; g++) {
+            const int n0 = wn0 + j * 32 + 8 * g + 4 * half;
+            if (m_ok && n0 < p.N)   // N % 4 == 0 is enforced for split-K
+              *(float4*)(ws + n0) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+          }
+        continue;
       }
-      if (!p.transpose_out) {
+      const float* rbias = (p.rowbias && m_ok) ? p.rowbias + (m / p.rows_per_batch) * p.ld_rowbias : nullptr;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int64_t m = bm + wm * 64 + i * 32 + mfma_row(r, half);
-          if (m < p.M) TT<T>::st(C + m * p.ldc + ncol, o[r]);
-        }
-      } else {
-        // V^T store: Ct[m / t_rows][ncol][m % t_rows]; a lane's 4 consecutive rows are contiguous there.
+      for (int j = 0; j < WTN; j++) {
+        if (p.geglu && (j & 1)) continue;   // gate tile is consumed with its value tile
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int64_t m0 = bm + wm * 64 + i * 32 + q * 8 + 4 * half;
+        for (int g = 0; g < 4; g++) {
+          const int nw0 = wn0 + j * 32 + 8 * g + 4 * half;              // column in W-row space
+          const int no0 = p.geglu ? ((wn0 + j * 32) >> 1) + 8 * g + 4 * half : nw0;   // output column
+          float o[4];
 #pragma unroll
           for (int e = 0; e < 4; e++) {
-            const int64_t m = m0 + e;
-            if (m < p.M) {
-              const int64_t b = m / p.t_rows, ml = m % p.t_rows;
-              TT<T>::st(C + b * p.t_batch_stride + (int64_t)ncol * p.t_ld + ml, o[q * 4 + e]);
+            const int nw = nw0 + e;
+            float v = acc[i][j][4 * g + e];
+            if (nw < p.N) {
+              if (p.bias) v += p.bias[nw];
+              if (rbias) v += rbias[nw];
+              if (p.geglu) {
+                float gt = acc[i][(j + 1) % WTN][4 * g + e];
+                if (p.bias) gt += p.bias[nw + 32];
+                v = v * gelu_erf_f(gt);
+              }
+            }
+            o[e] = v;
+          }
+          const int n_out = p.geglu ? p.N / 2 : p.N;
+          if (!m_ok) continue;
+          if (no0 + 3 < n_out && ((p.ldc | (R ? p.ldr : 0)) & 3) == 0) {
+            if (R) {
+              if constexpr (sizeof(T) == 2) {
+                const uint2 rv = *(const uint2*)(R + m * p.ldr + no0);
+                o[0] += __uint_as_float(rv.x << 16); o[1] += __uint_as_float(rv.x & 0xffff0000u);
+                o[2] += __uint_as_float(rv.y << 16); o[3] += __uint_as_float(rv.y & 0xffff0000u);
+              } else {
+                const float4 rv = *(const float4*)(R + m * p.ldr + no0);
+                o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] *= p.out_scale;
+            if constexpr (sizeof(T) == 2) *(uint2*)(C + m * p.ldc + no0) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+            else *(float4*)(C + m * p.ldc + no0) = make_float4(o[0], o[1], o[2], o[3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              if (no0 + e < n_out) {
+                float v = o[e];
+                if (R) v += TT<T>::ld(R + m * p.ldr + no0 + e);
+                TT<T>::st(C + m * p.ldc + no0 + e, v * p.out_scale);
+              }
             }
           }
         }
       }
     }
+  } else {
+    // TRANS: lane <-> column n; register r <-> row m.  V^T store Ct[m / t_rows][n][m % t_rows]
+#pragma unroll
+    for (int i = 0; i < WTM; i++)
+#pragma unroll
+      for (int j = 0; j < WTN; j++) {
+        const int n = wn0 + j * 32 + l31;
+        if (n >= p.N) continue;
+        const float bias_v = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int64_t m = wm0 + i * 32 + mfma_row(r, half);
+          if (m >= p.M) continue;
+          if (nsplit > 1) {
+            ((float*)p.workspace)[((int64_t)blockIdx.y * p.M + m) * p.N + n] = acc[i][j][r];
+            continue;
+          }
+          float v = acc[i][j][r] + bias_v;
+          if (p.rowbias) v += p.rowbias[(m / p.rows_per_batch) * p.ld_rowbias + n];
+          const int64_t b = m / p.t_rows, ml = m % p.t_rows;
+          TT<T>::st(C + b * p.t_batch_stride + (int64_t)n * p.t_ld + ml, v * p.out_scale);
+        }
+      }
   }
-  (void)n_out_total;
 }
 
 // split-K second pass: fixed-order reduction of the f32 partials + the same fused epilogue
@@ -224,19 +356,64 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(const emo_gem
   }
 }
 
-extern "C" int emo_gemm_suggest_split_k(int64_t M, int N, int K, int dtype) {
-  const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+// ------------------------------------------------------------------------------------------ host side
+struct GemmPlan { int nt5, split_k; };
+
+static GemmPlan plan_gemm(int64_t M, int N, int K, int dtype, int geglu) {
+  GemmPlan pl;
+  pl.nt5 = (!geglu && N % 160 == 0) ? 1 : 0;
+  const int bn = pl.nt5 ? 160 : 128;
+  const int64_t tiles = ((M + 127) / 128) * ((N + bn - 1) / bn);
   const int bk = dtype == EMO_F32 ? 16 : 32;
   const int nk = (K + bk - 1) / bk;
-  if (tiles >= 192 || nk < 16) return 1;
-  int s = (int)((512 + tiles - 1) / tiles);       // aim at ~2 blocks per CU
-  const int max_by_k = nk / 8;                     // keep >= 8 k-steps per slice
-  if (s > max_by_k) s = max_by_k;
-  if (s > 32) s = 32;
-  return s < 2 ? 1 : s;
+  int s = 1;
+  if (tiles < 192 && nk >= 16 && N % 4 == 0) {
+    s = (int)((512 + tiles - 1) / tiles);        // aim at ~2 blocks per CU
+    const int max_by_k = nk / 8;                  // keep >= 8 k-steps per slice
+    if (s > max_by_k) s = max_by_k;
+    if (s > 32) s = 32;
+    if (s < 2) s = 1;
+  }
+  pl.split_k = s;
+  return pl;
 }
+
+extern "C" int emo_gemm_suggest_split_k(int64_t M, int N, int K, int dtype) { return plan_gemm(M, N, K, dtype, 0).split_k; }
 extern "C" size_t emo_gemm_workspace_bytes(int64_t M, int N, int split_k) {
   return split_k > 1 ? (size_t)split_k * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+template <typename T, bool CONV, bool TRANS, int WTM, int WTN, int WVM, int WVN>
+static int launch_gemm(const emo_gemm_params& p, int S, hipStream_t st) {
+  using Tile = GemmTile<WTM, WTN, WVM, WVN>;
+  auto kern = gemm_kernel<T, CONV, TRANS, WTM, WTN, WVM, WVN>;
+  if (Tile::LDS_BYTES > 64 * 1024) {
+    static bool once = false;
+    if (!once) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES);
+      if (e != hipSuccess) return emo_fail(EMO_ERR_HIP, "emo_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      once = true;
+    }
+  }
+  const int64_t tiles = ((p.M + Tile::BM - 1) / Tile::BM) * ((p.N + Tile::BN - 1) / Tile::BN);
+  if (tiles >= (1ll << 31)) return emo_fail(EMO_ERR_BAD_SHAPE, "emo_gemm: too many tiles");
+  dim3 grid((unsigned)tiles, (unsigned)S);
+  kern<<<grid, GEMM_THREADS, Tile::LDS_BYTES, st>>>(p);
+  EMO_LAUNCH_CHECK();
+  return EMO_OK;
+}
+
+template <typename T, bool CONV, bool TRANS>
+static int dispatch_tile(const emo_gemm_params& p, const GemmPlan& pl, int S, hipStream_t st) {
+  if (pl.nt5) return launch_gemm<T, CONV, TRANS, 1, 5, 4, 1>(p, S, st);   // 4x1 waves of 32x160
+  return launch_gemm<T, CONV, TRANS, 2, 2, 2, 2>(p, S, st);               // 2x2 waves of 64x64
+}
+
+template <typename T>
+static int dispatch_gemm(const emo_gemm_params& p, const GemmPlan& pl, int S, hipStream_t st) {
+  const bool conv = p.conv_taps != 0;
+  if (p.transpose_out) return conv ? dispatch_tile<T, true, true>(p, pl, S, st) : dispatch_tile<T, false, true>(p, pl, S, st);
+  return conv ? dispatch_tile<T, true, false>(p, pl, S, st) : dispatch_tile<T, false, false>(p, pl, S, st);
 }
 
 extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
@@ -251,7 +428,7 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
   EMO_CHECK(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0, EMO_ERR_BAD_SHAPE, "emo_gemm: A/W must be 16-byte aligned");
   if (p.geglu) EMO_CHECK(p.N % 64 == 0, EMO_ERR_BAD_SHAPE, "emo_gemm: GEGLU needs N %% 64 == 0 (N=%d)", p.N);
   if (p.rowbias) EMO_CHECK(p.rows_per_batch > 0 && p.ld_rowbias >= p.N, EMO_ERR_BAD_SHAPE, "emo_gemm: rowbias geometry");
-  if (p.transpose_out) EMO_CHECK(p.t_rows > 0 && p.t_ld >= p.t_rows && !p.geglu, EMO_ERR_BAD_SHAPE, "emo_gemm: transpose geometry");
+  if (p.transpose_out) EMO_CHECK(p.t_rows > 0 && p.t_ld >= p.t_rows && !p.geglu && !p.residual, EMO_ERR_BAD_SHAPE, "emo_gemm: transpose geometry");
   const bool conv = p.conv_taps != 0;
   if (conv) {
     EMO_CHECK(p.conv_taps == 9, EMO_ERR_UNSUPPORTED, "emo_gemm: conv_taps=%d (only 3x3)", p.conv_taps);
@@ -262,20 +439,18 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
     const int He = p.upsample2x ? 2 * p.H : p.H, We = p.upsample2x ? 2 * p.W_ : p.W_;
     EMO_CHECK(p.Ho == (He + 2 - 3) / p.stride + 1 && p.Wo == (We + 2 - 3) / p.stride + 1, EMO_ERR_BAD_SHAPE, "emo_gemm: conv output size");
   }
-  const int64_t tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  EMO_CHECK(tiles < (1ll << 31), EMO_ERR_BAD_SHAPE, "emo_gemm: too many tiles");
-  const int S = p.split_k > 1 ? p.split_k : 1;
-  if (S > 1) EMO_CHECK(p.workspace != nullptr && S <= 65535, EMO_ERR_NULL, "emo_gemm: split_k=%d needs a workspace", S);
-  hipStream_t st = as_stream(stream);
-  dim3 grid((unsigned)tiles, (unsigned)S);
-  if (p.dtype == EMO_F32) {
-    if (conv) gemm_kernel<float, true><<<grid, GEMM_THREADS, 0, st>>>(p);
-    else gemm_kernel<float, false><<<grid, GEMM_THREADS, 0, st>>>(p);
-  } else {
-    if (conv) gemm_kernel<bf16_t, true><<<grid, GEMM_THREADS, 0, st>>>(p);
-    else gemm_kernel<bf16_t, false><<<grid, GEMM_THREADS, 0, st>>>(p);
+  if (!p.transpose_out) {
+    EMO_CHECK(((uintptr_t)p.C % 16) == 0 && (!p.residual || ((uintptr_t)p.residual % 8) == 0), EMO_ERR_BAD_SHAPE, "emo_gemm: C/residual alignment");
   }
-  EMO_LAUNCH_CHECK();
+  GemmPlan pl = plan_gemm(p.M, p.N, p.K, p.dtype, p.geglu);
+  const int S = p.split_k > 1 ? p.split_k : 1;
+  if (S > 1) {
+    EMO_CHECK(p.workspace != nullptr && S <= 65535, EMO_ERR_NULL, "emo_gemm: split_k=%d needs a workspace", S);
+    EMO_CHECK(p.N % 4 == 0, EMO_ERR_BAD_SHAPE, "emo_gemm: split-K needs N %% 4 == 0");
+  }
+  hipStream_t st = as_stream(stream);
+  int rc = p.dtype == EMO_F32 ? dispatch_gemm<float>(p, pl, S, st) : dispatch_gemm<bf16_t>(p, pl, S, st);
+  if (rc) return rc;
   if (S > 1) {
     const int64_t total = p.M * (p.geglu ? p.N / 2 : p.N);
     int64_t g = (total + 255) / 256; if (g > 4096) g = 4096;
