@@ -89,6 +89,20 @@ __device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * 
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf-GELU for the bf16 epilogues: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, far below a bf16 ulp),
+// ~12 VALU ops instead of ocml erff's ~40 - the GEGLU epilogue is VALU-bound otherwise.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * __expf(-z * z);
+  const float erf_v = copysignf(erf_abs, x);
+  return 0.5f * x * (1.0f + erf_v);
+}
+template <typename T> __device__ __forceinline__ float gelu_for(float x) {
+  if constexpr (sizeof(T) == 2) return gelu_erf_fast(x);
+  else return gelu_erf_f(x);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -35,19 +35,19 @@
 #include "common.h"
 
 static constexpr int KBYTES = 64;
-static constexpr int GEMM_THREADS = 256;
-static constexpr int NS = 4;   // LDS ring depth
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0, 0, 0, 0};
 
-template <int WTM, int WTN, int WVM, int WVN> struct GemmTile {
-  static_assert(WVM * WVN == 4, "4 waves");
+template <int WTM, int WTN, int WVM, int WVN, int NS_> struct GemmTile {
+  static constexpr int NS = NS_;   // LDS ring depth
+  static constexpr int NW = WVM * WVN, THREADS = 64 * NW;
   static constexpr int BM = 32 * WTM * WVM, BN = 32 * WTN * WVN;
-  static constexpr int A_ROWS = (BM + 63) / 64 * 64, B_ROWS = (BN + 63) / 64 * 64;
+  static constexpr int RPI = 16 * NW;   // LDS rows filled by one glds "round" of the whole block
+  static constexpr int A_ROWS = (BM + RPI - 1) / RPI * RPI, B_ROWS = (BN + RPI - 1) / RPI * RPI;
   static constexpr int A_BYTES = A_ROWS * KBYTES, B_BYTES = B_ROWS * KBYTES;
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   static constexpr int LDS_BYTES = NS * STAGE_BYTES;
-  static constexpr int LA = A_ROWS / 64, LB = B_ROWS / 64, LPS = LA + LB;   // glds per wave per stage
+  static constexpr int LA = A_ROWS / RPI, LB = B_ROWS / RPI, LPS = LA + LB;   // glds per wave per stage
 };
 
 #define EMO_GLDS16(gptr, lptr) \
@@ -63,9 +63,10 @@ __device__ __forceinline__ uint4 lds_read16(unsigned addr) {
 
 struct ConvRow { int img, iy0, ix0; };
 
-template <typename T, bool CONV, bool TRANS, int WTM, int WTN, int WVM, int WVN>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const emo_gemm_params p) {
-  using Tile = GemmTile<WTM, WTN, WVM, WVN>;
+template <typename T, bool CONV, bool TRANS, int WTM, int WTN, int WVM, int WVN, int NS>
+__global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_params p) {
+  using Tile = GemmTile<WTM, WTN, WVM, WVN, NS>;
+  constexpr int NW = Tile::NW;
   constexpr int V = TT<T>::VEC;          // elements per 16 B
   constexpr int BK = KBYTES / (int)sizeof(T);
   constexpr int BM = Tile::BM, BN = Tile::BN, LA = Tile::LA, LB = Tile::LB, LPS = Tile::LPS;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const emo_gemm_param
   bool a_ok[LA];
 #pragma unroll
   for (int i = 0; i < LA; i++) {
-    const int row = (i * 4 + wave) * 16 + lrow;
+    const int row = (i * NW + wave) * 16 + lrow;
     a_klog[i] = (lane & 3) ^ ((row >> 2) & 3);
     const int64_t m = bm + row;
     a_ok[i] = row < BM && m < p.M;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const emo_gemm_param
   bool b_ok[LB];
 #pragma unroll
   for (int i = 0; i < LB; i++) {
-    const int row = (i * 4 + wave) * 16 + lrow;
+    const int row = (i * NW + wave) * 16 + lrow;
     b_klog[i] = (lane & 3) ^ ((row >> 2) & 3);
     const int n = bn + row;
     b_ok[i] = row < BN && n < p.N;
@@ -146,13 +147,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const emo_gemm_param
           }
         }
       }
-      EMO_GLDS16(src, sa + (i * 4 + wave) * 1024);
+      EMO_GLDS16(src, sa + (i * NW + wave) * 1024);
     }
 #pragma unroll
     for (int i = 0; i < LB; i++) {
       const int k0 = kt * BK + b_klog[i] * V;
       const T* src = (b_ok[i] && k0 < p.K) ? b_base[i] + k0 : zero;
-      EMO_GLDS16(src, sb + (i * 4 + wave) * 1024);
+      EMO_GLDS16(src, sb + (i * NW + wave) * 1024);
     }
   };
 
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const emo_gemm_param
     // stage kt must have landed; up to min(NS-2, nk-1-kt) younger stages may still be in flight
     const int rem = nk - 1 - kt;
     if (rem >= NS - 2) wait_vmcnt<(NS - 2) * LPS>();
-    else if (rem == 1) wait_vmcnt<LPS>();
+    else if (NS > 3 && rem == 1) wait_vmcnt<LPS>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // everyone's part of stage kt landed; everyone finished reading slot (kt-1)%NS
     if (kt + NS - 1 < nk) issue(kt0 + kt + NS - 1, (kt + NS - 1) % NS);
@@ -249,6 +250,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const emo_gemm_param
         continue;
       }
       const float* rbias = (p.rowbias && m_ok) ? p.rowbias + (m / p.rows_per_batch) * p.ld_rowbias : nullptr;
+      const int n_out = p.geglu ? p.N / 2 : p.N;
+      const bool vec_ok = (p.N & 3) == 0 && ((p.ldc | (R ? p.ldr : 0)) & 3) == 0 && (!p.rowbias || (p.ld_rowbias & 3) == 0);
 #pragma unroll
       for (int j = 0; j < WTN; j++) {
         if (p.geglu && (j & 1)) continue;   // gate tile is consumed with its value tile
@@ -256,25 +259,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const emo_gemm_param
         for (int g = 0; g < 4; g++) {
           const int nw0 = wn0 + j * 32 + 8 * g + 4 * half;              // column in W-row space
           const int no0 = p.geglu ? ((wn0 + j * 32) >> 1) + 8 * g + 4 * half : nw0;   // output column
-          float o[4];
+          if (nw0 >= p.N) continue;
+          float o[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          if (vec_ok) {   // the whole quad is in range (N % 4 == 0)
+            if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
+            if (rbias) { const float4 b4 = *(const float4*)(rbias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
+            if (p.geglu) {
+              float gt[4] = {acc[i][(j + 1) % WTN][4 * g], acc[i][(j + 1) % WTN][4 * g + 1], acc[i][(j + 1) % WTN][4 * g + 2],
+                             acc[i][(j + 1) % WTN][4 * g + 3]};
+              if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0 + 32); gt[0] += b4.x; gt[1] += b4.y; gt[2] += b4.z; gt[3] += b4.w; }
 #pragma unroll
-          for (int e = 0; e < 4; e++) {
-            const int nw = nw0 + e;
-            float v = acc[i][j][4 * g + e];
-            if (nw < p.N) {
-              if (p.bias) v += p.bias[nw];
-              if (rbias) v += rbias[nw];
-              if (p.geglu) {
-                float gt = acc[i][(j + 1) % WTN][4 * g + e];
-                if (p.bias) gt += p.bias[nw + 32];
-                v = v * gelu_erf_f(gt);
-              }
+              for (int e = 0; e < 4; e++) o[e] *= gelu_for<T>(gt[e]);
             }
-            o[e] = v;
-          }
-          const int n_out = p.geglu ? p.N / 2 : p.N;
-          if (!m_ok) continue;
-          if (no0 + 3 < n_out && ((p.ldc | (R ? p.ldr : 0)) & 3) == 0) {
+            if (!m_ok) continue;
             if (R) {
               if constexpr (sizeof(T) == 2) {
                 const uint2 rv = *(const uint2*)(R + m * p.ldr + no0);
@@ -289,11 +286,20 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const emo_gemm_param
             for (int e = 0; e < 4; e++) o[e] *= p.out_scale;
             if constexpr (sizeof(T) == 2) *(uint2*)(C + m * p.ldc + no0) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
             else *(float4*)(C + m * p.ldc + no0) = make_float4(o[0], o[1], o[2], o[3]);
-          } else {
+          } else {   // ragged N / unaligned leading dims: scalar path
 #pragma unroll
             for (int e = 0; e < 4; e++) {
+              const int nw = nw0 + e;
+              if (nw >= p.N || !m_ok) continue;
+              float v = o[e];
+              if (p.bias) v += p.bias[nw];
+              if (rbias) v += rbias[nw];
+              if (p.geglu) {
+                float gt = acc[i][(j + 1) % WTN][4 * g + e];
+                if (p.bias) gt += p.bias[nw + 32];
+                v *= gelu_for<T>(gt);
+              }
               if (no0 + e < n_out) {
-                float v = o[e];
                 if (R) v += TT<T>::ld(R + m * p.ldr + no0 + e);
                 TT<T>::st(C + m * p.ldc + no0 + e, v * p.out_scale);
               }
@@ -357,11 +363,15 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(const emo_gem
 }
 
 // ------------------------------------------------------------------------------------------ host side
-struct GemmPlan { int nt5, split_k; };
+struct GemmPlan { int nt5, big, split_k; };
 
 static GemmPlan plan_gemm(int64_t M, int N, int K, int dtype, int geglu) {
   GemmPlan pl;
-  pl.nt5 = (!geglu && N % 160 == 0) ? 1 : 0;
+  // 256x256 / 8 waves for the big compute-bound shapes (N a multiple of 256, or wide enough that the ragged last
+  // tile is small), else 128x160 when N is a multiple of 160 (every SD-1.5 width), else 128x128
+  const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+  pl.big = (dtype == EMO_BF16 && tiles256 >= 224 && (N % 256 == 0 || N >= 1792)) ? 1 : 0;
+  pl.nt5 = (!pl.big && !geglu && N % 160 == 0) ? 1 : 0;
   const int bn = pl.nt5 ? 160 : 128;
   const int64_t tiles = ((M + 127) / 128) * ((N + bn - 1) / bn);
   const int bk = dtype == EMO_F32 ? 16 : 32;
@@ -383,10 +393,10 @@ extern "C" size_t emo_gemm_workspace_bytes(int64_t M, int N, int split_k) {
   return split_k > 1 ? (size_t)split_k * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
-template <typename T, bool CONV, bool TRANS, int WTM, int WTN, int WVM, int WVN>
+template <typename T, bool CONV, bool TRANS, int WTM, int WTN, int WVM, int WVN, int NS>
 static int launch_gemm(const emo_gemm_params& p, int S, hipStream_t st) {
-  using Tile = GemmTile<WTM, WTN, WVM, WVN>;
-  auto kern = gemm_kernel<T, CONV, TRANS, WTM, WTN, WVM, WVN>;
+  using Tile = GemmTile<WTM, WTN, WVM, WVN, NS>;
+  auto kern = gemm_kernel<T, CONV, TRANS, WTM, WTN, WVM, WVN, NS>;
   if (Tile::LDS_BYTES > 64 * 1024) {
     static bool once = false;
     if (!once) {
@@ -398,15 +408,16 @@ static int launch_gemm(const emo_gemm_params& p, int S, hipStream_t st) {
   const int64_t tiles = ((p.M + Tile::BM - 1) / Tile::BM) * ((p.N + Tile::BN - 1) / Tile::BN);
   if (tiles >= (1ll << 31)) return emo_fail(EMO_ERR_BAD_SHAPE, "emo_gemm: too many tiles");
   dim3 grid((unsigned)tiles, (unsigned)S);
-  kern<<<grid, GEMM_THREADS, Tile::LDS_BYTES, st>>>(p);
+  kern<<<grid, Tile::THREADS, Tile::LDS_BYTES, st>>>(p);
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
 
 template <typename T, bool CONV, bool TRANS>
 static int dispatch_tile(const emo_gemm_params& p, const GemmPlan& pl, int S, hipStream_t st) {
-  if (pl.nt5) return launch_gemm<T, CONV, TRANS, 1, 5, 4, 1>(p, S, st);   // 4x1 waves of 32x160
-  return launch_gemm<T, CONV, TRANS, 2, 2, 2, 2>(p, S, st);               // 2x2 waves of 64x64
+  if (pl.big && S == 1) return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, 4>(p, S, st);   // 2x4 waves of 128x64, 4 x 32 KB ring
+  if (pl.nt5) return launch_gemm<T, CONV, TRANS, 1, 5, 4, 1, 3>(p, S, st);   // 4x1 waves of 32x160, 3 x 20 KB ring
+  return launch_gemm<T, CONV, TRANS, 2, 2, 2, 2, 4>(p, S, st);               // 2x2 waves of 64x64, 4 x 16 KB ring
 }
 
 template <typename T>
