@@ -3,14 +3,20 @@
 // Replaces CrossAttention._attention (orig_attention.py:655-684: baddbmm -> softmax -> bmm) and
 // xformers.ops.memory_efficient_attention (models/motionmodule.py:300, models/videonet.py:62,117).
 //
-// Design (wave64, 32x32 MFMA), per workgroup = 4 waves x 32 query rows, KV tiles of 64 keys in LDS:
-//   S^T = K . Q^T    A = K tile rows from LDS (ds_read_b128, rows padded to an odd number of 16-B slots),
-//                    B = Q fragments held in registers for the whole kernel.  Output lane <-> query
-//                    column, so the online-softmax state (m, l) and the rescale are lane-local.
+// Design (wave64, 32x32 MFMA), per workgroup = 4 waves x 32 query rows, KV tiles of 64 keys:
+//   S^T = K . Q^T    A = K tile rows from LDS, B = Q fragments held in registers for the whole kernel.
+//                    Output lane <-> query column, so the online-softmax state (m, l) and the rescale
+//                    are lane-local.
 //   O^T = V^T . P^T  A = V^T tile from LDS (keys contiguous: V arrives pre-transposed from the V-projection
 //                    GEMM's epilogue), B = P straight from the S^T accumulator registers - no LDS round
 //                    trip, no cross-lane traffic: the K tile is stored with row bits 2<->3 swapped so that
 //                    a lane's 8 consecutive P registers are 8 consecutive keys.
+//   KV tiles stream through an LDS RING filled by asynchronous global_load_lds_dwordx4 (no VGPR staging):
+//   tiles t+1 (and t+2) are in flight while tile t is consumed; counted `s_waitcnt vmcnt`, one raw s_barrier
+//   per tile.  The LDS image is lane-linear, so rows are padded to an ODD number of 16-byte chunks by sourcing
+//   the pad chunk from a zero page (conflict-free ds_read_b128 and a zero K/V pad for free); fragment reads
+//   are inline-asm ds_read_b128 with hand-counted lgkmcnt (hipcc would drain vmcnt(0) before every C++ LDS
+//   read while a glds is in flight).
 // Two KV segments: [self / context keys of the batch row] ++ [a bank shared by seg1_div consecutive
 // batch rows] = the ReferenceNet read path (mutual_self_attention.py:238-241) without materialising the
 // F-times-repeated bank or the concatenated K/V.  Head dims 40/80/160 are zero-padded to 48/80/160 (bf16).
@@ -18,33 +24,50 @@
 
 static constexpr int ATT_THREADS = 256, BQ = 128, TK = 64;
 
+__device__ __attribute__((aligned(16))) unsigned int g_att_zero_page[4] = {0, 0, 0, 0};
+
 template <typename T, int DCH>
 struct AttCfg {
   static constexpr int V = TT<T>::VEC;
   static constexpr int DPAD = DCH * V;
   static constexpr int NT = (DPAD + 31) / 32;
-  static constexpr int KROW = DCH * 16 + 16;                  // bytes; (DCH+1) odd -> conflict-free b128 reads
-  static constexpr int VROW = TK * (int)sizeof(T) + 16;       // bytes; odd number of 16-B slots
-  static constexpr int K_BYTES = TK * KROW;
-  static constexpr int V_BYTES = NT * 32 * VROW;
-  static constexpr int LDS_BYTES = K_BYTES + V_BYTES;
-  static constexpr int STEPS = 32 / (2 * V);                  // mma16 steps per 32-key sub-tile
+  static constexpr int DCHP = DCH + 1;                         // odd chunk count per K row
+  static constexpr int VCH = TK * (int)sizeof(T) / 16;         // real 16-B chunks per V^T row
+  static constexpr int VCHP = VCH + 1;                         // odd
+  static constexpr int KROW = DCHP * 16, VROW = VCHP * 16;     // bytes
+  static constexpr int K_CHUNKS = TK * DCHP;
+  static constexpr int STEPS = 32 / (2 * V);                   // mma16 steps per 32-key sub-tile
 };
 
+#define EMO_GLDS16(gptr, lptr) \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ uint4 lds_read16(unsigned addr) {
+  uint4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
-template <typename T, int DCH>
-__global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attention_params p) {
+// G = glds per wave per tile, NSR = ring depth
+template <typename T, int DCH, int G, int NSR>
+__global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attention_params p, int stage_bytes) {
   using Cfg = AttCfg<T, DCH>;
   constexpr int V = Cfg::V, NT = Cfg::NT, KROW = Cfg::KROW, VROW = Cfg::VROW, STEPS = Cfg::STEPS;
+  constexpr int DCHP = Cfg::DCHP, VCH = Cfg::VCH, VCHP = Cfg::VCHP, K_CHUNKS = Cfg::K_CHUNKS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* Ks = smem;
-  unsigned char* Vs = smem + Cfg::K_BYTES;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
   const int qt = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
   const int d = p.d;
   const int dch_real = d / V;  // d*sizeof(T) % 16 == 0 checked on the host
+  const T* zero = (const T*)g_att_zero_page;
+
+  // ---- zero the whole ring once: V^T pad rows (n >= d) are never written by the loader and must be 0
+  for (int i = tid * 16; i < NSR * stage_bytes; i += ATT_THREADS * 16) *(uint4*)(smem + i) = make_uint4(0, 0, 0, 0);
 
   // ---- Q fragments: row q, chunks (2*kk + half)
   const int q = qt * BQ + wave * 32 + l31;
@@ -57,16 +80,55 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attent
     qf[kk] = (q_ok && c < dch_real) ? *(const uint4*)(qrow + c * V) : make_uint4(0, 0, 0, 0);
   }
 
-  // ---- zero the pad regions of the LDS tiles once (pad chunk of K rows, pad rows of V^T)
-  for (int i = tid; i < TK * (DCH - dch_real); i += ATT_THREADS) {
-    int r = i / (DCH - dch_real), c = dch_real + i % (DCH - dch_real);
-    *(uint4*)(Ks + r * KROW + c * 16) = make_uint4(0, 0, 0, 0);
+  // ---- loader geometry: glds #g of this wave writes LDS chunk positions (g*4 + wave)*64 + lane of the stage
+  //      [0, K_CHUNKS): K rows (row = pos / DCHP holds key (row&32)|swap23(row&31));  then d V^T rows of VCHP chunks
+  int ld_kind[G];     // 0 = zero page, 1 = K chunk, 2 = V^T chunk
+  int ld_a[G], ld_c[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const int pos = (g * 4 + wave) * 64 + lane;
+    ld_kind[g] = 0; ld_a[g] = 0; ld_c[g] = 0;
+    if (pos < K_CHUNKS) {
+      const int row = pos / DCHP, c = pos % DCHP;
+      if (c < dch_real) { ld_kind[g] = 1; ld_a[g] = (row & 32) | swap23(row & 31); ld_c[g] = c; }
+    } else {
+      const int qv = pos - K_CHUNKS, n = qv / VCHP, c = qv % VCHP;
+      if (n < d && c < VCH) { ld_kind[g] = 2; ld_a[g] = n; ld_c[g] = c; }
+    }
   }
-  constexpr int VCH = TK * (int)sizeof(T) / 16;  // 16-B chunks per V^T row
-  for (int i = tid; i < (NT * 32 - d) * VCH; i += ATT_THREADS) {
-    int r = d + i / VCH, c = i % VCH;
-    *(uint4*)(Vs + r * VROW + c * 16) = make_uint4(0, 0, 0, 0);
-  }
+
+  // ---- tile list over the (up to two) KV segments
+  const int nseg = (p.k1 != nullptr && b >= p.seg1_first_batch) ? 2 : 1;
+  const int tiles0 = (p.Lk0 + TK - 1) / TK;
+  const int tiles1 = nseg == 2 ? (p.Lk1 + TK - 1) / TK : 0;
+  const int ntiles = tiles0 + tiles1;
+  const int kb0 = b / p.seg0_div, kb1 = nseg == 2 ? b / p.seg1_div : 0;
+  const T* kbase0 = (const T*)p.k0 + (int64_t)kb0 * p.Lk0 * p.ldk0 + head * d;
+  const T* vbase0 = (const T*)p.v0t + ((int64_t)kb0 * p.heads * d + (int64_t)head * d) * p.ldv0t;
+  const T* kbase1 = nseg == 2 ? (const T*)p.k1 + (int64_t)kb1 * p.Lk1 * p.ldk1 + head * d : nullptr;
+  const T* vbase1 = nseg == 2 ? (const T*)p.v1t + ((int64_t)kb1 * p.heads * d + (int64_t)head * d) * p.ldv1t : nullptr;
+
+  auto issue = [&](int t, int slot) {
+    const bool s1 = t >= tiles0;
+    const int k0 = (s1 ? t - tiles0 : t) * TK;
+    const int Lk = s1 ? p.Lk1 : p.Lk0;
+    const int64_t ldk = s1 ? p.ldk1 : p.ldk0, ldvt = s1 ? p.ldv1t : p.ldv0t;
+    const T* kbase = s1 ? kbase1 : kbase0;
+    const T* vbase = s1 ? vbase1 : vbase0;
+    unsigned char* st = smem + slot * stage_bytes;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const T* src = zero;
+      if (ld_kind[g] == 1) {
+        const int key = k0 + ld_a[g];
+        if (key < Lk) src = kbase + (int64_t)key * ldk + ld_c[g] * V;
+      } else if (ld_kind[g] == 2) {
+        const int key0 = k0 + ld_c[g] * V;
+        if (key0 < Lk) src = vbase + (int64_t)ld_a[g] * ldvt + key0;   // a chunk straddling Lk is cleaned in LDS below
+      }
+      EMO_GLDS16(src, st + (g * 4 + wave) * 1024);
+    }
+  };
 
   f32x16 o[NT];
 #pragma unroll
@@ -75,92 +137,125 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attent
     for (int r = 0; r < 16; r++) o[nt][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
   const float c_exp = p.scale * 1.4426950408889634f;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
-  const int nseg = (p.k1 != nullptr && b >= p.seg1_first_batch) ? 2 : 1;
-  for (int seg = 0; seg < nseg; seg++) {
-    const int Lk = seg == 0 ? p.Lk0 : p.Lk1;
-    const int64_t ldk = seg == 0 ? p.ldk0 : p.ldk1;
-    const int64_t ldvt = seg == 0 ? p.ldv0t : p.ldv1t;
-    const int kb = seg == 0 ? b / p.seg0_div : b / p.seg1_div;
-    const T* kbase = (const T*)(seg == 0 ? p.k0 : p.k1) + (int64_t)kb * Lk * ldk + head * d;
-    const T* vbase = (const T*)(seg == 0 ? p.v0t : p.v1t) + ((int64_t)kb * p.heads * d + (int64_t)head * d) * ldvt;
-    for (int k0 = 0; k0 < Lk; k0 += TK) {
-      __syncthreads();  // previous tile fully consumed
-      // ---- stage K tile [64 keys][d] (row = sub-tile*32 + swap23(key&31)) and V^T tile [d][64 keys]
-      for (int i = tid; i < TK * dch_real; i += ATT_THREADS) {
-        const int key = i / dch_real, c = i % dch_real;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (k0 + key < Lk) v = *(const uint4*)(kbase + (int64_t)(k0 + key) * ldk + c * V);
-        *(uint4*)(Ks + ((key & 32) + swap23(key & 31)) * KROW + c * 16) = v;
-      }
-      for (int i = tid; i < d * VCH; i += ATT_THREADS) {
-        const int n = i / VCH, c = i % VCH;
-        const int key0 = k0 + c * V;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (key0 < Lk) {
-          v = *(const uint4*)(vbase + (int64_t)n * ldvt + key0);
-          if (key0 + V > Lk) {  // partial chunk: zero the keys beyond Lk (their P is 0, 0*garbage must not be NaN)
-            float f[V];
-            unpack16<T>(v, f);
+  __syncthreads();   // ring zeroed before the first async write lands (plain LDS stores: lgkmcnt drained by the barrier)
 #pragma unroll
-            for (int e = 0; e < V; e++) if (key0 + e >= Lk) f[e] = 0.f;
-            v = pack16<T>(f);
-          }
-        }
-        *(uint4*)(Vs + n * VROW + c * 16) = v;
+  for (int s = 0; s < NSR - 1; s++)
+    if (s < ntiles) issue(s, s);
+
+  for (int t = 0; t < ntiles; t++) {
+    if constexpr (NSR == 1) issue(t, 0);
+    const int rem = ntiles - 1 - t;
+    if constexpr (NSR >= 3) {
+      if (rem >= NSR - 2) wait_vmcnt<(NSR - 2) * G>();
+      else wait_vmcnt<0>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if constexpr (NSR > 1) {
+      if (t + NSR - 1 < ntiles) issue(t + NSR - 1, (t + NSR - 1) % NSR);
+    }
+    const bool s1 = t >= tiles0;
+    const int k0 = (s1 ? t - tiles0 : t) * TK;
+    const int Lk = s1 ? p.Lk1 : p.Lk0;
+    const unsigned st_base = lds_base + (t % NSR) * stage_bytes;
+    const unsigned ks_base = st_base, vs_base = st_base + K_CHUNKS * 16;
+    if (k0 + TK > Lk && (Lk % V) != 0) {
+      // ragged last tile whose final 16-byte V^T chunk straddles Lk: zero the columns >= Lk in LDS (their P is
+      // exactly 0, but 0 * garbage must not become NaN).  Rare (context length 77); costs one extra barrier.
+      const int cpart = (Lk - k0) / V, efirst = (Lk - k0) % V;
+      unsigned char* vs = smem + (t % NSR) * stage_bytes + K_CHUNKS * 16;
+      for (int n = tid; n < d; n += ATT_THREADS) {
+        uint4* ptr = (uint4*)(vs + n * VROW + cpart * 16);
+        float f[V];
+        unpack16<T>(*ptr, f);
+#pragma unroll
+        for (int e = 0; e < V; e++) if (e >= efirst) f[e] = 0.f;
+        *ptr = pack16<T>(f);
       }
       __syncthreads();
+    }
 
 #pragma unroll
-      for (int st = 0; st < 2; st++) {
-        if (k0 + st * 32 >= Lk) break;
-        // ---- S^T sub-tile: 32 keys x 32 queries
-        f32x16 s;
+    for (int st = 0; st < 2; st++) {
+      if (k0 + st * 32 >= Lk) break;
+      // ---- fragment reads: K rows for S^T, V^T rows for the PV of this sub-tile (issued early)
+      uint4 kf[DCH / 2];
+      const unsigned krow = ks_base + (st * 32 + l31) * KROW + half * 16;
 #pragma unroll
-        for (int r = 0; r < 16; r++) s[r] = 0.f;
-        const unsigned char* krow = Ks + (st * 32 + l31) * KROW + half * 16;
+      for (int kk = 0; kk < DCH / 2; kk++) kf[kk] = lds_read16(krow + kk * 32);
+      uint4 vf[STEPS][NT];
+      constexpr bool V_EARLY = STEPS * NT <= 15;   // lgkmcnt is a 4-bit counter
+      auto read_v = [&]() {
 #pragma unroll
-        for (int kk = 0; kk < DCH / 2; kk++) s = mma16<T>(*(const uint4*)(krow + kk * 32), qf[kk], s);
-        // ---- online softmax (lane-local query; the other half of the keys lives in lane^32)
-        float mx = -1e30f;
+        for (int sp = 0; sp < STEPS; sp++) {
+          const int r0 = sp * V;
+          const int key_off = st * 32 + 16 * (r0 >> 3) + 8 * half + (r0 & 7);
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++) vf[sp][nt] = lds_read16(vs_base + (nt * 32 + l31) * VROW + key_off * (int)sizeof(T));
+        }
+      };
+      if constexpr (V_EARLY) {
+        read_v();                     // in flight under the S^T MFMAs and the softmax
+        wait_lgkmcnt<STEPS * NT>();   // the K fragments
+      } else {
+        wait_lgkmcnt<0>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; r++) s[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < DCH / 2; kk++) s = mma16<T>(kf[kk], qf[kk], s);
+      // ---- online softmax (lane-local query; the other half of the keys lives in lane^32)
+      if (k0 + st * 32 + 32 > Lk) {   // ragged last sub-tile only (wave-uniform)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int key = k0 + st * 32 + 16 * (r >> 3) + 8 * half + (r & 7);
           if (key >= Lk) s[r] = -1e30f;
-          mx = fmaxf(mx, s[r]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f((m_run - m_new) * c_exp);
-        m_run = m_new;
-        float psum = 0.f;
-        float pr[16];
+      }
+      float mx = s[0];
 #pragma unroll
-        for (int r = 0; r < 16; r++) { pr[r] = exp2f((s[r] - m_new) * c_exp); psum += pr[r]; }
-        l_run = l_run * alpha + psum;
+      for (int r = 1; r < 16; r++) mx = fmaxf(mx, s[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = exp2f((m_run - m_new) * c_exp);
+      m_run = m_new;
+      const float m_sc = m_new * c_exp;
+      float psum = 0.f;
+      float pr[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) { pr[r] = exp2f(s[r] * c_exp - m_sc); psum += pr[r]; }
+      l_run = l_run * alpha + psum;
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // skip the O rescale when no lane's max moved
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
 #pragma unroll
           for (int r = 0; r < 16; r++) o[nt][r] *= alpha;
-        // ---- O^T += V^T . P^T
+      }
+      // ---- O^T += V^T . P^T
+      if constexpr (!V_EARLY) read_v();
+      wait_lgkmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int sp = 0; sp < STEPS; sp++) {
-          const int r0 = sp * V;
-          uint4 pf;
-          if constexpr (sizeof(T) == 2) {
-            pf = make_uint4(pack_bf2(pr[r0], pr[r0 + 1]), pack_bf2(pr[r0 + 2], pr[r0 + 3]), pack_bf2(pr[r0 + 4], pr[r0 + 5]),
-                            pack_bf2(pr[r0 + 6], pr[r0 + 7]));
-          } else {
-            pf = make_uint4(__float_as_uint(pr[r0]), __float_as_uint(pr[r0 + 1]), __float_as_uint(pr[r0 + 2]),
-                            __float_as_uint(pr[r0 + 3]));
-          }
-          const int key_off = st * 32 + 16 * (r0 >> 3) + 8 * half + (r0 & 7);
-          const unsigned char* vrow = Vs + l31 * VROW + key_off * (int)sizeof(T);
-#pragma unroll
-          for (int nt = 0; nt < NT; nt++) o[nt] = mma16<T>(*(const uint4*)(vrow + nt * 32 * VROW), pf, o[nt]);
+      for (int sp = 0; sp < STEPS; sp++) {
+        const int r0 = sp * V;
+        uint4 pf;
+        if constexpr (sizeof(T) == 2) {
+          pf = make_uint4(pack_bf2(pr[r0], pr[r0 + 1]), pack_bf2(pr[r0 + 2], pr[r0 + 3]), pack_bf2(pr[r0 + 4], pr[r0 + 5]),
+                          pack_bf2(pr[r0 + 6], pr[r0 + 7]));
+        } else {
+          pf = make_uint4(__float_as_uint(pr[r0]), __float_as_uint(pr[r0 + 1]), __float_as_uint(pr[r0 + 2]),
+                          __float_as_uint(pr[r0 + 3]));
         }
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) o[nt] = mma16<T>(vf[sp][nt], pf, o[nt]);
       }
     }
+    if constexpr (NSR == 1) __builtin_amdgcn_s_barrier();   // synchronous ring: nobody may still read slot 0
   }
 
   // ---- normalise and store: lane holds O[q][n], n = nt*32 + 8*(r>>2) + 4*half + (r&3)
@@ -185,34 +280,70 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attent
   }
 }
 
-template <typename T, int DCH>
-static int launch_attention(const emo_attention_params& p, hipStream_t st) {
+template <typename T, int DCH, int G>
+struct AttLaunch {
   using Cfg = AttCfg<T, DCH>;
-  auto kern = attention_kernel<T, DCH>;
-  if (Cfg::LDS_BYTES > 64 * 1024) {
+  static constexpr int NEED = Cfg::K_CHUNKS + Cfg::NT * 32 * Cfg::VCHP;
+  static constexpr int STAGE_CHUNKS = G * 256 > NEED ? G * 256 : NEED;
+  static constexpr int STAGE_BYTES = STAGE_CHUNKS * 16;
+  // ring depth: as deep as LDS allows while keeping >= 2 workgroups per CU when possible
+  static constexpr int NSR = 3 * STAGE_BYTES <= 80 * 1024 ? 3 : (2 * STAGE_BYTES <= 160 * 1024 ? 2 : 1);
+  static_assert(NSR * STAGE_BYTES <= 160 * 1024, "attention stage does not fit LDS");
+};
+
+template <typename T, int DCH, int G>
+static int launch_attention2(const emo_attention_params& p, hipStream_t st) {
+  using L = AttLaunch<T, DCH, G>;
+  auto kern = attention_kernel<T, DCH, G, L::NSR>;
+  constexpr int lds = L::NSR * L::STAGE_BYTES;
+  if (lds > 64 * 1024) {
     static bool once = false;  // idempotent attribute; benign race
     if (!once) {
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e != hipSuccess) return emo_fail(EMO_ERR_HIP, "emo_attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
       once = true;
     }
   }
   dim3 grid((p.Lq + BQ - 1) / BQ, p.heads, p.B);
-  kern<<<grid, ATT_THREADS, Cfg::LDS_BYTES, st>>>(p);
+  kern<<<grid, ATT_THREADS, lds, st>>>(p, L::STAGE_BYTES);
   EMO_LAUNCH_CHECK();
   return EMO_OK;
+}
+
+// DPREV = chunk count of the next smaller head-dim class: this class serves dch in (DPREV, DCH]
+template <typename T, int DCH, int DPREV>
+static int launch_attention(const emo_attention_params& p, hipStream_t st) {
+  using Cfg = AttCfg<T, DCH>;
+  // chunks the loader must cover for THIS head dim (K rows + d V^T rows), rounded up to whole 256-lane rounds
+  const int g = (Cfg::K_CHUNKS + p.d * Cfg::VCHP + 255) / 256;
+  constexpr int GMIN = (Cfg::K_CHUNKS + (DPREV + 1) * Cfg::V * Cfg::VCHP + 255) / 256;
+  constexpr int GMAX = (Cfg::K_CHUNKS + Cfg::DPAD * Cfg::VCHP + 255) / 256;
+#define EMO_ATT_G(GV)                                                            \
+  case GV:                                                                       \
+    if constexpr (GV >= GMIN && GV <= GMAX) return launch_attention2<T, DCH, GV>(p, st); \
+    break;
+  switch (g) {
+    EMO_ATT_G(1) EMO_ATT_G(2) EMO_ATT_G(3) EMO_ATT_G(4) EMO_ATT_G(5) EMO_ATT_G(6) EMO_ATT_G(7) EMO_ATT_G(8)
+    EMO_ATT_G(9) EMO_ATT_G(10) EMO_ATT_G(11) EMO_ATT_G(12) EMO_ATT_G(13) EMO_ATT_G(14) EMO_ATT_G(15) EMO_ATT_G(16)
+    EMO_ATT_G(17) EMO_ATT_G(18) EMO_ATT_G(19) EMO_ATT_G(20) EMO_ATT_G(21) EMO_ATT_G(22)
+    default: break;
+  }
+#undef EMO_ATT_G
+  return emo_fail(EMO_ERR_UNSUPPORTED, "emo_attention: loader rounds %d out of range for head dim %d", g, p.d);
 }
 
 template <typename T>
 static int dispatch_attention(const emo_attention_params& p, hipStream_t st) {
   constexpr int V = TT<T>::VEC;
   const int dch = p.d / V;
-  if (dch <= 2) return launch_attention<T, 2>(p, st);
-  if (dch <= 4) return launch_attention<T, 4>(p, st);
-  if (dch <= 6) return launch_attention<T, 6>(p, st);
-  if (dch <= 10) return launch_attention<T, 10>(p, st);
-  if (dch <= 20) return launch_attention<T, 20>(p, st);
-  if (dch <= 40) return launch_attention<T, 40>(p, st);
+  if (dch <= 2) return launch_attention<T, 2, 0>(p, st);
+  if (dch <= 4) return launch_attention<T, 4, 2>(p, st);
+  if (dch <= 6) return launch_attention<T, 6, 4>(p, st);
+  if (dch <= 10) return launch_attention<T, 10, 6>(p, st);
+  if (dch <= 20) return launch_attention<T, 20, 10>(p, st);
+  if constexpr (sizeof(T) == 4) {
+    if (dch <= 40) return launch_attention<T, 40, 20>(p, st);
+  }
   return emo_fail(EMO_ERR_UNSUPPORTED, "emo_attention: head dim %d too large", p.d);
 }
 
