@@ -78,6 +78,8 @@ def _launch(name, flops, nbytes, fn, tag=""):
 
 
 def _stream():
+    if not torch.cuda.is_available():
+        raise _lib.EmoHipError("no HIP device: emote_hack_amd ops launch gfx950 kernels (there is no CPU fallback)")
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

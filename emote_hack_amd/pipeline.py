@@ -136,9 +136,9 @@ class EMOAnimationPipeline:
         self._write_banks(st.appearance_encoder, st.writer, st.ref_rep, st.timesteps[mine], st.text)
         st.bank_shapes = [tuple(st.writer.bank[p][0].shape) for p in st.writer.order]
         send = self._pack_banks(st.writer)
-        recv = torch.empty(ws, send.numel(), device=send.device, dtype=send.dtype)
+        recv = torch.empty(ws * send.numel(), device=send.device, dtype=send.dtype)   # flat: valid for RCCL and gloo
         td.all_gather_into_tensor(recv, send)
-        st.bank_group, st.bank_group_start = recv, si
+        st.bank_group, st.bank_group_start = recv.view(ws, send.numel()), si
 
     @torch.no_grad()
     def denoise_step(self, st, si):

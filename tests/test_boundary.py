@@ -1,0 +1,175 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol include/emo_hip.h
+declares (no compute calls without a GPU), the product never imports the oracle, the host-side mirror has
+the reference's interface (ctor kwargs, state-dict keys, error behaviour)."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+from tests import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "emo_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(emo_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from emote_hack_amd import _lib
+    lib = _lib.load()
+    declared = header_functions()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/emo_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == declared, set(_lib.SIGNATURES) ^ set(declared)
+    assert lib.emo_version() >= 100
+    # extern "C": no mangled emo_ entry points
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert set(declared) <= exported
+
+
+def test_ctypes_struct_layout_matches_header():
+    """Field order of the params structs must match the header (a stale .so once silently mis-read a field)."""
+    from emote_hack_amd._lib import AttentionParams, GemmParams
+    src = open(os.path.join(ROOT, "include", "emo_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    for cname, struct in (("emo_gemm_params", GemmParams), ("emo_attention_params", AttentionParams)):
+        body = re.search(r"typedef struct \{((?:(?!typedef struct).)*?)\} " + cname, src, flags=re.S).group(1)
+        fields = re.findall(r"(?:const\s+)?(?:void|float|int64_t|uint32_t|int)\s*\*?\s*([A-Za-z_0-9]+)\s*;", body)
+        assert fields == [f[0] for f in struct._fields_], (cname, fields)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "emote_hack_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f"{f} imports the oracle"
+                assert "/root/reference" not in txt, f"{f} reads the reference at run time"
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly without a HIP device."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from emote_hack_amd import ops
+    from emote_hack_amd._lib import EmoHipError
+    from emote_hack_amd.unet import UNet3DConditionModel
+    with pytest.raises(EmoHipError):
+        ops.silu(torch.zeros(4))
+    m = UNet3DConditionModel(**cases.TINY)
+    with pytest.raises(EmoHipError):
+        m(torch.zeros(1, 4, 1, 16, 16), 1, torch.zeros(1, 5, 32))
+
+
+# ------------------------------------------------------------------ UNet surface
+@pytest.fixture(scope="module")
+def ints():
+    return json.load(open(os.path.join(cases.GOLDEN_DIR, "ints.json")))
+
+
+def test_state_dict_keys_match_reference(ints):
+    import hashlib
+    from emote_hack_amd.spec import build_spec, param_shapes
+    for cfg, key in ((cases.TINY_MOTION, "tiny_motion_keys"), (cases.TINY_LINEAR, "tiny_linear_keys")):
+        mine = {k: list(v) for k, v in param_shapes(build_spec(cfg)).items()}
+        assert mine == ints[key]
+    for cfg, key in ((cases.SD15_MOTION, "sd15_motion"), (dict(cases.SD15_MOTION, motion_module_mid_block=True), "sd15_motion_mid"),
+                     (cases.SD15, "sd15")):
+        shp = param_shapes(build_spec(cfg))
+        canon = "\n".join(f"{k}:{','.join(map(str, shp[k]))}" for k in sorted(shp))
+        d = ints[key + "_digest"]
+        assert len(shp) == d["n_keys"]
+        assert hashlib.sha256(canon.encode()).hexdigest() == d["sha256"]
+        n_params = sum(int(torch.Size(s).numel()) for k, s in shp.items() if not k.endswith("pos_encoder.pe"))
+        assert n_params == d["n_params"]
+
+
+def test_bank_pairing_order(ints):
+    from emote_hack_amd.spec import build_spec, reference_block_order
+    strip = lambda names: [n.replace(".transformer_blocks.0", "") for n in names]
+    assert reference_block_order(build_spec(cases.TINY_MOTION), "midup") == strip(ints["bank_order_tiny_midup"])
+    assert reference_block_order(build_spec(cases.TINY_MOTION), "full") == strip(ints["bank_order_tiny_full"])
+    assert reference_block_order(build_spec(cases.SD15_MOTION), "midup") == strip(ints["bank_order_sd15_midup"])
+
+
+def test_unet_ctor_surface_and_errors():
+    from emote_hack_amd.unet import UNet3DConditionModel
+    m = UNet3DConditionModel(**cases.SD15_MOTION)
+    assert m.config.sample_size == 64 and m.in_channels == 4 and m.config.attention_head_dim == (8, 8, 8, 8)
+    assert m.config["norm_eps"] == 1e-5
+    with pytest.raises(TypeError):
+        UNet3DConditionModel(not_a_kwarg=1)
+    with pytest.raises(ValueError, match="does not exist"):   # 2-D names must be renamed (unet_3d_blocks.py:103)
+        UNet3DConditionModel(**dict(cases.SD15, down_block_types=("CrossAttnDownBlock2D",) * 3 + ("DownBlock2D",)))
+    with pytest.raises(ValueError, match="unknown mid_block_type"):
+        UNet3DConditionModel(**dict(cases.SD15, mid_block_type="Foo"))
+    sd = {k: torch.zeros(s) for k, s in m._shapes.items()}
+    del sd["conv_in.weight"]
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(sd, strict=True)
+    missing, unexpected = m.load_state_dict(dict(sd, extra=torch.zeros(1)), strict=False)
+    assert missing == ["conv_in.weight"] and unexpected == ["extra"]
+
+
+def test_unet_config_yaml_rules(tmp_path):
+    """2D->3D names, unknown keys dropped, norm_num_groups honoured, '1e-05' cast to float."""
+    from emote_hack_amd.config import unet_config_from_yaml
+    y = tmp_path / "unet-config.yaml"
+    y.write_text("""
+denoising_unet_config:
+  default:
+    act_fn: silu
+    attention_head_dim: 8
+    block_out_channels: [320, 640, 1280, 1280]
+    cross_attention_dim: 768
+    down_block_types: ["CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"]
+    up_block_types: ["UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"]
+    norm_eps: 1e-05
+    norm_num_groups: 4
+    sample_size: 64
+    projection_class_embeddings_input_dim: null
+""")
+    cfg = unet_config_from_yaml(str(y))
+    assert cfg["down_block_types"][0] == "CrossAttnDownBlock3D" and cfg["up_block_types"][0] == "UpBlock3D"
+    assert cfg["norm_eps"] == 1e-5 and isinstance(cfg["norm_eps"], float)
+    assert cfg["norm_num_groups"] == 4 and "projection_class_embeddings_input_dim" not in cfg
+
+
+# ------------------------------------------------------------------ host-side INT logic, product vs goldens / oracle
+def test_context_windows_bit_exact(ints):
+    from emote_hack_amd.context import uniform
+    for c in ints["windows"]:
+        f, ctx, stride, ov = c["args"]
+        assert list(uniform(0, 50, f, ctx, stride, ov)) == c["windows"]
+    for c in ints["windows_step"]:
+        f, ctx, stride, ov = c["args"]
+        assert list(uniform(c["step"], 50, f, ctx, stride, ov)) == c["windows"]
+
+
+@pytest.mark.parametrize("kind", ["ddim", "ddpm"])
+def test_scheduler_matches_oracle(kind):
+    from emote_hack_amd import DDIMScheduler, DDPMScheduler
+    from oracle.scheduler_ref import SchedulerRef
+    mine = DDIMScheduler() if kind == "ddim" else DDPMScheduler()
+    ref = SchedulerRef(kind)
+    assert mine.set_timesteps(50) == ref.set_timesteps(50)          # INT, bit-exact
+    assert mine.timesteps == (list(range(981, 0, -20)) if kind == "ddim" else list(range(980, -1, -20)))
+    for t in mine.timesteps:
+        a, b = mine.coefficients(t), ref.coefficients(t)
+        assert all(abs(x - y) <= 1e-12 * max(1, abs(y)) for x, y in zip(a, b)), (t, a, b)
+    mine2 = DDIMScheduler(beta_schedule="scaled_linear")
+    ref2 = SchedulerRef("ddim", beta_schedule="scaled_linear")
+    mine2.set_timesteps(25); ref2.set_timesteps(25)
+    assert mine2.coefficients(41)[0] == pytest.approx(ref2.coefficients(41)[0], rel=1e-12)
+    with pytest.raises(ValueError):
+        DDIMScheduler(clip_sample=True)

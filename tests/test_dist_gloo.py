@@ -1,0 +1,159 @@
+"""N>1 path on CPU: world_size-2 `gloo` run of the product pipeline's sharded sampling loop
+(emote_hack_amd/pipeline.py: windows dealt `[rank::world_size]`, ReferenceNet passes dealt over ranks +
+all_gather of the packed banks, all_reduce of the window accumulators, redundant deterministic sampler step).
+
+There is no GPU here, so the HIP launches are replaced IN THIS TEST by the CPU oracle (test infrastructure):
+the UNet / ReferenceNet are oracle-backed stubs and the three sampler ops are monkeypatched.  What is under
+test is the distributed host logic: both ranks must end with latents identical to each other and equal to the
+single-process oracle loop."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests import cases
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class OracleBackedUNet:
+    """Stand-in with the product UNet's surface; arithmetic by oracle/unet_ref.py (CPU)."""
+
+    def __init__(self, cfg, sd, has_out=True):
+        from emote_hack_amd.config import normalize_unet_config
+        from emote_hack_amd.spec import build_spec, reference_block_order
+        self.cfg, self.sd = cfg, sd
+        self.config = normalize_unet_config(dict(cfg), strict=False)
+        self.spec = build_spec(cfg, has_out=has_out)
+        self.in_channels, self.dtype, self.device = 4, torch.float32, torch.device("cpu")
+        self._reference_control = None
+        self._order = lambda fusion: reference_block_order(self.spec, fusion)
+
+    def bank_order(self, fusion="midup"):
+        return self._order(fusion)
+
+    def __call__(self, sample, timestep, encoder_hidden_states, return_dict=False, _return_rows=False, audio_features=None,
+                 speed_embeddings=None):
+        from oracle import unet_ref as U
+        rc = self._reference_control
+        if sample.dim() == 4:
+            sample = sample.unsqueeze(2)
+        B, _, F, H, W = sample.shape
+        sd = self.sd if self.spec.has_out else {k: v for k, v in self.sd.items() if not k.startswith(("conv_out", "conv_norm_out"))}
+        if rc is not None and rc.mode == "write":
+            _, written = U.unet_forward(sd, self.cfg, sample, timestep, encoder_hidden_states, bank_mode="write",
+                                        fusion_blocks=rc.fusion_blocks)
+            for p in rc.order:
+                rc.bank[p].append(written[p])
+            return (None,)
+        kw = {}
+        if rc is not None and rc.mode == "read":
+            banks = {p: rc.bank[p][0] for p in rc.order if rc.bank[p]}
+            kw = dict(bank_mode="read", banks=banks, uc_rows=cases.uc_rows(B, F), fusion_blocks=rc.fusion_blocks)
+        y = U.unet_forward(sd, self.cfg, sample, timestep, encoder_hidden_states, audio_features=audio_features,
+                           speed_embeddings=speed_embeddings, **kw)
+        if _return_rows:
+            return y.permute(0, 2, 3, 4, 1).reshape(-1, y.shape[1]).contiguous()
+        return (y,)
+
+
+def _patch_ops():
+    """CPU stand-ins for the three HIP sampler ops + convert (oracle semantics)."""
+    from emote_hack_amd import ops
+    from oracle.scheduler_ref import counter_normal
+
+    def convert(src, dtype, fp16_round=False):
+        return (src.half().float() if fp16_round else src).to(dtype)
+
+    def accumulate_window(pred_rows, npb, counter, frames, *, C_, F, HW, add_counter):
+        nf = frames.numel()
+        npb.view(C_, F, HW)[:, frames.long()] += pred_rows.reshape(nf, HW, C_).permute(2, 0, 1)
+        if add_counter:
+            counter[frames.long()] += 1
+
+    def cfg_step(noise_pred, counter, latents, *, C_, F, HW, guidance_scale, c_x, c_eps, c_noise, seed, step, eps_out=None):
+        avg = noise_pred / counter.view(1, 1, F, 1)
+        eps = avg[0] + guidance_scale * (avg[1] - avg[0])
+        x = c_x * latents.view(C_, F, HW) + c_eps * eps
+        if c_noise != 0.0:
+            x = x + c_noise * counter_normal(seed, step, latents.numel()).view(C_, F, HW)
+        latents.view(C_, F, HW).copy_(x)
+        if eps_out is not None:
+            eps_out.copy_(eps.reshape(-1))
+
+    ops.convert, ops.accumulate_window, ops.cfg_step = convert, accumulate_window, cfg_step
+
+
+def _models():
+    from emote_hack_amd.spec import build_spec, param_shapes
+    from emote_hack_amd.synth import synth_state_dict
+    unet_sd = synth_state_dict(param_shapes(build_spec(cases.TINY_MOTION)))
+    ref_sd = synth_state_dict(param_shapes(build_spec(cases.TINY)), prefix=cases.REF_PREFIX)
+    return unet_sd, ref_sd
+
+
+def _inputs():
+    from emote_hack_amd.synth import seeded_randn
+    return seeded_randn((1, 4, 8, 16, 16), 5), seeded_randn((1, 4, 16, 16), 3), seeded_randn((2, 5, 32), 2)
+
+
+def _worker(rank, world, port, kind, out_dir):
+    import torch.distributed as td
+    torch.set_num_threads(2)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    _patch_ops()
+    from emote_hack_amd import DDIMScheduler, DDPMScheduler
+    from emote_hack_amd.pipeline import EMOAnimationPipeline
+    unet_sd, ref_sd = _models()
+    unet = OracleBackedUNet(cases.TINY_MOTION, unet_sd)
+    ref = OracleBackedUNet(cases.TINY, ref_sd, has_out=False)
+    pipe = EMOAnimationPipeline(unet=unet, scheduler=DDIMScheduler() if kind == "ddim" else DDPMScheduler())
+    lat, refl, text = _inputs()
+    out = pipe.denoise(lat, refl, text, appearance_encoder=ref, num_inference_steps=3, guidance_scale=7.5, context_frames=4,
+                       context_stride=1, context_overlap=0, seed=0, dist=True, rank=rank, world_size=world)
+    torch.save(out.clone(), os.path.join(out_dir, f"lat_{kind}_{rank}.pt"))
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["ddim", "ddpm"])
+def test_two_rank_gloo_loop_matches_single_process_oracle(tmp_path, kind):
+    from oracle.pipeline_ref import denoise_loop
+    from oracle.scheduler_ref import SchedulerRef
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
+    l0 = torch.load(os.path.join(tmp_path, f"lat_{kind}_0.pt"))
+    l1 = torch.load(os.path.join(tmp_path, f"lat_{kind}_1.pt"))
+    assert torch.equal(l0, l1), "ranks must hold identical latents without a broadcast"
+    unet_sd, ref_sd = _models()
+    lat, refl, text = _inputs()
+    ref = denoise_loop(unet_sd, cases.TINY_MOTION, ref_sd, cases.TINY, lat, refl, text, scheduler=SchedulerRef(kind),
+                       num_inference_steps=3, guidance_scale=7.5, context_frames=4, context_stride=1, context_overlap=0, seed=0)
+    torch.testing.assert_close(l0, ref, rtol=1e-3, atol=1e-4)
+
+
+def test_window_dealing_covers_every_frame_once():
+    """`global_context[rank::world_size]` (EMOAnimationPipeline.py:757): with overlap 0 every frame belongs to
+    exactly one rank's windows; with overlap the counters add up to the single-rank counter."""
+    from emote_hack_amd.context import uniform
+    for f_tot, ctx, ov, world in ((48, 12, 0, 4), (96, 12, 0, 8), (48, 16, 4, 4), (24, 16, 4, 2)):
+        windows = list(uniform(0, 50, f_tot, ctx, 1, ov))
+        total = torch.zeros(f_tot)
+        for w in windows:
+            total[w] += 1
+        per_rank = torch.zeros(f_tot)
+        for r in range(world):
+            for w in windows[r::world]:
+                per_rank[w] += 1
+        assert torch.equal(total, per_rank) and bool((total >= 1).all())
+        if ov == 0:
+            assert bool((total == 1).all())
