@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libemo_hip.so")
+LIB_PATH = os.environ.get("EMO_HIP_LIB") or os.path.join(HERE, "lib", "libemo_hip.so")
 
 EMO_F32, EMO_BF16 = 0, 1
 
@@ -73,6 +73,11 @@ SIGNATURES = {
     "emo_temporal_attention": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _i, _i, _f, _i, _p]),
     "emo_cfg_step": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _u32, _u32, _p]),
     "emo_accumulate_window": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "emo_act": (_i, [_p, _p, _i64, _i, _i, _p]),
+    "emo_speed_encode": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "emo_speed_bucket": (_i, [_p, _p, _p, _i, _i, _p]),
+    "emo_gather_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "emo_add_rowbias": (_i, [_p, _i, _p, _i, _p, _i, _i64, _i, _i, _i, _p]),
 }
 
 _lib = None

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libemo_hip.so")
-SOURCES = ["elementwise.hip", "norm.hip", "gemm.hip", "attention.hip", "temporal.hip"]
+SOURCES = ["elementwise.hip", "norm.hip", "gemm.hip", "attention.hip", "temporal.hip", "conditioning.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-pass-failed"]

@@ -1,0 +1,293 @@
+"""EMO conditioning modules on MI355X - host mirrors of the reference's small
+pure-torch classes, same constructor arguments and state-dict keys, arithmetic in HIP kernels.
+
+  SpeedEncoder              Net.py:198-258                 tanh bucket code -> Linear -> ReLU -> Linear
+  SpeedController           train_stage_3_speedlayers.py:20-55 (= Net.py:554-589)   argmin bucket (INT) -> Embedding -> MLP
+  FaceRegionController      train_stage_3_speedlayers.py:57-76      4x conv3x3 (+ReLU)
+  CrossAttentionLayer / AudioAttentionLayers / ReferenceAttentionLayer   Net.py:263-365   single-head attention, q/k/v WITH bias
+  AudioAttention / TemporalAttention      train_stage_2_temporal_audio.py:123-177        8-head cross / temporal attention
+  stage3_combine            train_stage_3_speedlayers.py:242-271    unet(latents + face) + speed_embed[..., None, None]
+
+None of these is wired into the UNet by the reference (EMOAnimationPipeline.py:783-784 passes kwargs the UNet
+rejects); here the UNet accepts their outputs (`speed_embeddings`, `audio_features`).  Reference quirks kept as
+documented behaviour: SpeedEncoder has 9 fixed centres (the reference ctor asserts len == num_speed_buckets, so
+only 9 works: Net.py:212,221-224); CrossAttentionLayer needs q-len == kv-len only through its assert (:287),
+which we keep.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+from ._lib import EmoHipError
+
+
+class _HipModule:
+    """state-dict driven module: shapes declared by subclasses; weights packed on .to(device, dtype)."""
+    _shapes: dict = {}
+
+    def __init__(self):
+        self._sd = None
+        self.dtype, self.device = torch.float32, torch.device("cpu")
+        self._w = None
+
+    def state_dict_shapes(self):
+        return dict(self._shapes)
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self._shapes if k not in sd]
+        if strict and missing:
+            raise RuntimeError(f"missing keys {missing}")
+        for k, shp in self._shapes.items():
+            if k in sd and tuple(sd[k].shape) != tuple(shp):
+                raise RuntimeError(f"size mismatch for {k}")
+        self._sd = {k: sd[k].detach().float() for k in self._shapes if k in sd}
+        self._pack()
+        return missing, [k for k in sd if k not in self._shapes]
+
+    def to(self, device=None, dtype=None):
+        if dtype is not None:
+            self.dtype = dtype
+        if device is not None:
+            self.device = torch.device(device)
+        self._pack()
+        return self
+
+    def _pack(self):
+        if self._sd is None or self.device.type != "cuda":
+            return
+        self._w = {k: (v.to(self.device, self.dtype if (v.dim() >= 2 and not k.endswith("temperature")) else torch.float32)).contiguous()
+                   for k, v in self._sd.items()}
+
+    def _need(self):
+        if self._w is None:
+            raise EmoHipError(f"{type(self).__name__}: load_state_dict + .to('cuda') first (no CPU execution path)")
+
+    def _lin(self, x, name, relu=False):
+        y = ops.gemm(x, self._w[name + ".weight"], self._w.get(name + ".bias"))
+        return ops.act(y, "relu") if relu else y
+
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+
+class SpeedEncoder(_HipModule):
+    CENTERS = [-1.0, -0.5, -0.2, -0.1, 0.0, 0.1, 0.2, 0.5, 1.0]   # Net.py:221-224
+
+    def __init__(self, num_speed_buckets: int, speed_embedding_dim: int):
+        super().__init__()
+        assert isinstance(num_speed_buckets, int) and num_speed_buckets > 0
+        assert isinstance(speed_embedding_dim, int) and speed_embedding_dim > 0
+        assert len(self.CENTERS) == num_speed_buckets, "bucket_centers length must match num_speed_buckets"   # Net.py:212
+        self.num_speed_buckets, self.speed_embedding_dim = num_speed_buckets, speed_embedding_dim
+        D = speed_embedding_dim
+        self._shapes = {"mlp.0.weight": (D, num_speed_buckets), "mlp.0.bias": (D,), "mlp.2.weight": (D, D), "mlp.2.bias": (D,)}
+
+    def _pack(self):
+        super()._pack()
+        if self._w is not None:
+            nb = self.num_speed_buckets
+            w0 = torch.zeros(self.speed_embedding_dim, 16, device=self.device, dtype=self.dtype)   # K padded 9 -> 16
+            w0[:, :nb] = self._w["mlp.0.weight"]
+            self._w["mlp.0.weight"] = w0
+            self._centers = torch.tensor(self.CENTERS + [0.0] * (16 - nb), device=self.device)
+            self._radii = torch.tensor([0.1] * nb + [1e30] * (16 - nb), device=self.device)  # pad: tanh(~0)=0 x zero weight
+
+    def encode_speed(self, v):
+        assert v.ndim == 1, "head_rotation_speed must be a 1D tensor"
+        self._need()
+        return ops.speed_encode(v.to(self.device).float().contiguous(), self._centers, self._radii, self.dtype)[:, :self.num_speed_buckets]
+
+    def forward(self, head_rotation_speeds):
+        assert head_rotation_speeds.ndim == 1 and head_rotation_speeds.dtype == torch.float32
+        self._need()
+        code = ops.speed_encode(head_rotation_speeds.to(self.device).contiguous(), self._centers, self._radii, self.dtype)
+        return self._lin(self._lin(code, "mlp.0", relu=True), "mlp.2")
+
+
+class SpeedController(_HipModule):
+    def __init__(self, num_buckets: int = 9, embed_dim: int = 1024):
+        super().__init__()
+        self.num_buckets, self.embed_dim = num_buckets, embed_dim
+        D = embed_dim
+        self._shapes = {"speed_embedding.weight": (num_buckets, D), "speed_mlp.0.weight": (D, D), "speed_mlp.0.bias": (D,),
+                        "speed_mlp.2.weight": (D, D), "speed_mlp.2.bias": (D,)}
+
+    def map_speed_to_bucket(self, speed):
+        centers = torch.linspace(-1.0, 1.0, self.num_buckets).to(self.device)   # constant table, as the reference's buffer
+        return ops.speed_bucket(speed.to(self.device).float().contiguous(), centers)
+
+    def forward(self, speeds):
+        self._need()
+        idx = self.map_speed_to_bucket(speeds)
+        e = ops.gather_rows(self._w["speed_embedding.weight"], idx)
+        return self._lin(self._lin(e, "speed_mlp.0", relu=True), "speed_mlp.2")
+
+
+class FaceRegionController(_HipModule):
+    def __init__(self, in_channels: int = 1, out_channels: int = 1024):
+        super().__init__()
+        self.chans = [in_channels, 64, 128, 256, out_channels]
+        self._shapes = {}
+        for i, k in enumerate((0, 2, 4, 6)):
+            self._shapes[f"encoder.{k}.weight"] = (self.chans[i + 1], self.chans[i], 3, 3)
+            self._shapes[f"encoder.{k}.bias"] = (self.chans[i + 1],)
+
+    def _pack(self):
+        if self._sd is None or self.device.type != "cuda":
+            return
+        self._w = {}
+        for i, k in enumerate((0, 2, 4, 6)):
+            t = self._sd[f"encoder.{k}.weight"].to(self.device)
+            co, ci = t.shape[:2]
+            cip = (ci + 7) // 8 * 8
+            o = torch.zeros(co, 3, 3, cip, device=self.device)
+            o[..., :ci] = t.permute(0, 2, 3, 1)
+            self._w[f"encoder.{k}.weight"] = o.reshape(co, 9 * cip).to(self.dtype).contiguous()
+            self._w[f"encoder.{k}.bias"] = self._sd[f"encoder.{k}.bias"].to(self.device).float().contiguous()
+
+    def forward(self, mask):
+        """mask (B, Cin, H, W) -> (B, D, H, W) f32."""
+        self._need()
+        B, Cin, H, W = mask.shape
+        x = ops.ncfhw_to_rows(mask.to(self.device).unsqueeze(2), self.dtype, cpad=(Cin + 7) // 8 * 8)
+        for i, k in enumerate((0, 2, 4, 6)):
+            x, _, _ = ops.conv3x3(x, self._w[f"encoder.{k}.weight"], self._w[f"encoder.{k}.bias"], B, H, W)
+            if k != 6:
+                x = ops.act(x, "relu")
+        return ops.rows_to_ncfhw(x, B, self.chans[-1], 1, H, W).squeeze(2)
+
+
+class CrossAttentionLayer(_HipModule):
+    """Net.py:263-303: single head, q/k/v Linear with bias, scores / sqrt(feature_dim)."""
+
+    def __init__(self, feature_dim):
+        super().__init__()
+        self.feature_dim = feature_dim
+        D = feature_dim
+        self._shapes = {f"{n}.{w}": ((D, D) if w == "weight" else (D,)) for n in ("query", "key", "value") for w in ("weight", "bias")}
+
+    def forward(self, latent_code, audio_features, _prefix=""):
+        assert latent_code.dim() == 3 and audio_features.dim() == 3
+        assert latent_code.size(1) == audio_features.size(1), "Feature dimensions of latent_code and audio_features must match"
+        self._need()
+        B, Lq, D = latent_code.shape
+        Lk = audio_features.shape[1]
+        x = ops.convert(latent_code.to(self.device).float().reshape(-1, D), self.dtype)
+        a = ops.convert(audio_features.to(self.device).float().reshape(-1, D), self.dtype)
+        w = self._w
+        q = ops.gemm(x, w[_prefix + "query.weight"], w[_prefix + "query.bias"])
+        k = ops.gemm(a, w[_prefix + "key.weight"], w[_prefix + "key.bias"])
+        vt = ops.gemm(a, w[_prefix + "value.weight"], w[_prefix + "value.bias"], transpose_rows=Lk, transpose_ld=(Lk + 7) // 8 * 8)
+        o = ops.attention(q, k, vt, Lk, B=B, Lq=Lq, heads=1, d=D, scale=1.0 / math.sqrt(D))
+        return ops.convert(o, torch.float32).reshape(B, Lq, D)
+
+
+class AudioAttentionLayers(_HipModule):
+    """Net.py:305-325: latent = layer(latent, audio) + latent per layer."""
+
+    def __init__(self, feature_dim, num_layers):
+        super().__init__()
+        assert feature_dim > 0 and num_layers > 0
+        self.feature_dim, self.num_layers = feature_dim, num_layers
+        D = feature_dim
+        self._shapes = {f"layers.{i}.{n}.{w}": ((D, D) if w == "weight" else (D,)) for i in range(num_layers)
+                        for n in ("query", "key", "value") for w in ("weight", "bias")}
+        self._layer = CrossAttentionLayer(feature_dim)
+
+    def forward(self, latent_code, audio_features):
+        self._need()
+        self._layer._w, self._layer.dtype, self._layer.device = self._w, self.dtype, self.device
+        x = latent_code.to(self.device).float()
+        for i in range(self.num_layers):
+            y = self._layer.forward(x, audio_features, _prefix=f"layers.{i}.")
+            x = ops.add(y.reshape(-1, self.feature_dim), x.reshape(-1, self.feature_dim).contiguous()).reshape(x.shape)
+        return x
+
+
+class ReferenceAttentionLayer(CrossAttentionLayer):
+    """Net.py:333-365: same single-head attention, residual inside; reference (B, 1, D) key/value."""
+
+    def forward(self, latent_code, reference_features):
+        self._need()
+        B, Lq, D = latent_code.shape
+        Lk = reference_features.shape[1]
+        x = ops.convert(latent_code.to(self.device).float().reshape(-1, D), self.dtype)
+        a = ops.convert(reference_features.to(self.device).float().reshape(-1, D), self.dtype)
+        w = self._w
+        q = ops.gemm(x, w["query.weight"], w["query.bias"])
+        k = ops.gemm(a, w["key.weight"], w["key.bias"])
+        vt = ops.gemm(a, w["value.weight"], w["value.bias"], transpose_rows=Lk, transpose_ld=(Lk + 7) // 8 * 8)
+        o = ops.attention(q, k, vt, Lk, B=B, Lq=Lq, heads=1, d=D, scale=1.0 / math.sqrt(D))
+        return ops.convert(ops.add(o, x), torch.float32).reshape(B, Lq, D)
+
+
+class AudioAttention(_HipModule):
+    """train_stage_2_temporal_audio.py:146-177: q = frame_proj(x); k = v = audio_proj(a) (shared); 8 heads."""
+
+    def __init__(self, frame_dim: int, audio_dim: int, num_heads: int = 8):
+        super().__init__()
+        self.frame_dim, self.audio_dim, self.num_heads = frame_dim, audio_dim, num_heads
+        self.scale = (frame_dim // num_heads) ** -0.5
+        C = frame_dim
+        self._shapes = {"frame_proj.weight": (C, C), "frame_proj.bias": (C,), "audio_proj.weight": (C, audio_dim),
+                        "audio_proj.bias": (C,), "out_proj.weight": (C, C), "out_proj.bias": (C,)}
+
+    def forward(self, frame_features, audio_features):
+        self._need()
+        B, T, C = frame_features.shape
+        La = audio_features.shape[1]
+        x = ops.convert(frame_features.to(self.device).float().reshape(-1, C), self.dtype)
+        a = ops.convert(audio_features.to(self.device).float().reshape(-1, self.audio_dim), self.dtype)
+        w = self._w
+        q = ops.gemm(x, w["frame_proj.weight"], w["frame_proj.bias"])
+        k = ops.gemm(a, w["audio_proj.weight"], w["audio_proj.bias"])
+        vt = ops.gemm(a, w["audio_proj.weight"], w["audio_proj.bias"], transpose_rows=La, transpose_ld=(La + 7) // 8 * 8)
+        o = ops.attention(q, k, vt, La, B=B, Lq=T, heads=self.num_heads, d=C // self.num_heads, scale=self.scale)
+        return ops.convert(ops.gemm(o, w["out_proj.weight"], w["out_proj.bias"]), torch.float32).reshape(B, T, C)
+
+
+class TemporalAttention(_HipModule):
+    """train_stage_2_temporal_audio.py:123-144: fused qkv (no bias); scores * per-head `temperature` (init 1.0, NOT
+    d^-0.5).  The temperature is folded into the q rows of the packed qkv weight (exact: a per-head scalar)."""
+
+    def __init__(self, dim: int, num_heads: int = 8):
+        super().__init__()
+        self.dim, self.num_heads = dim, num_heads
+        self._shapes = {"temperature": (num_heads, 1, 1), "qkv.weight": (3 * dim, dim), "proj.weight": (dim, dim), "proj.bias": (dim,)}
+
+    def _pack(self):
+        if self._sd is None or self.device.type != "cuda":
+            return
+        C, H = self.dim, self.num_heads
+        wq = self._sd["qkv.weight"].clone()
+        wq[:C] = wq[:C] * self._sd["temperature"].reshape(H, 1, 1).expand(H, C // H, 1).reshape(C, 1)
+        self._w = {"q": wq[:C].to(self.device, self.dtype).contiguous(), "k": wq[C:2 * C].to(self.device, self.dtype).contiguous(),
+                   "v": wq[2 * C:].to(self.device, self.dtype).contiguous(),
+                   "proj.weight": self._sd["proj.weight"].to(self.device, self.dtype).contiguous(),
+                   "proj.bias": self._sd["proj.bias"].to(self.device).float().contiguous()}
+
+    def forward(self, x):
+        self._need()
+        B, T, C = x.shape
+        xr = ops.convert(x.to(self.device).float().reshape(-1, C), self.dtype)
+        q, k = ops.gemm(xr, self._w["q"]), ops.gemm(xr, self._w["k"])
+        vt = ops.gemm(xr, self._w["v"], transpose_rows=T, transpose_ld=(T + 7) // 8 * 8)
+        o = ops.attention(q, k, vt, T, B=B, Lq=T, heads=self.num_heads, d=C // self.num_heads, scale=1.0)
+        return ops.convert(ops.gemm(o, self._w["proj.weight"], self._w["proj.bias"]), torch.float32).reshape(B, T, C)
+
+
+def stage3_combine(unet_fn, noisy_latents, face_features, speed_embed):
+    """EMOStage3.forward combine rule (train_stage_3_speedlayers.py:242-271) on 4-D latents (B, C, H, W):
+    unet(latents + face_features) + speed_embed[..., None, None].  Elementwise parts run in HIP."""
+    B, Cc, H, W = noisy_latents.shape
+    dev = face_features.device if face_features.is_cuda else torch.device("cuda")
+    a = ops.ncfhw_to_rows(noisy_latents.to(dev).unsqueeze(2), torch.float32)
+    f = ops.ncfhw_to_rows(face_features.to(dev).unsqueeze(2), torch.float32)
+    aug = ops.rows_to_ncfhw(ops.add(a, f), B, Cc, 1, H, W).squeeze(2)
+    out = unet_fn(aug)
+    o = ops.ncfhw_to_rows(out.to(dev).unsqueeze(2), torch.float32)
+    o = ops.add_rowbias(o, speed_embed.to(dev).float().contiguous(), H * W)
+    return ops.rows_to_ncfhw(o, B, out.shape[1], 1, H, W).squeeze(2)

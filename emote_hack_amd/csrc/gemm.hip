@@ -115,45 +115,65 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
     }
   }
   int b_klog[LB];
-  const T* b_base[LB];
-  bool b_ok[LB];
+  const T* b_ptr[LB];     // advanced by b_inc (BK or 0 elements) per issued stage: 2 VALU adds per glds
+  int b_inc[LB];
 #pragma unroll
   for (int i = 0; i < LB; i++) {
     const int row = (i * NW + wave) * 16 + lrow;
     b_klog[i] = (lane & 3) ^ ((row >> 2) & 3);
     const int n = bn + row;
-    b_ok[i] = row < BN && n < p.N;
-    b_base[i] = W + (int64_t)(b_ok[i] ? n : 0) * p.K;
+    const bool ok = row < BN && n < p.N;
+    b_ptr[i] = ok ? W + (int64_t)n * p.K + b_klog[i] * V : zero;
+    b_inc[i] = ok ? BK : 0;
   }
+  const T* a_ptr[LA];
+  int a_inc[LA];
+#pragma unroll
+  for (int i = 0; i < LA; i++) {
+    a_ptr[i] = a_ok[i] ? a_base[i] + a_klog[i] * V : zero;
+    a_inc[i] = a_ok[i] ? BK : 0;
+  }
+  const bool k_ragged = (p.K % BK) != 0;            // only the very last stage can run past K
+  const bool cin_aligned = CONV && (p.Cin % BK) == 0; // a stage then lies inside one 3x3 tap (tap is wave-uniform)
 
-  auto issue = [&](int kt, int slot) {   // kt: absolute k-stage index
+  auto issue = [&](int kt, int slot) {   // kt: absolute k-stage index; called with kt increasing by 1
     unsigned char* sa = lds + slot * Tile::STAGE_BYTES;
     unsigned char* sb = sa + Tile::A_BYTES;
+    const bool tail = k_ragged && (kt + 1) * BK > p.K;
+    if constexpr (!CONV) {
 #pragma unroll
-    for (int i = 0; i < LA; i++) {
-      const int k0 = kt * BK + a_klog[i] * V;
-      const T* src = zero;
-      if (a_ok[i] && k0 < p.K) {
-        if (!CONV) {
-          src = a_base[i] + k0;
-        } else {
-          const int tap = k0 / p.Cin, ci = k0 - tap * p.Cin;
-          const int ky = tap / 3, kx = tap - ky * 3;
-          int iy = a_cr[i].iy0 + ky, ix = a_cr[i].ix0 + kx;
-          const int Hin = p.upsample2x ? 2 * p.H : p.H, Win = p.upsample2x ? 2 * p.W_ : p.W_;
-          if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
-            if (p.upsample2x) { iy >>= 1; ix >>= 1; }
-            src = A + (((int64_t)a_cr[i].img * p.H + iy) * p.W_ + ix) * p.lda + ci;
-          }
-        }
+      for (int i = 0; i < LA; i++) {
+        const T* src = a_ptr[i];
+        if (tail && kt * BK + a_klog[i] * V >= p.K) src = zero;
+        EMO_GLDS16(src, sa + (i * NW + wave) * 1024);
+        a_ptr[i] += a_inc[i];
       }
-      EMO_GLDS16(src, sa + (i * NW + wave) * 1024);
+    } else {
+      int tap_u = 0, ci_u = 0;
+      if (cin_aligned) { tap_u = (kt * BK) / p.Cin; ci_u = kt * BK - tap_u * p.Cin; }
+      const int Hin = p.upsample2x ? 2 * p.H : p.H, Win = p.upsample2x ? 2 * p.W_ : p.W_;
+#pragma unroll
+      for (int i = 0; i < LA; i++) {
+        const int k0 = kt * BK + a_klog[i] * V;
+        int tap, ci;
+        if (cin_aligned) { tap = tap_u; ci = ci_u + a_klog[i] * V; }
+        else { tap = k0 / p.Cin; ci = k0 - tap * p.Cin; }
+        const int ky = tap / 3, kx = tap - ky * 3;
+        int iy = a_cr[i].iy0 + ky, ix = a_cr[i].ix0 + kx;
+        const T* src = zero;
+        if (a_ok[i] && k0 < p.K && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
+          if (p.upsample2x) { iy >>= 1; ix >>= 1; }
+          src = A + (((int64_t)a_cr[i].img * p.H + iy) * p.W_ + ix) * p.lda + ci;
+        }
+        EMO_GLDS16(src, sa + (i * NW + wave) * 1024);
+      }
     }
 #pragma unroll
     for (int i = 0; i < LB; i++) {
-      const int k0 = kt * BK + b_klog[i] * V;
-      const T* src = (b_ok[i] && k0 < p.K) ? b_base[i] + k0 : zero;
+      const T* src = b_ptr[i];
+      if (tail && kt * BK + b_klog[i] * V >= p.K) src = zero;
       EMO_GLDS16(src, sb + (i * NW + wave) * 1024);
+      b_ptr[i] += b_inc[i];
     }
   };
 
@@ -186,6 +206,12 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
     for (int kk = 0; kk < 2; kk++) fb_off[j][kk] = Tile::A_BYTES + r * KBYTES + (((kk * 2 + half) ^ ((r >> 2) & 3)) * 16);
   }
 
+  if (kt0 > 0) {   // split-K slice: start the incremental pointers at this slice's first stage
+#pragma unroll
+    for (int i = 0; i < LA; i++) a_ptr[i] += (int64_t)kt0 * a_inc[i];
+#pragma unroll
+    for (int i = 0; i < LB; i++) b_ptr[i] += (int64_t)kt0 * b_inc[i];
+  }
 #pragma unroll
   for (int s = 0; s < NS - 1; s++)
     if (s < nk) issue(kt0 + s, s);
@@ -196,7 +222,11 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
     else if (NS > 3 && rem == 1) wait_vmcnt<LPS>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // everyone's part of stage kt landed; everyone finished reading slot (kt-1)%NS
-    if (kt + NS - 1 < nk) issue(kt0 + kt + NS - 1, (kt + NS - 1) % NS);
+    // dense: issue the next stage's loads right after the barrier; conv: after the first MFMA cluster (its
+    // per-lane address arithmetic then overlaps the matrix pipe: +8 % on the 3x3 convs, neutral for dense)
+    if constexpr (!CONV) {
+      if (kt + NS - 1 < nk) issue(kt0 + kt + NS - 1, (kt + NS - 1) % NS);
+    }
     const unsigned st = lds_base + (kt % NS) * Tile::STAGE_BYTES;
     uint4 fa[2][WTM], fb[2][WTN];
 #pragma unroll
@@ -215,6 +245,10 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
         if constexpr (TRANS) acc[i][j] = mma16<T>(fa[0][i], fb[0][j], acc[i][j]);   // rows = m, lane = n
         else acc[i][j] = mma16<T>(fb[0][j], fa[0][i], acc[i][j]);                   // rows = n, lane = m
       }
+    if constexpr (CONV) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + NS - 1 < nk) issue(kt0 + kt + NS - 1, (kt + NS - 1) % NS);
+    }
     wait_lgkmcnt<0>();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -415,6 +449,7 @@ static int launch_gemm(const emo_gemm_params& p, int S, hipStream_t st) {
 
 template <typename T, bool CONV, bool TRANS>
 static int dispatch_tile(const emo_gemm_params& p, const GemmPlan& pl, int S, hipStream_t st) {
+  // (4-wave 128x256 / 256x128 tiles were measured 15-35 % slower than the 8-wave 256x256 at equal LDS traffic per MFMA)
   if (pl.big && S == 1) return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, 4>(p, S, st);   // 2x4 waves of 128x64, 4 x 32 KB ring
   if (pl.nt5) return launch_gemm<T, CONV, TRANS, 1, 5, 4, 1, 3>(p, S, st);   // 4x1 waves of 32x160, 3 x 20 KB ring
   return launch_gemm<T, CONV, TRANS, 2, 2, 2, 2, 4>(p, S, st);               // 2x2 waves of 64x64, 4 x 16 KB ring

@@ -319,3 +319,45 @@ def accumulate_window(pred_rows, noise_pred_branch, counter, frames_i32, *, C_, 
     pp, ld = _rows(pred_rows)
     check(_lib.load().emo_accumulate_window(pp, ld, _ptr(noise_pred_branch), _ptr(counter), _ptr(frames_i32), frames_i32.numel(),
                                             C_, F, HW, int(add_counter), dt(pred_rows), _stream()), "emo_accumulate_window")
+
+
+# ----------------------------------------------------------------------------- EMO conditioning ops (A17/A18)
+_ACT = {"silu": 0, "relu": 1, "tanh": 2}
+
+
+def act(x: torch.Tensor, kind: str) -> torch.Tensor:
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    check(_lib.load().emo_act(_ptr(x), _ptr(y), x.numel(), _ACT[kind], dt(x), _stream()), "emo_act")
+    return y
+
+
+def speed_encode(v: torch.Tensor, centers: torch.Tensor, radii: torch.Tensor, dtype) -> torch.Tensor:
+    _need_cuda(v, centers, radii)
+    out = torch.empty(v.shape[0], centers.shape[0], device=v.device, dtype=dtype)
+    check(_lib.load().emo_speed_encode(_ptr(v), _ptr(centers), _ptr(radii), _ptr(out), v.shape[0], centers.shape[0], dt(dtype),
+                                       _stream()), "emo_speed_encode")
+    return out
+
+
+def speed_bucket(v: torch.Tensor, centers: torch.Tensor) -> torch.Tensor:
+    _need_cuda(v, centers)
+    idx = torch.empty(v.shape[0], device=v.device, dtype=torch.int32)
+    check(_lib.load().emo_speed_bucket(_ptr(v), _ptr(centers), _ptr(idx), v.shape[0], centers.shape[0], _stream()), "emo_speed_bucket")
+    return idx
+
+
+def gather_rows(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(idx.shape[0], table.shape[1], device=table.device, dtype=table.dtype)
+    check(_lib.load().emo_gather_rows(_ptr(table), _ptr(idx), _ptr(out), idx.shape[0], table.shape[1], table.shape[0], dt(table),
+                                      _stream()), "emo_gather_rows")
+    return out
+
+
+def add_rowbias(x: torch.Tensor, rb: torch.Tensor, rows_per_batch: int) -> torch.Tensor:
+    px, ldx = _rows(x)
+    pr, ldr = _rows(rb)
+    y = torch.empty(x.shape[0], x.shape[1], device=x.device, dtype=x.dtype)
+    check(_lib.load().emo_add_rowbias(px, ldx, pr, ldr, _ptr(y), y.stride(0), x.shape[0], x.shape[1], rows_per_batch, dt(x), _stream()),
+          "emo_add_rowbias")
+    return y

@@ -169,6 +169,21 @@ int emo_cfg_step(const float* noise_pred, const float* counter, float* latents, 
 int emo_accumulate_window(const void* pred, int ld, float* noise_pred_branch, float* counter, const int32_t* frames,
                           int nf, int C, int F, int HW, int add_counter, int dtype, void* stream);
 
+/* ---- EMO conditioning ----------------------------------------------
+ * emo_act: y = act(x), kind 0 SiLU | 1 ReLU | 2 tanh over n contiguous elements (the ReLU / tanh of
+ *   Net.py:214-218,246 and train_stage_3_speedlayers.py:36-40,66-73).
+ * emo_speed_encode: SpeedEncoder.encode_speed (Net.py:231-247): out[b,i] = tanh((v[b]-centers[i])/radii[i]*3).
+ * emo_speed_bucket: SpeedController.map_speed_to_bucket (train_stage_3_speedlayers.py:42-47), INT bit-exact:
+ *   idx[b] = argmin_i |v[b] - centers[i]| (first minimum on ties).
+ * emo_gather_rows: nn.Embedding lookup out[b,:] = table[idx[b],:].
+ * emo_add_rowbias: y[m,:] = x[m,:] + rb[m / rows_per_batch,:] (EMOStage3.forward combine, :268-269). */
+int emo_act(const void* x, void* y, int64_t n, int kind, int dtype, void* stream);
+int emo_speed_encode(const float* v, const float* centers, const float* radii, void* out, int B, int nb, int dtype, void* stream);
+int emo_speed_bucket(const float* v, const float* centers, int32_t* idx, int B, int nb, void* stream);
+int emo_gather_rows(const void* table, const int32_t* idx, void* out, int B, int D, int rows, int dtype, void* stream);
+int emo_add_rowbias(const void* x, int ldx, const void* rb, int ldr, void* y, int ldy, int64_t M, int C, int rows_per_batch,
+                    int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
