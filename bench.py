@@ -81,6 +81,21 @@ def cpu_baseline(unet, ref):
                       f"({t_ref:.1f}s); step = 2*unet + 2*refnet, x{NUM_INFERENCE_STEPS} steps"}
 
 
+def pmc_traffic(family):
+    """HBM bytes per launch of the kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
+    collected in separate runs of this same command, FETCH x2 gfx950 correction) - profiles/r*_pmc.json.
+    PMC counters cannot be read from inside the process, so this is the latest committed measurement or null."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))["per_kernel_family"].get(family)
+        return {"hbm_bytes_per_launch": d["hbm_bytes_per_launch"], "source": os.path.relpath(files[-1], ROOT)} if d else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,9 +187,10 @@ def main():
             out["roofline"] = {"kernel": {"gemm_dense": "gemm_kernel<bf16,false>", "gemm_conv3x3": "gemm_kernel<bf16,true>",
                                           "attention": "attention_kernel", "temporal_attention": "temporal_attention_kernel"}[dom],
                                "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / MFMA_PEAK_BF16_TFLOPS, "traffic": None,
+                               "frac": ach / MFMA_PEAK_BF16_TFLOPS, "traffic": pmc_traffic(dom),
                                "launches": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
-                               "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9}
+                               "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+                               "algorithmic_mbytes_per_launch": d["bytes"] / d["launches"] / 1e6}
             out["kernels"] = {k: {"launches": v["launches"], "ms_per_step": v["ms"] / a.steps,
                                   "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None,
                                   "gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in sorted(summ.items())}

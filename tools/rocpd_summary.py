@@ -32,3 +32,14 @@ def main(path):
 
 if __name__ == "__main__":
     main(sys.argv[1])
+
+
+def pmc(path, counter):
+    """per-kernel average of a PMC counter from a `rocprofv3 --pmc <counter> --kernel-trace` database"""
+    db = sqlite3.connect(path)
+    rows = db.execute("select name, counter_value from pmc_events where counter_name = ?", (counter,)).fetchall()
+    agg = {}
+    for name, v in rows:
+        d = agg.setdefault(short(name), [0, 0.0])
+        d[0] += 1; d[1] += v
+    return agg
