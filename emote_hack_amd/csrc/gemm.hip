@@ -343,7 +343,9 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
       }
     }
   } else {
-    // TRANS: lane <-> column n; register r <-> row m.  V^T store Ct[m / t_rows][n][m % t_rows]
+    // TRANS: lane <-> column n; register quad g <-> rows 8*g + 4*half + {0..3} (4 CONSECUTIVE rows), which are 4
+    // contiguous elements of V^T: Ct[m / t_rows][n][m % t_rows] -> one 8-byte (bf16) / 16-byte (f32) store per quad
+    const bool quad_ok = (p.t_rows & 3) == 0 && (p.t_ld & 3) == 0 && (p.t_batch_stride & 3) == 0;
 #pragma unroll
     for (int i = 0; i < WTM; i++)
 #pragma unroll
@@ -352,17 +354,34 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
         if (n >= p.N) continue;
         const float bias_v = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int64_t m = wm0 + i * 32 + mfma_row(r, half);
-          if (m >= p.M) continue;
+        for (int g = 0; g < 4; g++) {
+          const int64_t m0 = wm0 + i * 32 + 8 * g + 4 * half;
+          if (m0 >= p.M) continue;
           if (nsplit > 1) {
-            ((float*)p.workspace)[((int64_t)blockIdx.y * p.M + m) * p.N + n] = acc[i][j][r];
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+              if (m0 + e < p.M) ((float*)p.workspace)[((int64_t)blockIdx.y * p.M + m0 + e) * p.N + n] = acc[i][j][4 * g + e];
             continue;
           }
-          float v = acc[i][j][r] + bias_v;
-          if (p.rowbias) v += p.rowbias[(m / p.rows_per_batch) * p.ld_rowbias + n];
-          const int64_t b = m / p.t_rows, ml = m % p.t_rows;
-          TT<T>::st(C + b * p.t_batch_stride + (int64_t)n * p.t_ld + ml, v * p.out_scale);
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            float v = acc[i][j][4 * g + e] + bias_v;
+            if (p.rowbias && m0 + e < p.M) v += p.rowbias[((m0 + e) / p.rows_per_batch) * p.ld_rowbias + n];
+            o[e] = v * p.out_scale;
+          }
+          const int64_t b = m0 / p.t_rows, ml = m0 % p.t_rows;
+          T* dst = C + b * p.t_batch_stride + (int64_t)n * p.t_ld + ml;
+          if (quad_ok && m0 + 3 < p.M) {   // t_rows % 4 == 0 => the quad never straddles a batch
+            if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+            else *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              const int64_t m = m0 + e;
+              if (m < p.M) TT<T>::st(C + (m / p.t_rows) * p.t_batch_stride + (int64_t)n * p.t_ld + (m % p.t_rows), o[e]);
+            }
+          }
         }
       }
   }

@@ -87,7 +87,7 @@ class EMOAnimationPipeline:
     def prepare_denoise(self, latents, ref_image_latents, text_embeddings, *, appearance_encoder, num_inference_steps=50,
                         guidance_scale=7.5, eta=0.0, context_frames=16, context_stride=1, context_overlap=4,
                         context_batch_size=1, context_schedule="uniform", audio_features=None, speed_embeddings=None, seed=0,
-                        fusion_blocks="midup", dist=False, rank=0, world_size=1, return_eps=False):
+                        fusion_blocks="midup", dist=False, rank=0, world_size=1, return_eps=False, use_graphs=False):
         """Set up the loop state (EMOAnimationPipeline.py:628-696).  latents f32 (1,4,F_tot,h,w);
         ref_image_latents (1,4,h,w); text_embeddings (2,L,D) = [uncond, cond]."""
         unet, sch = self.unet, self.scheduler
@@ -116,13 +116,23 @@ class EMOAnimationPipeline:
         nb = math.ceil(len(queue) / st.cbs)
         st.global_context = [queue[i * st.cbs:(i + 1) * st.cbs] for i in range(nb)]
         st.frame_idx = {tuple(c): torch.tensor(c, dtype=torch.int32, device=dev) for ctx in st.global_context for c in ctx}
+        st.dist_pre, st.rank_pre, st.world_pre = bool(dist) and world_size > 1, rank, world_size
+        st.my_contexts = st.global_context[rank::world_size] if st.dist_pre else st.global_context          # :757
+        st.ctx_index = [[torch.tensor(c, dtype=torch.int64, device=dev) for c in ctx] for ctx in st.my_contexts]
+        st.t_table = torch.tensor(st.timesteps, dtype=torch.int64, device=dev)   # INT timestep table, bit-exact
+        st.t_buf = torch.zeros(1, dtype=torch.int64, device=dev)
+        st.use_graphs, st.graphs, st.graph_pool = bool(use_graphs), {}, None
+        if st.use_graphs:
+            st.graph_pool = torch.cuda.graph_pool_handle()
+        if audio_features is not None:
+            audio_features = audio_features.to(dev)
         st.noise_pred = torch.empty(2, st.C4, st.f_tot, st.HW, device=dev, dtype=torch.float32)
         st.counter = torch.empty(st.f_tot, device=dev, dtype=torch.float32)
         st.guidance_scale, st.eta, st.seed = guidance_scale, eta, seed
         st.audio_features, st.speed_embeddings = audio_features, speed_embeddings
         st.dist, st.rank, st.world_size = bool(dist) and world_size > 1, rank, world_size
         st.return_eps, st.eps_trace = return_eps, []
-        st.bank_group, st.bank_shapes, st.bank_group_start = None, None, -1
+        st.bank_group, st.bank_shapes, st.bank_group_start, st.bank_now = None, None, -1, None
         return st
 
     def _exchange_banks(self, st, si):
@@ -133,46 +143,79 @@ class EMOAnimationPipeline:
         import torch.distributed as td
         ws = st.world_size
         mine = min(si + st.rank, len(st.timesteps) - 1)   # tail group: surplus ranks recompute the last step (unused)
-        self._write_banks(st.appearance_encoder, st.writer, st.ref_rep, st.timesteps[mine], st.text)
+        self._write_banks(st.appearance_encoder, st.writer, st.ref_rep, st.t_table[mine:mine + 1], st.text)
         st.bank_shapes = [tuple(st.writer.bank[p][0].shape) for p in st.writer.order]
         send = self._pack_banks(st.writer)
         recv = torch.empty(ws * send.numel(), device=send.device, dtype=send.dtype)   # flat: valid for RCCL and gloo
         td.all_gather_into_tensor(recv, send)
         st.bank_group, st.bank_group_start = recv.view(ws, send.numel()), si
+        if getattr(st, "bank_now", None) is None:
+            st.bank_now = torch.empty_like(send)
+
+    # ---- the two GPU-heavy parts of a step; both read the timestep from the device buffer st.t_buf so that they
+    #      can be captured once into HIP graphs and replayed for the other 49 steps
+    def _part_writer(self, st):
+        self._write_banks(st.appearance_encoder, st.writer, st.ref_rep, st.t_buf, st.text)    # :711-716
+
+    def _part_unet(self, st, ci):
+        unet, dev = self.unet, self.unet.device
+        context = st.my_contexts[ci]
+        idx = st.ctx_index[ci]                                                               # device int64 frame indices
+        x = torch.cat([st.latents.index_select(2, i) for i in idx]).repeat(2, 1, 1, 1, 1)    # :759-763 (index/copy only)
+        x = self.scheduler.scale_model_input(x, None)
+        b = x.shape[0]
+        st.reader.update(st.writer)                                                           # :774
+        af = None
+        if st.audio_features is not None:   # per-frame audio context; uc rows get a zero context
+            cond = torch.cat([st.audio_features.index_select(0, i) for i in idx])
+            af = torch.cat([torch.zeros_like(cond), cond])
+        rows = unet(x, st.t_buf, encoder_hidden_states=st.text[:b], audio_features=af, speed_embeddings=st.speed_embeddings,
+                    return_dict=False, _return_rows=True)                                     # :777-786
+        st.reader.clear()                                                                     # :788
+        nf = len(context[0])
+        for j, c in enumerate(context):                                                       # :790-794
+            fr = st.frame_idx[tuple(c)]
+            for branch in (0, 1):
+                bi = branch * len(context) + j
+                ops.accumulate_window(rows[bi * nf * st.HW:(bi + 1) * nf * st.HW], st.noise_pred[branch], st.counter, fr,
+                                      C_=st.C4, F=st.f_tot, HW=st.HW, add_counter=(branch == 0))
+
+    def _run(self, st, key, fn):
+        """Eager on first use (warm-up: lazy kernel attributes, allocator), HIP-graph capture on the second, replay after.
+        Launch-bound host code (~1700 kernel launches per step from Python) disappears from the critical path."""
+        if not st.use_graphs or ops.PROFILER is not None:
+            return fn()
+        state = st.graphs.get(key)
+        if state is None:
+            fn()
+            st.graphs[key] = "warm"
+            return
+        if state == "warm":
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=st.graph_pool):
+                fn()
+            st.graphs[key] = g
+            state = g
+        state.replay()
 
     @torch.no_grad()
     def denoise_step(self, st, si):
         """One iteration of the hot loop (EMOAnimationPipeline.py:698-823)."""
-        unet, sch = self.unet, self.scheduler
-        dev = unet.device
+        sch = self.scheduler
+        dev = self.unet.device
         t = st.timesteps[si]
+        st.t_buf.copy_(st.t_table[si:si + 1], non_blocking=True)     # device-to-device: the INT timestep of this step
         st.noise_pred.zero_()
         st.counter.zero_()
         if not st.dist:
-            self._write_banks(st.appearance_encoder, st.writer, st.ref_rep, t, st.text)       # :711-716
+            self._run(st, "writer", lambda: self._part_writer(st))
         else:
             if st.bank_group is None or si >= st.bank_group_start + st.world_size or si < st.bank_group_start:
                 self._exchange_banks(st, si)
-            self._unpack_banks(st.bank_group[si - st.bank_group_start], st.writer, st.bank_shapes)
-        for context in st.global_context[st.rank::st.world_size] if st.dist else st.global_context:   # :757
-            x = torch.cat([st.latents[:, :, c] for c in context]).repeat(2, 1, 1, 1, 1)       # :759-763 (index/copy only)
-            x = sch.scale_model_input(x, t)
-            b = x.shape[0]
-            st.reader.update(st.writer)                                                        # :774
-            af = None
-            if st.audio_features is not None:   # per-frame audio context; uc rows get a zero context
-                cond = torch.cat([st.audio_features[c] for c in context]).to(dev)
-                af = torch.cat([torch.zeros_like(cond), cond])
-            rows = unet(x, t, encoder_hidden_states=st.text[:b], audio_features=af, speed_embeddings=st.speed_embeddings,
-                        return_dict=False, _return_rows=True)                                  # :777-786
-            st.reader.clear()                                                                  # :788
-            nf = len(context[0])
-            for j, c in enumerate(context):                                                    # :790-794
-                fr = st.frame_idx[tuple(c)]
-                for branch in (0, 1):
-                    bi = branch * len(context) + j
-                    ops.accumulate_window(rows[bi * nf * st.HW:(bi + 1) * nf * st.HW], st.noise_pred[branch], st.counter, fr,
-                                          C_=st.C4, F=st.f_tot, HW=st.HW, add_counter=(branch == 0))
+            st.bank_now.copy_(st.bank_group[si - st.bank_group_start])   # static buffer: graph-stable addresses
+            self._unpack_banks(st.bank_now, st.writer, st.bank_shapes)
+        for ci in range(len(st.my_contexts)):                                                  # :757
+            self._run(st, ("unet", ci), lambda ci=ci: self._part_unet(st, ci))
         if st.dist:                                                                            # replaces :796-809 + :819-821
             import torch.distributed as td
             td.all_reduce(st.noise_pred)

@@ -96,8 +96,9 @@ def test_reference_write_read(tiny, dtype):
         torch.testing.assert_close(y[:1].cpu(), tiny["motion/out"][:1], rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("graphs", [False, True])
 @pytest.mark.parametrize("kind", ["ddim", "ddpm"])
-def test_denoise_loop_vs_golden(kind):
+def test_denoise_loop_vs_golden(kind, graphs):
     """3 steps, 8 frames in overlapping windows of 4 - the loop of EMOAnimationPipeline.py:698-823."""
     from emote_hack_amd import DDIMScheduler, DDPMScheduler
     from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
@@ -109,7 +110,7 @@ def test_denoise_loop_vs_golden(kind):
     pipe = EMOAnimationPipeline(unet=unet, scheduler=sch)
     lat, eps = pipe.denoise(seeded_randn((1, 4, 8, 16, 16), 5).to(DEV), seeded_randn((1, 4, 16, 16), 3), seeded_randn((2, 5, 32), 2),
                             appearance_encoder=ref, num_inference_steps=3, guidance_scale=7.5, context_frames=4,
-                            context_stride=1, context_overlap=2, seed=0, return_eps=True)
+                            context_stride=1, context_overlap=2, seed=0, return_eps=True, use_graphs=graphs)
     for i in range(3):
         torch.testing.assert_close(eps[i].cpu(), g[f"{kind}/eps{i}"], rtol=2e-3, atol=2e-4)
     torch.testing.assert_close(lat.cpu(), g[f"{kind}/latents"], rtol=2e-3, atol=2e-4)
