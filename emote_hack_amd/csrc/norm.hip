@@ -15,7 +15,7 @@ static constexpr int GN_MAXJ = 3;  // column vectors per thread: C <= 256*3*VEC
 
 static inline int gn_nsplit(int64_t S) {
   int64_t n = (S + 15) / 16;
-  if (n > 256) n = 256;
+  if (n > 1024) n = 1024;
   if (n < 1) n = 1;
   return (int)n;
 }
@@ -46,7 +46,27 @@ __global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(const T* __restr
     RP = GN_THREADS / CV;
     const int r = tid / CV, cv = tid % CV;
     if (r < RP) {
-      for (int64_t s = s0 + r; s < s1; s += RP) {
+      int64_t s = s0 + r;
+      for (; s + 3 * RP < s1; s += 4 * RP) {   // 4 independent 16-byte loads in flight per thread
+        uint4 v0 = *(const uint4*)(base + s * ldx + cv * V);
+        uint4 v1 = *(const uint4*)(base + (s + RP) * ldx + cv * V);
+        uint4 v2 = *(const uint4*)(base + (s + 2 * RP) * ldx + cv * V);
+        uint4 v3 = *(const uint4*)(base + (s + 3 * RP) * ldx + cv * V);
+        float f[V];
+        unpack16<T>(v0, f);
+#pragma unroll
+        for (int e = 0; e < V; e++) { sum[0][e] += f[e]; sq[0][e] += f[e] * f[e]; }
+        unpack16<T>(v1, f);
+#pragma unroll
+        for (int e = 0; e < V; e++) { sum[0][e] += f[e]; sq[0][e] += f[e] * f[e]; }
+        unpack16<T>(v2, f);
+#pragma unroll
+        for (int e = 0; e < V; e++) { sum[0][e] += f[e]; sq[0][e] += f[e] * f[e]; }
+        unpack16<T>(v3, f);
+#pragma unroll
+        for (int e = 0; e < V; e++) { sum[0][e] += f[e]; sq[0][e] += f[e] * f[e]; }
+      }
+      for (; s < s1; s += RP) {
         float f[V];
         unpack16<T>(*(const uint4*)(base + s * ldx + cv * V), f);
 #pragma unroll
@@ -137,7 +157,22 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
       float mean = st[2 * g], rstd = st[2 * g + 1];
       a[e] = rstd * gamma[c]; b[e] = beta[c] - mean * a[e];
     }
-    for (int64_t s = s0 + r; s < s1; s += RP) {
+    int64_t s = s0 + r;
+    for (; s + RP < s1; s += 2 * RP) {   // 2 rows in flight per thread
+      uint4 v0 = *(const uint4*)(xb + s * ldx + cv * V);
+      uint4 v1 = *(const uint4*)(xb + (s + RP) * ldx + cv * V);
+      float f[V], h[V];
+      unpack16<T>(v0, f);
+      unpack16<T>(v1, h);
+#pragma unroll
+      for (int e = 0; e < V; e++) {
+        float v = f[e] * a[e] + b[e]; f[e] = silu ? silu_f(v) : v;
+        float u = h[e] * a[e] + b[e]; h[e] = silu ? silu_f(u) : u;
+      }
+      *(uint4*)(yb + s * ldy + cv * V) = pack16<T>(f);
+      *(uint4*)(yb + (s + RP) * ldy + cv * V) = pack16<T>(h);
+    }
+    for (; s < s1; s += RP) {
       float f[V];
       unpack16<T>(*(const uint4*)(xb + s * ldx + cv * V), f);
 #pragma unroll
