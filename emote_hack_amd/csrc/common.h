@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <type_traits>
+#include <utility>
 #include "../../include/emo_hip.h"
 
 typedef unsigned short bf16_t;  // raw bfloat16 bits
@@ -108,5 +110,12 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [0, N) - keeps every array index a constant
+// expression (runtime-indexed register arrays are demoted to scratch memory by hipcc)
+template <int... Is, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f)); }
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

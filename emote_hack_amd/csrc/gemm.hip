@@ -11,15 +11,18 @@
 // Structure (v3):
 //   * block = 4 waves; a wave owns WTM x WTN MFMA 32x32 tiles: 2x2 waves of 64x64 (BM=BN=128) or 4x1 waves of
 //     32x160 (BM=128, BN=160: every channel count of the SD-1.5 UNet is a multiple of 160, so N=320 is two
-//     full tiles instead of 2.5 of 128).
-//   * K is streamed in 64-BYTE stages (bf16: 32, f32: 16 k-values) through a 4-deep LDS ring filled by
-//     ASYNCHRONOUS direct-to-LDS loads (global_load_lds_dwordx4, no VGPR round trip): three stages are in
-//     flight while the fourth is consumed, `s_waitcnt vmcnt(N)` is COUNTED (never 0 in steady state) and there
-//     is one raw s_barrier per stage.  The HBM-bound level-0 GEMMs (K = 320) need that many bytes in flight;
-//     the compute-bound ones get their MFMAs fed without a drain per stage.
-//   * the LDS image of a stage is lane-linear (a glds writes wave-base + lane*16), rows are 64 B, so the
-//     16-byte chunk position is XOR-swizzled with (row>>2)&3 on the SOURCE address and on the fragment read:
-//     the ds_read_b128 of a 16-lane group then hits 16 distinct 16-byte slots (conflict-free).
+//     full tiles instead of 2.5 of 128), or 2x4 = 8 waves of 128x64 (256x256) for the big compute-bound shapes.
+//   * K is streamed in 128-BYTE stages (bf16: 64, f32: 32 k-values; one full L2 line per row per stage - with
+//     64-byte rows every L2 request used half a line and the 128x128 tile sat on the L2 request rate) through an LDS
+//     ring filled by ASYNCHRONOUS direct-to-LDS loads (global_load_lds_dwordx4, no VGPR round trip), counted
+//     `s_waitcnt vmcnt`, one raw s_barrier per stage.
+//   * software-pipelined stage: after the barrier only the first k-step's fragment read is exposed; the reads of
+//     step kk+1 and the next stage's glds (with their address arithmetic) are issued one at a time BETWEEN the MFMAs
+//     of step kk (compile-time `static_for` so every register-array index is a constant: a runtime index sends the
+//     arrays to scratch and breaks the asm-read/wait protocol).
+//   * the LDS image of a stage is lane-linear (a glds writes wave-base + lane*16), so the 16-byte chunk position is
+//     XOR-swizzled with (row / rows-per-bank-row) on the SOURCE address and on the fragment read: the ds_read_b128 of
+//     a 16-lane group then hits 16 distinct 16-byte slots (conflict-free, SQ_LDS_BANK_CONFLICT = 0 measured).
 //   * fragment reads are inline-asm ds_read_b128 with hand-counted lgkmcnt: hipcc drains vmcnt(0) in front of
 //     every C++-level LDS read while a glds is in flight, which would serialise the ring.
 //   * out-of-range rows / K tails / conv zero padding source a 16-byte zero page instead of branching.
@@ -34,7 +37,17 @@
 // Split-K (small M): f32 partial slabs + a fixed-order reduce/epilogue kernel (deterministic).
 #include "common.h"
 
-static constexpr int KBYTES = 64;
+#ifndef EMO_GEMM_KBYTES
+#define EMO_GEMM_KBYTES 128
+#endif
+static constexpr int KBYTES = EMO_GEMM_KBYTES;   // bytes of K per ring stage and per LDS row (128 = one full L2 line per row)
+static constexpr int CPR = KBYTES / 16;          // 16-byte chunks per LDS row
+static constexpr int KSTEPS = KBYTES / 32;       // mma16 steps per stage (a step consumes 2 chunks: one per lane half)
+static constexpr int RPB = 256 / KBYTES;         // LDS rows per 256-byte bank row
+// XOR swizzle of the chunk position: rows that share a 256-B bank row get the same key, consecutive bank rows
+// different keys -> the 16 lanes of a ds_read_b128 group (rows {0-3,12-15,20-27} / {4-11,16-19,28-31}) hit 16
+// distinct 16-byte slots
+__device__ __forceinline__ int swz(int row) { return (row / RPB) & (CPR - 1); }
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0, 0, 0, 0};
 
@@ -42,7 +55,7 @@ template <int WTM, int WTN, int WVM, int WVN, int NS_> struct GemmTile {
   static constexpr int NS = NS_;   // LDS ring depth
   static constexpr int NW = WVM * WVN, THREADS = 64 * NW;
   static constexpr int BM = 32 * WTM * WVM, BN = 32 * WTN * WVN;
-  static constexpr int RPI = 16 * NW;   // LDS rows filled by one glds "round" of the whole block
+  static constexpr int RPI = 64 * NW / CPR;   // LDS rows filled by one glds "round" of the whole block
   static constexpr int A_ROWS = (BM + RPI - 1) / RPI * RPI, B_ROWS = (BN + RPI - 1) / RPI * RPI;
   static constexpr int A_BYTES = A_ROWS * KBYTES, B_BYTES = B_ROWS * KBYTES;
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
@@ -94,15 +107,15 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
 
   // ---- loader geometry: glds #i of this wave fills LDS rows (i*4 + wave)*16 .. +16 of the operand; lane l
   // writes physical chunk (l&3) of row (l>>2), which holds LOGICAL chunk (l&3) ^ ((row>>2)&3)
-  const int lrow = lane >> 2;
+  const int lrow = lane / CPR, lchunk = lane % CPR;
   int a_klog[LA];
   const T* a_base[LA];    // dense: row pointer (k added per stage); conv: unused
   ConvRow a_cr[LA];
   bool a_ok[LA];
 #pragma unroll
   for (int i = 0; i < LA; i++) {
-    const int row = (i * NW + wave) * 16 + lrow;
-    a_klog[i] = (lane & 3) ^ ((row >> 2) & 3);
+    const int row = (i * NW + wave) * (64 / CPR) + lrow;
+    a_klog[i] = lchunk ^ swz(row);
     const int64_t m = bm + row;
     a_ok[i] = row < BM && m < p.M;
     a_base[i] = A + (a_ok[i] ? m : 0) * p.lda;
@@ -119,8 +132,8 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
   int b_inc[LB];
 #pragma unroll
   for (int i = 0; i < LB; i++) {
-    const int row = (i * NW + wave) * 16 + lrow;
-    b_klog[i] = (lane & 3) ^ ((row >> 2) & 3);
+    const int row = (i * NW + wave) * (64 / CPR) + lrow;
+    b_klog[i] = lchunk ^ swz(row);
     const int n = bn + row;
     const bool ok = row < BN && n < p.N;
     b_ptr[i] = ok ? W + (int64_t)n * p.K + b_klog[i] * V : zero;
@@ -136,45 +149,44 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
   const bool k_ragged = (p.K % BK) != 0;            // only the very last stage can run past K
   const bool cin_aligned = CONV && (p.Cin % BK) == 0; // a stage then lies inside one 3x3 tap (tap is wave-uniform)
 
-  auto issue = [&](int kt, int slot) {   // kt: absolute k-stage index; called with kt increasing by 1
+  // one glds of operand A (index i < LA) / B (i < LB) of k-stage kt into ring slot `slot`; stages are issued in order
+  auto issue_a = [&](int kt, int slot, auto I) {
+    constexpr int i = decltype(I)::value;
     unsigned char* sa = lds + slot * Tile::STAGE_BYTES;
-    unsigned char* sb = sa + Tile::A_BYTES;
     const bool tail = k_ragged && (kt + 1) * BK > p.K;
     if constexpr (!CONV) {
-#pragma unroll
-      for (int i = 0; i < LA; i++) {
-        const T* src = a_ptr[i];
-        if (tail && kt * BK + a_klog[i] * V >= p.K) src = zero;
-        EMO_GLDS16(src, sa + (i * NW + wave) * 1024);
-        a_ptr[i] += a_inc[i];
-      }
+      const T* src = a_ptr[i];
+      if (tail && kt * BK + a_klog[i] * V >= p.K) src = zero;
+      EMO_GLDS16(src, sa + (i * NW + wave) * 1024);
+      a_ptr[i] += a_inc[i];
     } else {
-      int tap_u = 0, ci_u = 0;
-      if (cin_aligned) { tap_u = (kt * BK) / p.Cin; ci_u = kt * BK - tap_u * p.Cin; }
       const int Hin = p.upsample2x ? 2 * p.H : p.H, Win = p.upsample2x ? 2 * p.W_ : p.W_;
-#pragma unroll
-      for (int i = 0; i < LA; i++) {
-        const int k0 = kt * BK + a_klog[i] * V;
-        int tap, ci;
-        if (cin_aligned) { tap = tap_u; ci = ci_u + a_klog[i] * V; }
-        else { tap = k0 / p.Cin; ci = k0 - tap * p.Cin; }
-        const int ky = tap / 3, kx = tap - ky * 3;
-        int iy = a_cr[i].iy0 + ky, ix = a_cr[i].ix0 + kx;
-        const T* src = zero;
-        if (a_ok[i] && k0 < p.K && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
-          if (p.upsample2x) { iy >>= 1; ix >>= 1; }
-          src = A + (((int64_t)a_cr[i].img * p.H + iy) * p.W_ + ix) * p.lda + ci;
-        }
-        EMO_GLDS16(src, sa + (i * NW + wave) * 1024);
+      const int k0 = kt * BK + a_klog[i] * V;
+      int tap, ci;
+      if (cin_aligned) { tap = (kt * BK) / p.Cin; ci = kt * BK - tap * p.Cin + a_klog[i] * V; }   // tap is wave-uniform (SALU)
+      else { tap = k0 / p.Cin; ci = k0 - tap * p.Cin; }
+      const int ky = tap / 3, kx = tap - ky * 3;
+      int iy = a_cr[i].iy0 + ky, ix = a_cr[i].ix0 + kx;
+      const T* src = zero;
+      if (a_ok[i] && k0 < p.K && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
+        if (p.upsample2x) { iy >>= 1; ix >>= 1; }
+        src = A + (((int64_t)a_cr[i].img * p.H + iy) * p.W_ + ix) * p.lda + ci;
       }
+      EMO_GLDS16(src, sa + (i * NW + wave) * 1024);
     }
-#pragma unroll
-    for (int i = 0; i < LB; i++) {
-      const T* src = b_ptr[i];
-      if (tail && kt * BK + b_klog[i] * V >= p.K) src = zero;
-      EMO_GLDS16(src, sb + (i * NW + wave) * 1024);
-      b_ptr[i] += b_inc[i];
-    }
+  };
+  auto issue_b = [&](int kt, int slot, auto I) {
+    constexpr int i = decltype(I)::value;
+    unsigned char* sb = lds + slot * Tile::STAGE_BYTES + Tile::A_BYTES;
+    const bool tail = k_ragged && (kt + 1) * BK > p.K;
+    const T* src = b_ptr[i];
+    if (tail && kt * BK + b_klog[i] * V >= p.K) src = zero;
+    EMO_GLDS16(src, sb + (i * NW + wave) * 1024);
+    b_ptr[i] += b_inc[i];
+  };
+  auto issue = [&](int kt, int slot) {
+    static_for<LA>([&](auto I) { issue_a(kt, slot, I); });
+    static_for<LB>([&](auto I) { issue_b(kt, slot, I); });
   };
 
   f32x16 acc[WTM][WTN];
@@ -192,18 +204,18 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
 
   // fragment read addresses (LDS byte offsets, stage-relative), swizzled
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-  unsigned fa_off[WTM][2], fb_off[WTN][2];
+  unsigned fa_off[WTM][KSTEPS], fb_off[WTN][KSTEPS];
 #pragma unroll
   for (int i = 0; i < WTM; i++) {
     const int r = wvm * 32 * WTM + i * 32 + l31;
 #pragma unroll
-    for (int kk = 0; kk < 2; kk++) fa_off[i][kk] = r * KBYTES + (((kk * 2 + half) ^ ((r >> 2) & 3)) * 16);
+    for (int kk = 0; kk < KSTEPS; kk++) fa_off[i][kk] = r * KBYTES + (((kk * 2 + half) ^ swz(r)) * 16);
   }
 #pragma unroll
   for (int j = 0; j < WTN; j++) {
     const int r = wvn * 32 * WTN + j * 32 + l31;
 #pragma unroll
-    for (int kk = 0; kk < 2; kk++) fb_off[j][kk] = Tile::A_BYTES + r * KBYTES + (((kk * 2 + half) ^ ((r >> 2) & 3)) * 16);
+    for (int kk = 0; kk < KSTEPS; kk++) fb_off[j][kk] = Tile::A_BYTES + r * KBYTES + (((kk * 2 + half) ^ swz(r)) * 16);
   }
 
   if (kt0 > 0) {   // split-K slice: start the incremental pointers at this slice's first stage
@@ -219,45 +231,59 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
     // stage kt must have landed; up to min(NS-2, nk-1-kt) younger stages may still be in flight
     const int rem = nk - 1 - kt;
     if (rem >= NS - 2) wait_vmcnt<(NS - 2) * LPS>();
-    else if (NS > 3 && rem == 1) wait_vmcnt<LPS>();
+    else if (NS > 3 && rem >= 1) {   // draining: rem younger stages in flight
+      if (rem == 1) wait_vmcnt<LPS>();
+      else if (NS > 4 && rem == 2) wait_vmcnt<2 * LPS>();
+      else if (NS > 5 && rem == 3) wait_vmcnt<3 * LPS>();
+      else if (NS > 6 && rem == 4) wait_vmcnt<4 * LPS>();
+      else if (NS > 7 && rem == 5) wait_vmcnt<5 * LPS>();
+      else wait_vmcnt<0>();
+    }
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // everyone's part of stage kt landed; everyone finished reading slot (kt-1)%NS
-    // dense: issue the next stage's loads right after the barrier; conv: after the first MFMA cluster (its
-    // per-lane address arithmetic then overlaps the matrix pipe: +8 % on the 3x3 convs, neutral for dense)
-    if constexpr (!CONV) {
-      if (kt + NS - 1 < nk) issue(kt0 + kt + NS - 1, (kt + NS - 1) % NS);
-    }
     const unsigned st = lds_base + (kt % NS) * Tile::STAGE_BYTES;
+    const bool more = kt + NS - 1 < nk;
+    const int kt_next = kt0 + kt + NS - 1, slot_next = (kt + NS - 1) % NS;
+    // Software-pipelined stage: the only exposed latency is the first k-step's fragment read.  The fragment reads
+    // of step kk+1 and the next ring stage's glds (with their address arithmetic) are issued one at a time BETWEEN the
+    // MFMAs of step kk, so their issue cost and latency hide under the matrix pipe.
     uint4 fa[2][WTM], fb[2][WTN];
 #pragma unroll
-    for (int kk = 0; kk < 2; kk++) {
+    for (int i = 0; i < WTM; i++) fa[0][i] = lds_read16(st + fa_off[i][0]);
 #pragma unroll
-      for (int i = 0; i < WTM; i++) fa[kk][i] = lds_read16(st + fa_off[i][kk]);
-#pragma unroll
-      for (int j = 0; j < WTN; j++) fb[kk][j] = lds_read16(st + fb_off[j][kk]);
-    }
-    wait_lgkmcnt<WTM + WTN>();            // the kk=0 fragments
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < WTM; i++)
-#pragma unroll
-      for (int j = 0; j < WTN; j++) {
-        if constexpr (TRANS) acc[i][j] = mma16<T>(fa[0][i], fb[0][j], acc[i][j]);   // rows = m, lane = n
-        else acc[i][j] = mma16<T>(fb[0][j], fa[0][i], acc[i][j]);                   // rows = n, lane = m
-      }
-    if constexpr (CONV) {
+    for (int j = 0; j < WTN; j++) fb[0][j] = lds_read16(st + fb_off[j][0]);
+    constexpr int NMMA = WTM * WTN, NRD = WTM + WTN;
+    static_for<KSTEPS>([&](auto KK) {
+      constexpr int kk = decltype(KK)::value, cur = kk & 1, nxt = cur ^ 1;
+      wait_lgkmcnt<0>();                       // fragments of step kk
       __builtin_amdgcn_sched_barrier(0);
-      if (kt + NS - 1 < nk) issue(kt0 + kt + NS - 1, (kt + NS - 1) % NS);
-    }
-    wait_lgkmcnt<0>();
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < WTM; i++)
-#pragma unroll
-      for (int j = 0; j < WTN; j++) {
-        if constexpr (TRANS) acc[i][j] = mma16<T>(fa[1][i], fb[1][j], acc[i][j]);
-        else acc[i][j] = mma16<T>(fb[1][j], fa[1][i], acc[i][j]);
-      }
+      // side ops of this cluster: the next step's fragment reads, then this cluster's share of the glds
+      constexpr int n_rd = (kk + 1 < KSTEPS) ? NRD : 0;
+      constexpr int g_begin = kk * LPS / KSTEPS, g_end = (kk + 1) * LPS / KSTEPS;
+      constexpr int n_side = n_rd + (g_end - g_begin);
+      static_for<NMMA>([&](auto Q) {
+        constexpr int q = decltype(Q)::value, i = q / WTN, j = q % WTN;
+        if constexpr (TRANS) acc[i][j] = mma16<T>(fa[cur][i], fb[cur][j], acc[i][j]);   // rows = m, lane = n
+        else acc[i][j] = mma16<T>(fb[cur][j], fa[cur][i], acc[i][j]);                   // rows = n, lane = m
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<n_side>([&](auto O) {
+          constexpr int o = decltype(O)::value;
+          if constexpr ((o * NMMA) / n_side == q) {
+            if constexpr (o < n_rd) {
+              if constexpr (o < WTM) fa[nxt][o] = lds_read16(st + fa_off[o][(kk + 1) % KSTEPS]);
+              else fb[nxt][o - WTM] = lds_read16(st + fb_off[o - WTM][(kk + 1) % KSTEPS]);
+            } else {
+              constexpr int g = g_begin + (o - n_rd);
+              if (more) {
+                if constexpr (g < LA) issue_a(kt_next, slot_next, std::integral_constant<int, g>{});
+                else issue_b(kt_next, slot_next, std::integral_constant<int, g - LA>{});
+              }
+            }
+          }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
   }
 
   T* __restrict__ C = (T*)p.C;
@@ -427,12 +453,12 @@ static GemmPlan plan_gemm(int64_t M, int N, int K, int dtype, int geglu) {
   pl.nt5 = (!pl.big && !geglu && N % 160 == 0) ? 1 : 0;
   const int bn = pl.nt5 ? 160 : 128;
   const int64_t tiles = ((M + 127) / 128) * ((N + bn - 1) / bn);
-  const int bk = dtype == EMO_F32 ? 16 : 32;
+  const int bk = KBYTES / (dtype == EMO_F32 ? 4 : 2);
   const int nk = (K + bk - 1) / bk;
   int s = 1;
-  if (tiles < 192 && nk >= 16 && N % 4 == 0) {
+  if (tiles < 192 && nk >= 8 && N % 4 == 0) {
     s = (int)((512 + tiles - 1) / tiles);        // aim at ~2 blocks per CU
-    const int max_by_k = nk / 8;                  // keep >= 8 k-steps per slice
+    const int max_by_k = nk / 4;                  // keep >= 4 stages per slice
     if (s > max_by_k) s = max_by_k;
     if (s > 32) s = 32;
     if (s < 2) s = 1;
@@ -469,9 +495,15 @@ static int launch_gemm(const emo_gemm_params& p, int S, hipStream_t st) {
 template <typename T, bool CONV, bool TRANS>
 static int dispatch_tile(const emo_gemm_params& p, const GemmPlan& pl, int S, hipStream_t st) {
   // (4-wave 128x256 / 256x128 tiles were measured 15-35 % slower than the 8-wave 256x256 at equal LDS traffic per MFMA)
-  if (pl.big && S == 1) return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, 4>(p, S, st);   // 2x4 waves of 128x64, 4 x 32 KB ring
-  if (pl.nt5) return launch_gemm<T, CONV, TRANS, 1, 5, 4, 1, 3>(p, S, st);   // 4x1 waves of 32x160, 3 x 20 KB ring
-  return launch_gemm<T, CONV, TRANS, 2, 2, 2, 2, 4>(p, S, st);               // 2x2 waves of 64x64, 4 x 16 KB ring
+#ifdef EMO_FORCE22
+  return launch_gemm<T, CONV, TRANS, 2, 2, 2, 2, EMO_NS22>(p, S, st);
+#endif
+  if (pl.big && S == 1) return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, 2>(p, S, st);   // 2x4 waves of 128x64, 2 x 64 KB ring
+  if (pl.nt5) return launch_gemm<T, CONV, TRANS, 1, 5, 4, 1, 2>(p, S, st);   // 4x1 waves of 32x160, 2 x 36 KB ring
+#ifndef EMO_NS22
+#define EMO_NS22 2
+#endif
+  return launch_gemm<T, CONV, TRANS, 2, 2, 2, 2, EMO_NS22>(p, S, st);               // 2x2 waves of 64x64, 4 x 16 KB ring
 }
 
 template <typename T>
