@@ -50,8 +50,8 @@ __device__ __forceinline__ uint4 lds_read16(unsigned addr) {
 }
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
-// G = glds per wave per tile, NSR = ring depth
-template <typename T, int DCH, int G, int NSR>
+// G = glds per wave per tile, NSR = ring depth, QT = 32-query tiles per wave (2 halves the LDS fragment traffic per MFMA)
+template <typename T, int DCH, int G, int NSR, int QT>
 __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attention_params p, int stage_bytes) {
   using Cfg = AttCfg<T, DCH>;
   constexpr int V = Cfg::V, NT = Cfg::NT, KROW = Cfg::KROW, VROW = Cfg::VROW, STEPS = Cfg::STEPS;
@@ -69,15 +69,21 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attent
   // ---- zero the whole ring once: V^T pad rows (n >= d) are never written by the loader and must be 0
   for (int i = tid * 16; i < NSR * stage_bytes; i += ATT_THREADS * 16) *(uint4*)(smem + i) = make_uint4(0, 0, 0, 0);
 
-  // ---- Q fragments: row q, chunks (2*kk + half)
-  const int q = qt * BQ + wave * 32 + l31;
-  const bool q_ok = q < p.Lq;
-  const T* qrow = (const T*)p.q + ((int64_t)b * p.Lq + (q_ok ? q : 0)) * p.ldq + head * d;
-  uint4 qf[DCH / 2];
+  // ---- Q fragments: QT tiles of 32 query rows per wave; row q, chunks (2*kk + half)
+  constexpr int BQW = 32 * QT;              // query rows per wave
+  int qrow_idx[QT];
+  bool q_ok[QT];
+  uint4 qf[QT][DCH / 2];
 #pragma unroll
-  for (int kk = 0; kk < DCH / 2; kk++) {
-    const int c = 2 * kk + half;
-    qf[kk] = (q_ok && c < dch_real) ? *(const uint4*)(qrow + c * V) : make_uint4(0, 0, 0, 0);
+  for (int t = 0; t < QT; t++) {
+    qrow_idx[t] = qt * (4 * BQW) + wave * BQW + t * 32 + l31;
+    q_ok[t] = qrow_idx[t] < p.Lq;
+    const T* qrow = (const T*)p.q + ((int64_t)b * p.Lq + (q_ok[t] ? qrow_idx[t] : 0)) * p.ldq + head * d;
+#pragma unroll
+    for (int kk = 0; kk < DCH / 2; kk++) {
+      const int c = 2 * kk + half;
+      qf[t][kk] = (q_ok[t] && c < dch_real) ? *(const uint4*)(qrow + c * V) : make_uint4(0, 0, 0, 0);
+    }
   }
 
   // ---- loader geometry: glds #g of this wave writes LDS chunk positions (g*4 + wave)*64 + lane of the stage
@@ -130,12 +136,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attent
     }
   };
 
-  f32x16 o[NT];
+  f32x16 o[QT][NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; nt++)
+  for (int t = 0; t < QT; t++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) o[nt][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) o[t][nt][r] = 0.f;
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int t = 0; t < QT; t++) { m_run[t] = -1e30f; l_run[t] = 0.f; }
   const float c_exp = p.scale * 1.4426950408889634f;
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
@@ -178,105 +188,126 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attent
       __syncthreads();
     }
 
+    // The whole 64-key tile is processed at once: S^T for both 32-key sub-tiles, ONE online-softmax update per query
+    // row per tile (half the max/rescale work of per-sub-tile updates), then O^T += V^T P^T.  K and V^T fragments are
+    // read once per wave and reused for the QT query tiles.
+    const bool two = k0 + 32 < Lk;                 // second sub-tile has at least one valid key (wave-uniform)
+    uint4 kf[2][DCH / 2];
 #pragma unroll
     for (int st = 0; st < 2; st++) {
-      if (k0 + st * 32 >= Lk) break;
-      // ---- fragment reads: K rows for S^T, V^T rows for the PV of this sub-tile (issued early)
-      uint4 kf[DCH / 2];
       const unsigned krow = ks_base + (st * 32 + l31) * KROW + half * 16;
 #pragma unroll
-      for (int kk = 0; kk < DCH / 2; kk++) kf[kk] = lds_read16(krow + kk * 32);
-      uint4 vf[STEPS][NT];
-      constexpr bool V_EARLY = STEPS * NT <= 15;   // lgkmcnt is a 4-bit counter
-      auto read_v = [&]() {
+      for (int kk = 0; kk < DCH / 2; kk++) kf[st][kk] = lds_read16(krow + kk * 32);
+    }
+    wait_lgkmcnt<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 pf[QT][2][STEPS];                        // P^T fragments (B operand of the PV MFMAs)
 #pragma unroll
-        for (int sp = 0; sp < STEPS; sp++) {
-          const int r0 = sp * V;
-          const int key_off = st * 32 + 16 * (r0 >> 3) + 8 * half + (r0 & 7);
+    for (int t = 0; t < QT; t++) {
+      f32x16 s0, s1;
 #pragma unroll
-          for (int nt = 0; nt < NT; nt++) vf[sp][nt] = lds_read16(vs_base + (nt * 32 + l31) * VROW + key_off * (int)sizeof(T));
-        }
-      };
-      if constexpr (V_EARLY) {
-        read_v();                     // in flight under the S^T MFMAs and the softmax
-        wait_lgkmcnt<STEPS * NT>();   // the K fragments
-      } else {
-        wait_lgkmcnt<0>();
+      for (int r = 0; r < 16; r++) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < DCH / 2; kk++) s0 = mma16<T>(kf[0][kk], qf[t][kk], s0);
+      if (two) {
+#pragma unroll
+        for (int kk = 0; kk < DCH / 2; kk++) s1 = mma16<T>(kf[1][kk], qf[t][kk], s1);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      f32x16 s;
-#pragma unroll
-      for (int r = 0; r < 16; r++) s[r] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < DCH / 2; kk++) s = mma16<T>(kf[kk], qf[kk], s);
-      // ---- online softmax (lane-local query; the other half of the keys lives in lane^32)
-      if (k0 + st * 32 + 32 > Lk) {   // ragged last sub-tile only (wave-uniform)
+      if (k0 + TK > Lk) {   // ragged last tile only (wave-uniform): mask keys >= Lk
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          const int key = k0 + st * 32 + 16 * (r >> 3) + 8 * half + (r & 7);
-          if (key >= Lk) s[r] = -1e30f;
+          const int key = k0 + 16 * (r >> 3) + 8 * half + (r & 7);
+          if (key >= Lk) s0[r] = -1e30f;
+          if (key + 32 >= Lk) s1[r] = -1e30f;
         }
       }
-      float mx = s[0];
+      float mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
-      for (int r = 1; r < 16; r++) mx = fmaxf(mx, s[r]);
+      for (int r = 1; r < 16; r++) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = exp2f((m_run - m_new) * c_exp);
-      m_run = m_new;
+      const float m_new = fmaxf(m_run[t], mx);
+      const float alpha = exp2f((m_run[t] - m_new) * c_exp);
+      m_run[t] = m_new;
       const float m_sc = m_new * c_exp;
       float psum = 0.f;
-      float pr[16];
+      float p0[16], p1[16];
 #pragma unroll
-      for (int r = 0; r < 16; r++) { pr[r] = exp2f(s[r] * c_exp - m_sc); psum += pr[r]; }
-      l_run = l_run * alpha + psum;
+      for (int r = 0; r < 16; r++) {
+        p0[r] = exp2f(s0[r] * c_exp - m_sc);
+        p1[r] = exp2f(s1[r] * c_exp - m_sc);
+        psum += p0[r] + p1[r];
+      }
+      l_run[t] = l_run[t] * alpha + psum;
       if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // skip the O rescale when no lane's max moved
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-          for (int r = 0; r < 16; r++) o[nt][r] *= alpha;
+          for (int r = 0; r < 16; r++) o[t][nt][r] *= alpha;
       }
-      // ---- O^T += V^T . P^T
-      if constexpr (!V_EARLY) read_v();
-      wait_lgkmcnt<0>();
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int sp = 0; sp < STEPS; sp++) {
         const int r0 = sp * V;
-        uint4 pf;
         if constexpr (sizeof(T) == 2) {
-          pf = make_uint4(pack_bf2(pr[r0], pr[r0 + 1]), pack_bf2(pr[r0 + 2], pr[r0 + 3]), pack_bf2(pr[r0 + 4], pr[r0 + 5]),
-                          pack_bf2(pr[r0 + 6], pr[r0 + 7]));
+          pf[t][0][sp] = make_uint4(pack_bf2(p0[r0], p0[r0 + 1]), pack_bf2(p0[r0 + 2], p0[r0 + 3]), pack_bf2(p0[r0 + 4], p0[r0 + 5]),
+                                    pack_bf2(p0[r0 + 6], p0[r0 + 7]));
+          pf[t][1][sp] = make_uint4(pack_bf2(p1[r0], p1[r0 + 1]), pack_bf2(p1[r0 + 2], p1[r0 + 3]), pack_bf2(p1[r0 + 4], p1[r0 + 5]),
+                                    pack_bf2(p1[r0 + 6], p1[r0 + 7]));
         } else {
-          pf = make_uint4(__float_as_uint(pr[r0]), __float_as_uint(pr[r0 + 1]), __float_as_uint(pr[r0 + 2]),
-                          __float_as_uint(pr[r0 + 3]));
+          pf[t][0][sp] = make_uint4(__float_as_uint(p0[r0]), __float_as_uint(p0[r0 + 1]), __float_as_uint(p0[r0 + 2]), __float_as_uint(p0[r0 + 3]));
+          pf[t][1][sp] = make_uint4(__float_as_uint(p1[r0]), __float_as_uint(p1[r0 + 1]), __float_as_uint(p1[r0 + 2]), __float_as_uint(p1[r0 + 3]));
         }
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) o[nt] = mma16<T>(vf[sp][nt], pf, o[nt]);
       }
+    }
+    // ---- O^T += V^T . P^T : per sub-tile the V^T fragments are read once and feed the QT query tiles
+#pragma unroll
+    for (int st = 0; st < 2; st++) {
+      if (st == 1 && !two) break;
+      uint4 vf[STEPS][NT];
+#pragma unroll
+      for (int sp = 0; sp < STEPS; sp++) {
+        const int r0 = sp * V;
+        const int key_off = st * 32 + 16 * (r0 >> 3) + 8 * half + (r0 & 7);
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) vf[sp][nt] = lds_read16(vs_base + (nt * 32 + l31) * VROW + key_off * (int)sizeof(T));
+        if constexpr (STEPS * NT > 15) {           // lgkmcnt is a 4-bit counter: drain per step for the widest heads
+          wait_lgkmcnt<0>();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      wait_lgkmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int sp = 0; sp < STEPS; sp++)
+#pragma unroll
+        for (int t = 0; t < QT; t++)
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++) o[t][nt] = mma16<T>(vf[sp][nt], pf[t][st][sp], o[t][nt]);
     }
     if constexpr (NSR == 1) __builtin_amdgcn_s_barrier();   // synchronous ring: nobody may still read slot 0
   }
 
   // ---- normalise and store: lane holds O[q][n], n = nt*32 + 8*(r>>2) + 4*half + (r&3)
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  if (q_ok) {
-    T* orow = (T*)p.out + ((int64_t)b * p.Lq + q) * p.ldo + head * d;
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++)
+  for (int t = 0; t < QT; t++) {
+    const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_ok[t]) {
+      T* orow = (T*)p.out + ((int64_t)b * p.Lq + qrow_idx[t]) * p.ldo + head * d;
 #pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int n0 = nt * 32 + 8 * g + 4 * half;
-        if (n0 < d) {
-          float v0 = o[nt][4 * g] * inv, v1 = o[nt][4 * g + 1] * inv, v2 = o[nt][4 * g + 2] * inv, v3 = o[nt][4 * g + 3] * inv;
-          if constexpr (sizeof(T) == 2) {
-            *(uint2*)(orow + n0) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
-          } else {
-            *(float4*)(orow + n0) = make_float4(v0, v1, v2, v3);
+      for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int n0 = nt * 32 + 8 * g + 4 * half;
+          if (n0 < d) {
+            float v0 = o[t][nt][4 * g] * inv, v1 = o[t][nt][4 * g + 1] * inv, v2 = o[t][nt][4 * g + 2] * inv, v3 = o[t][nt][4 * g + 3] * inv;
+            if constexpr (sizeof(T) == 2) {
+              *(uint2*)(orow + n0) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
+            } else {
+              *(float4*)(orow + n0) = make_float4(v0, v1, v2, v3);
+            }
           }
         }
-      }
+    }
   }
 }
 
@@ -291,10 +322,10 @@ struct AttLaunch {
   static_assert(NSR * STAGE_BYTES <= 160 * 1024, "attention stage does not fit LDS");
 };
 
-template <typename T, int DCH, int G>
-static int launch_attention2(const emo_attention_params& p, hipStream_t st) {
+template <typename T, int DCH, int G, int QT>
+static int launch_attention3(const emo_attention_params& p, hipStream_t st) {
   using L = AttLaunch<T, DCH, G>;
-  auto kern = attention_kernel<T, DCH, G, L::NSR>;
+  auto kern = attention_kernel<T, DCH, G, L::NSR, QT>;
   constexpr int lds = L::NSR * L::STAGE_BYTES;
   if (lds > 64 * 1024) {
     static bool once = false;  // idempotent attribute; benign race
@@ -304,10 +335,20 @@ static int launch_attention2(const emo_attention_params& p, hipStream_t st) {
       once = true;
     }
   }
-  dim3 grid((p.Lq + BQ - 1) / BQ, p.heads, p.B);
+  dim3 grid((p.Lq + BQ * QT - 1) / (BQ * QT), p.heads, p.B);
   kern<<<grid, ATT_THREADS, lds, st>>>(p, L::STAGE_BYTES);
   EMO_LAUNCH_CHECK();
   return EMO_OK;
+}
+
+template <typename T, int DCH, int G>
+static int launch_attention2(const emo_attention_params& p, hipStream_t st) {
+  // two 32-query tiles per wave (K / V^T fragments reused, half the LDS traffic per MFMA) when the head dim leaves
+  // the registers for it and there are enough query rows to still fill the chip
+  // QT = 2 (two 32-query tiles per wave: K / V^T fragments reused, half the LDS fragment traffic per MFMA) was measured
+  // 1.7x SLOWER at d=40 (201 vs 341 TFLOP/s): 318 registers -> 1 wave per SIMD.  Occupancy beats LDS traffic here,
+  // so every head dim runs one query tile per wave; the QT template parameter stays for a leaner register budget.
+  return launch_attention3<T, DCH, G, 1>(p, st);
 }
 
 // DPREV = chunk count of the next smaller head-dim class: this class serves dch in (DPREV, DCH]
