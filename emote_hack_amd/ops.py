@@ -222,7 +222,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
     if transpose_rows:
         nb = M // transpose_rows
         if out is None:
-            out = torch.zeros(nb, n_out, transpose_ld, device=a.device, dtype=a.dtype)
+            out = torch.empty(nb, n_out, transpose_ld, device=a.device, dtype=a.dtype)   # pad columns [L, ld) are cleaned by the attention loader
         p.transpose_out, p.t_rows, p.t_ld, p.t_batch_stride = 1, transpose_rows, transpose_ld, n_out * transpose_ld
         p.C, p.ldc = out.data_ptr(), 0
     else:

@@ -122,8 +122,12 @@ class EMOAnimationPipeline:
         st.t_table = torch.tensor(st.timesteps, dtype=torch.int64, device=dev)   # INT timestep table, bit-exact
         st.t_buf = torch.zeros(1, dtype=torch.int64, device=dev)
         st.use_graphs, st.graphs, st.graph_pool = bool(use_graphs), {}, None
+        st.overlap, st.side, st.writer_pool, st.unet_state = False, None, None, {}
         if st.use_graphs:
             st.graph_pool = torch.cuda.graph_pool_handle()
+            st.writer_pool = torch.cuda.graph_pool_handle()   # own pool: the write pass may run concurrently with the down path
+            st.overlap = (not st.dist_pre) and fusion_blocks == "midup"
+            st.side = torch.cuda.Stream() if st.overlap else None
         if audio_features is not None:
             audio_features = audio_features.to(dev)
         st.noise_pred = torch.empty(2, st.C4, st.f_tot, st.HW, device=dev, dtype=torch.float32)
@@ -157,21 +161,19 @@ class EMOAnimationPipeline:
     def _part_writer(self, st):
         self._write_banks(st.appearance_encoder, st.writer, st.ref_rep, st.t_buf, st.text)    # :711-716
 
-    def _part_unet(self, st, ci):
-        unet, dev = self.unet, self.unet.device
-        context = st.my_contexts[ci]
+    def _unet_inputs(self, st, ci):
+        dev = self.unet.device
         idx = st.ctx_index[ci]                                                               # device int64 frame indices
         x = torch.cat([st.latents.index_select(2, i) for i in idx]).repeat(2, 1, 1, 1, 1)    # :759-763 (index/copy only)
         x = self.scheduler.scale_model_input(x, None)
-        b = x.shape[0]
-        st.reader.update(st.writer)                                                           # :774
         af = None
         if st.audio_features is not None:   # per-frame audio context; uc rows get a zero context
             cond = torch.cat([st.audio_features.index_select(0, i) for i in idx])
             af = torch.cat([torch.zeros_like(cond), cond])
-        rows = unet(x, st.t_buf, encoder_hidden_states=st.text[:b], audio_features=af, speed_embeddings=st.speed_embeddings,
-                    return_dict=False, _return_rows=True)                                     # :777-786
-        st.reader.clear()                                                                     # :788
+        return x, af
+
+    def _accumulate(self, st, ci, rows):
+        context = st.my_contexts[ci]
         nf = len(context[0])
         for j, c in enumerate(context):                                                       # :790-794
             fr = st.frame_idx[tuple(c)]
@@ -180,7 +182,37 @@ class EMOAnimationPipeline:
                 ops.accumulate_window(rows[bi * nf * st.HW:(bi + 1) * nf * st.HW], st.noise_pred[branch], st.counter, fr,
                                       C_=st.C4, F=st.f_tot, HW=st.HW, add_counter=(branch == 0))
 
-    def _run(self, st, key, fn):
+    def _update_reader(self, st):
+        if st.writer.order and not all(st.writer.bank[p] for p in st.writer.order):
+            raise RuntimeError("ReferenceNet banks are empty at reader.update(): the write pass must run (or be captured) "
+                               "in the same step as its consumer")
+        st.reader.update(st.writer)                                                           # :774
+
+    def _part_unet(self, st, ci):
+        x, af = self._unet_inputs(st, ci)
+        self._update_reader(st)
+        rows = self.unet(x, st.t_buf, encoder_hidden_states=st.text[:x.shape[0]], audio_features=af,
+                         speed_embeddings=st.speed_embeddings, return_dict=False, _return_rows=True)   # :777-786
+        st.reader.clear()                                                                     # :788
+        self._accumulate(st, ci, rows)
+
+    # the same pass split at the first use of the reference banks (fusion 'midup': mid block): the down path does not
+    # depend on the ReferenceNet, so it overlaps the write pass running on a second HIP stream
+    def _part_unet_down(self, st, ci):
+        x, af = self._unet_inputs(st, ci)
+        s = self.unet._begin(x, st.t_buf, st.text[:x.shape[0]], af, st.speed_embeddings)
+        self.unet._run_down(s)
+        st.unet_state[ci] = s
+
+    def _part_unet_rest(self, st, ci):
+        s = st.unet_state[ci]
+        self._update_reader(st)
+        st.reader._prepare(s.c, self.unet)
+        rows = self.unet._run_rest(s, return_rows=True)
+        st.reader.clear()                                                                     # :788
+        self._accumulate(st, ci, rows)
+
+    def _run(self, st, key, fn, pool=None):
         """Eager on first use (warm-up: lazy kernel attributes, allocator), HIP-graph capture on the second, replay after.
         Launch-bound host code (~1700 kernel launches per step from Python) disappears from the critical path."""
         if not st.use_graphs or ops.PROFILER is not None:
@@ -192,7 +224,7 @@ class EMOAnimationPipeline:
             return
         if state == "warm":
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=st.graph_pool):
+            with torch.cuda.graph(g, pool=pool if pool is not None else st.graph_pool):
                 fn()
             st.graphs[key] = g
             state = g
@@ -207,15 +239,36 @@ class EMOAnimationPipeline:
         st.t_buf.copy_(st.t_table[si:si + 1], non_blocking=True)     # device-to-device: the INT timestep of this step
         st.noise_pred.zero_()
         st.counter.zero_()
-        if not st.dist:
-            self._run(st, "writer", lambda: self._part_writer(st))
+        overlap = st.overlap
+        if overlap:
+            # ReferenceNet write pass  ||  bank-independent Backbone down path.  All three parts go through the same
+            # warm -> capture -> replay sequence IN THE SAME STEPS, so the reader/writer bank lists are populated when the
+            # consumers are captured (a graph replay does not re-run the Python bank bookkeeping).  The second stream is
+            # only used once graphs exist (eager allocations must not cross streams).
+            use_side = st.graphs.get("writer") is not None and ops.PROFILER is None
+            main = torch.cuda.current_stream()
+            if use_side:
+                st.side.wait_stream(main)
+                with torch.cuda.stream(st.side):
+                    self._run(st, "writer", lambda: self._part_writer(st), pool=st.writer_pool)
+            else:
+                self._run(st, "writer", lambda: self._part_writer(st), pool=st.writer_pool)
+            for ci in range(len(st.my_contexts)):
+                self._run(st, ("down", ci), lambda ci=ci: self._part_unet_down(st, ci))
+            if use_side:
+                main.wait_stream(st.side)
+            for ci in range(len(st.my_contexts)):
+                self._run(st, ("rest", ci), lambda ci=ci: self._part_unet_rest(st, ci))
+        elif not st.dist:
+            self._run(st, "writer", lambda: self._part_writer(st), pool=st.writer_pool)
         else:
             if st.bank_group is None or si >= st.bank_group_start + st.world_size or si < st.bank_group_start:
                 self._exchange_banks(st, si)
             st.bank_now.copy_(st.bank_group[si - st.bank_group_start])   # static buffer: graph-stable addresses
             self._unpack_banks(st.bank_now, st.writer, st.bank_shapes)
-        for ci in range(len(st.my_contexts)):                                                  # :757
-            self._run(st, ("unet", ci), lambda ci=ci: self._part_unet(st, ci))
+        if not overlap:
+            for ci in range(len(st.my_contexts)):                                              # :757
+                self._run(st, ("unet", ci), lambda ci=ci: self._part_unet(st, ci))
         if st.dist:                                                                            # replaces :796-809 + :819-821
             import torch.distributed as td
             td.all_reduce(st.noise_pred)

@@ -54,6 +54,10 @@ class _Ctx:
         self.active = ()
 
 
+class _State:
+    """activations handed between the three forward stages"""
+
+
 class UNet3DConditionModel:
     def __init__(self, **kwargs):
         self._has_out = kwargs.pop("_has_out", True)
@@ -334,39 +338,29 @@ class UNet3DConditionModel:
         h = ops.gemm(g, w[tb + ".ff2.w"], w[tb + ".ff2.b"], residual=h)
         return ops.gemm(h, w[p + ".proj_out.w"], w[p + ".proj_out.b"], residual=x)
 
-    # ------------------------------------------------------------------ forward
-    def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None,
-                down_block_additional_residuals: Optional[Tuple[torch.Tensor]] = None,
-                mid_block_additional_residual: Optional[torch.Tensor] = None, return_dict: bool = True,
-                audio_features=None, speed_embeddings=None, _bank_ctx=None, _return_rows=False) -> Union[UNet3DConditionOutput, Tuple]:
-        """unet_controlnet.py:328-483.  sample (B,C,F,h,w); timestep Tensor|int|float;
-        encoder_hidden_states (B|B*F, L, D).  EMO extension kwargs (EMOAnimationPipeline.py:783-784):
-        audio_features (B*F, L_a, D) per-frame attn2 context; speed_embeddings (B, 4*C0) added to emb."""
+    # ------------------------------------------------------------------ forward (three stages so that the sampler can
+    # overlap the ReferenceNet pass with the bank-independent down path on a second HIP stream)
+    def _begin(self, sample, timestep, encoder_hidden_states, audio_features=None, speed_embeddings=None,
+               down_block_additional_residuals=None, mid_block_additional_residual=None):
         if self._w is None:
             raise EmoHipError("UNet3DConditionModel: weights not loaded / model not on a HIP device "
                               "(load_state_dict + .to('cuda')); there is no CPU execution path")
-        if attention_mask is not None:
-            raise NotImplementedError("attention_mask is outside the hot path (always None in the pipeline)")
-        if class_labels is not None:
-            raise NotImplementedError("class embeddings are outside the hot path")
         if sample.dim() != 5:
             raise ValueError(f"Expected sample to have ndim=5, but got ndim={sample.dim()}.")
-        cfg, w, spec, dtp = self.config, self._w, self.spec, self.dtype
+        cfg, w, dtp = self.config, self._w, self.dtype
         B, Cin, F, H, W = sample.shape
         if Cin != cfg["in_channels"]:
             raise ValueError(f"sample has {Cin} channels, expected {cfg['in_channels']}")
         up = 2 ** self.num_upsamplers
         if H % up or W % up:
             raise NotImplementedError("sample H/W must be multiples of 2**num_upsamplers (upsample_size forwarding is not built)")
-        dev = self.device
-        c = _bank_ctx if _bank_ctx is not None else _Ctx(B, F, H, W)
-        c.B, c.F, c.H, c.W = B, F, H, W
-        rc = self._reference_control
-        if _bank_ctx is None and rc is not None:
-            rc._prepare(c, self)
-        sample = sample.to(dev)
         if cfg["center_input_sample"]:
             raise NotImplementedError("center_input_sample=True is outside the hot path (False in every shipped config)")
+        dev = self.device
+        s = _State()
+        s.c = _Ctx(B, F, H, W)
+        s.B, s.F, s.H, s.W = B, F, H, W
+        sample = sample.to(dev)
         # time (unet_controlnet.py:376-398)
         if not torch.is_tensor(timestep):
             timesteps = torch.tensor([timestep], dtype=torch.int64, device=dev)
@@ -379,67 +373,98 @@ class UNet3DConditionModel:
         if speed_embeddings is not None:  # EMO extension: class-embedding slot (unet_controlnet.py:400-408)
             se = ops.convert(speed_embeddings.to(dev).float().reshape(B, -1), dtp)
             emb = ops.add(emb, se)
-        temb_all = ops.convert(ops.gemm(ops.silu(emb), w["temb_all.w"], w["temb_all.b"]), torch.float32)
+        s.temb_all = ops.convert(ops.gemm(ops.silu(emb), w["temb_all.w"], w["temb_all.b"]), torch.float32)
         # context rows
         ctx = encoder_hidden_states if audio_features is None else audio_features
         ctx = ctx.to(dev)
         if ctx.shape[0] == B * F:
-            ctx_div = 1
+            s.ctx_div = 1
         elif ctx.shape[0] == B:
-            ctx_div = F
+            s.ctx_div = F
         else:
             raise ValueError(f"encoder_hidden_states batch {ctx.shape[0]} is neither B={B} nor B*F={B * F}")
-        ctx_len = ctx.shape[1]
-        ctx_rows = ops.convert(ctx.float().reshape(-1, ctx.shape[2]), dtp)
-
+        s.ctx_len = ctx.shape[1]
+        s.ctx_rows = ops.convert(ctx.float().reshape(-1, ctx.shape[2]), dtp)
+        s.ctrl = (down_block_additional_residuals, mid_block_additional_residual)
         x = ops.ncfhw_to_rows(sample, dtp, cpad=_round_up(Cin, 8))
-        x, _, _ = ops.conv3x3(x, w["conv_in.w"], w["conv_in.b"], B * F, H, W)
-        skips = [x]
-        h_, w_ = H, W
+        s.x, _, _ = ops.conv3x3(x, w["conv_in.w"], w["conv_in.b"], B * F, H, W)
+        s.skips = [s.x]
+        s.h, s.w = H, W
+        return s
+
+    def _run_down(self, s):
+        w, spec, dtp, dev = self._w, self.spec, self.dtype, self.device
+        x, c, h_, w_ = s.x, s.c, s.h, s.w
         for blk in spec.down:
             for r, a, mo in zip(blk.resnets, blk.attentions, blk.motions):
-                x = self._resnet(r, x, temb_all, c, h_, w_)
+                x = self._resnet(r, x, s.temb_all, c, h_, w_)
                 if a is not None:
-                    x = self._transformer(a, x, ctx_rows, ctx_len, ctx_div, c, h_, w_)
+                    x = self._transformer(a, x, s.ctx_rows, s.ctx_len, s.ctx_div, c, h_, w_)
                 if mo is not None:
                     x = self._motion(mo, x, c, h_, w_)
-                skips.append(x)
+                s.skips.append(x)
             if blk.sampler:
-                x, h_, w_ = ops.conv3x3(x, w[blk.sampler + ".w"], w[blk.sampler + ".b"], B * F, h_, w_, stride=2)
-                skips.append(x)
-        if down_block_additional_residuals is not None and mid_block_additional_residual is not None:
-            new = []
-            for s, r in zip(skips, down_block_additional_residuals):  # unet_controlnet.py:430-439
-                new.append(ops.add(s, ops.ncfhw_to_rows(r.to(dev), dtp)))
-            skips = new
+                x, h_, w_ = ops.conv3x3(x, w[blk.sampler + ".w"], w[blk.sampler + ".b"], s.B * s.F, h_, w_, stride=2)
+                s.skips.append(x)
+        down_res, mid_res = s.ctrl
+        if down_res is not None and mid_res is not None:
+            s.skips = [ops.add(sk, ops.ncfhw_to_rows(r.to(dev), dtp)) for sk, r in zip(s.skips, down_res)]  # unet_controlnet.py:430-439
+        s.x, s.h, s.w = x, h_, w_
+
+    def _run_rest(self, s, return_rows=False):
+        cfg, w, spec, dtp, dev = self.config, self._w, self.spec, self.dtype, self.device
+        x, c, h_, w_ = s.x, s.c, s.h, s.w
+        B, F = s.B, s.F
+        down_res, mid_res = s.ctrl
         sc = cfg["mid_block_scale_factor"]
-        x = self._resnet(spec.mid.resnets[0], x, temb_all, c, h_, w_, sc)
-        x = self._transformer(spec.mid.attentions[0], x, ctx_rows, ctx_len, ctx_div, c, h_, w_)
+        x = self._resnet(spec.mid.resnets[0], x, s.temb_all, c, h_, w_, sc)
+        x = self._transformer(spec.mid.attentions[0], x, s.ctx_rows, s.ctx_len, s.ctx_div, c, h_, w_)
         if spec.mid.motions[0] is not None:
             x = self._motion(spec.mid.motions[0], x, c, h_, w_)
-        x = self._resnet(spec.mid.resnets[1], x, temb_all, c, h_, w_, sc)
-        if down_block_additional_residuals is not None and mid_block_additional_residual is not None:
-            x = ops.add(x, ops.ncfhw_to_rows(mid_block_additional_residual.to(dev), dtp))
+        x = self._resnet(spec.mid.resnets[1], x, s.temb_all, c, h_, w_, sc)
+        if down_res is not None and mid_res is not None:
+            x = ops.add(x, ops.ncfhw_to_rows(mid_res.to(dev), dtp))
+        skips = s.skips
         for blk in spec.up:
             for r, a, mo in zip(blk.resnets, blk.attentions, blk.motions):
                 x = ops.concat_cols(x, skips.pop())  # unet_3d_blocks.py:627-629
-                x = self._resnet(r, x, temb_all, c, h_, w_)
+                x = self._resnet(r, x, s.temb_all, c, h_, w_)
                 if a is not None:
-                    x = self._transformer(a, x, ctx_rows, ctx_len, ctx_div, c, h_, w_)
+                    x = self._transformer(a, x, s.ctx_rows, s.ctx_len, s.ctx_div, c, h_, w_)
                 if mo is not None:
                     x = self._motion(mo, x, c, h_, w_)
             if blk.sampler:
                 x, h_, w_ = ops.conv3x3(x, w[blk.sampler + ".w"], w[blk.sampler + ".b"], B * F, h_, w_, upsample2x=True)
-        if _bank_ctx is None and rc is not None:
+        rc = self._reference_control
+        if rc is not None:
             rc._finish(c, self)
         if not spec.has_out:
-            out = None
-        else:
-            x = ops.group_norm(x, w["conv_norm_out.g"], w["conv_norm_out.b"], B, cfg["norm_num_groups"], cfg["norm_eps"], True)
-            x, _, _ = ops.conv3x3(x, w["conv_out.w"], w["conv_out.b"], B * F, h_, w_)
-            if _return_rows:  # the sampler consumes NHWC rows directly (no layout round trip)
-                return x
-            out = ops.rows_to_ncfhw(x, B, cfg["out_channels"], F, h_, w_)
+            return None
+        x = ops.group_norm(x, w["conv_norm_out.g"], w["conv_norm_out.b"], B, cfg["norm_num_groups"], cfg["norm_eps"], True)
+        x, _, _ = ops.conv3x3(x, w["conv_out.w"], w["conv_out.b"], B * F, h_, w_)
+        if return_rows:  # the sampler consumes NHWC rows directly (no layout round trip)
+            return x
+        return ops.rows_to_ncfhw(x, B, cfg["out_channels"], F, h_, w_)
+
+    def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None,
+                down_block_additional_residuals: Optional[Tuple[torch.Tensor]] = None,
+                mid_block_additional_residual: Optional[torch.Tensor] = None, return_dict: bool = True,
+                audio_features=None, speed_embeddings=None, _return_rows=False) -> Union[UNet3DConditionOutput, Tuple]:
+        """unet_controlnet.py:328-483.  sample (B,C,F,h,w); timestep Tensor|int|float;
+        encoder_hidden_states (B|B*F, L, D).  EMO extension kwargs (EMOAnimationPipeline.py:783-784):
+        audio_features (B*F, L_a, D) per-frame attn2 context; speed_embeddings (B, 4*C0) added to emb."""
+        if attention_mask is not None:
+            raise NotImplementedError("attention_mask is outside the hot path (always None in the pipeline)")
+        if class_labels is not None:
+            raise NotImplementedError("class embeddings are outside the hot path")
+        s = self._begin(sample, timestep, encoder_hidden_states, audio_features, speed_embeddings,
+                        down_block_additional_residuals, mid_block_additional_residual)
+        if self._reference_control is not None:
+            self._reference_control._prepare(s.c, self)
+        self._run_down(s)
+        out = self._run_rest(s, return_rows=_return_rows)
+        if _return_rows:
+            return out
         if not return_dict:
             return (out,)
         return UNet3DConditionOutput(sample=out)
