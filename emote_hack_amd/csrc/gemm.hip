@@ -35,6 +35,7 @@
 //   bf16: v_mfma_f32_32x32x16_bf16, f32 accumulate.   f32: v_mfma_f32_32x32x2_f32 (exact f32 fma chain).
 // Epilogue fused: bias, per-batch row bias (temb), GEGLU, residual, scale, row-major or V^T store.
 // Split-K (small M): f32 partial slabs + a fixed-order reduce/epilogue kernel (deterministic).
+#include <stdlib.h>
 #include "common.h"
 
 #ifndef EMO_GEMM_KBYTES
@@ -451,6 +452,16 @@ static GemmPlan plan_gemm(int64_t M, int N, int K, int dtype, int geglu) {
   const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
   pl.big = (dtype == EMO_BF16 && tiles256 >= 224 && (N % 256 == 0 || N >= 1792)) ? 1 : 0;
   pl.nt5 = (!pl.big && !geglu && N % 160 == 0) ? 1 : 0;
+  if (pl.nt5 && N % 128 == 0) {
+    // both 128x160 and 128x128 tile N exactly: take the one that fills the 2-blocks-per-CU slots better (the 2x2 wave
+    // layout also reads 1.0 instead of 1.2 LDS fragments per MFMA, so it wins ties)
+    const int64_t mt = (M + 127) / 128, slots = 512;
+    const int64_t b5 = mt * (N / 160), b4 = mt * (N / 128);
+    const double f5 = (double)b5 / (double)(((b5 + slots - 1) / slots) * slots);
+    const double f4 = (double)b4 / (double)(((b4 + slots - 1) / slots) * slots);
+    static const int force = getenv("EMO_GEMM_TILE") ? atoi(getenv("EMO_GEMM_TILE")) : 0;
+    if (force == 4 || (force == 0 && f4 * 1.05 >= f5)) pl.nt5 = 0;
+  }
   const int bn = pl.nt5 ? 160 : 128;
   const int64_t tiles = ((M + 127) / 128) * ((N + bn - 1) / bn);
   const int bk = KBYTES / (dtype == EMO_F32 ? 4 : 2);
