@@ -67,7 +67,7 @@ SIGNATURES = {
     "emo_groupnorm_apply": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _i, _i, _p]),
     "emo_layernorm": (_i, [_p, _i, _p, _p, _p, _i, _i64, _i, _f, _p, _i, _i, _i, _p]),
     "emo_gemm": (_i, [C.POINTER(GemmParams), _p]),
-    "emo_gemm_suggest_split_k": (_i, [_i64, _i, _i, _i]),
+    "emo_gemm_suggest_split_k": (_i, [_i64, _i, _i, _i, _i, _i]),
     "emo_gemm_workspace_bytes": (C.c_size_t, [_i64, _i, _i]),
     "emo_attention": (_i, [C.POINTER(AttentionParams), _p]),
     "emo_temporal_attention": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _i, _i, _f, _i, _p]),

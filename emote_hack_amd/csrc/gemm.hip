@@ -414,44 +414,82 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
   }
 }
 
-// split-K second pass: fixed-order reduction of the f32 partials + the same fused epilogue
+// split-K second pass: fixed-order reduction of the f32 partials + the same fused epilogue; a thread owns 4 consecutive
+// output columns (N % 4 == 0 is enforced for split-K): 16-byte partial loads, 8/16-byte stores
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(const emo_gemm_params p) {
   const int n_out = p.geglu ? p.N / 2 : p.N;
-  const int64_t total = p.M * n_out;
+  const int nq = n_out >> 2;
+  const int64_t total = p.M * nq;
   const float* __restrict__ ws = (const float*)p.workspace;
   const int64_t slab = p.M * (int64_t)p.N;
   T* __restrict__ C = (T*)p.C;
   const T* __restrict__ R = (const T*)p.residual;
+  const bool vec_io = ((p.ldc | (R ? p.ldr : 0)) & 3) == 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = i / n_out;
-    const int no = (int)(i % n_out);
+    const int64_t m = i / nq;
+    const int no = (int)(i % nq) * 4;
     const int nw = p.geglu ? (no / 32) * 64 + (no % 32) : no;   // column in W-row space
-    float v = 0.f, g = 0.f;
+    float v[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < p.split_k; s++) {
-      v += ws[s * slab + m * p.N + nw];
-      if (p.geglu) g += ws[s * slab + m * p.N + nw + 32];
+      const float4 a = *(const float4*)(ws + s * slab + m * p.N + nw);
+      v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+      if (p.geglu) {
+        const float4 b = *(const float4*)(ws + s * slab + m * p.N + nw + 32);
+        g[0] += b.x; g[1] += b.y; g[2] += b.z; g[3] += b.w;
+      }
     }
-    if (p.bias) { v += p.bias[nw]; if (p.geglu) g += p.bias[nw + 32]; }
-    if (p.rowbias) v += p.rowbias[(m / p.rows_per_batch) * p.ld_rowbias + nw];
-    if (p.geglu) v = v * gelu_erf_f(g);
-    if (R) v += TT<T>::ld(R + m * p.ldr + no);
-    v *= p.out_scale;
-    if (!p.transpose_out) TT<T>::st(C + m * p.ldc + no, v);
-    else TT<T>::st(C + (m / p.t_rows) * p.t_batch_stride + (int64_t)no * p.t_ld + (m % p.t_rows), v);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      if (p.bias) { v[e] += p.bias[nw + e]; if (p.geglu) g[e] += p.bias[nw + 32 + e]; }
+      if (p.rowbias) v[e] += p.rowbias[(m / p.rows_per_batch) * p.ld_rowbias + nw + e];
+      if (p.geglu) v[e] = v[e] * gelu_erf_f(g[e]);
+    }
+    if (!p.transpose_out) {
+      if (vec_io) {
+        if (R) {
+          if constexpr (sizeof(T) == 2) {
+            const uint2 rv = *(const uint2*)(R + m * p.ldr + no);
+            v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+            v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+          } else {
+            const float4 rv = *(const float4*)(R + m * p.ldr + no);
+            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] *= p.out_scale;
+        if constexpr (sizeof(T) == 2) *(uint2*)(C + m * p.ldc + no) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        else *(float4*)(C + m * p.ldc + no) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          float o = v[e];
+          if (R) o += TT<T>::ld(R + m * p.ldr + no + e);
+          TT<T>::st(C + m * p.ldc + no + e, o * p.out_scale);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        TT<T>::st(C + (m / p.t_rows) * p.t_batch_stride + (int64_t)(no + e) * p.t_ld + (m % p.t_rows), v[e] * p.out_scale);
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------ host side
-struct GemmPlan { int nt5, big, split_k; };
+struct GemmPlan { int nt5, big, small, split_k; };
 
-static GemmPlan plan_gemm(int64_t M, int N, int K, int dtype, int geglu) {
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+
+static GemmPlan plan_gemm(int64_t M, int N, int K, int dtype, int geglu, int transpose_out) {
   GemmPlan pl;
   // 256x256 / 8 waves for the big compute-bound shapes (N a multiple of 256, or wide enough that the ragged last
   // tile is small), else 128x160 when N is a multiple of 160 (every SD-1.5 width), else 128x128
   const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
   pl.big = (dtype == EMO_BF16 && tiles256 >= 224 && (N % 256 == 0 || N >= 1792)) ? 1 : 0;
   pl.nt5 = (!pl.big && !geglu && N % 160 == 0) ? 1 : 0;
+  pl.small = 0;
   if (pl.nt5 && N % 128 == 0) {
     // both 128x160 and 128x128 tile N exactly: take the one that fills the 2-blocks-per-CU slots better (the 2x2 wave
     // layout also reads 1.0 instead of 1.2 LDS fragments per MFMA, so it wins ties)
@@ -459,16 +497,26 @@ static GemmPlan plan_gemm(int64_t M, int N, int K, int dtype, int geglu) {
     const int64_t b5 = mt * (N / 160), b4 = mt * (N / 128);
     const double f5 = (double)b5 / (double)(((b5 + slots - 1) / slots) * slots);
     const double f4 = (double)b4 / (double)(((b4 + slots - 1) / slots) * slots);
-    static const int force = getenv("EMO_GEMM_TILE") ? atoi(getenv("EMO_GEMM_TILE")) : 0;
+    static const int force = env_int("EMO_GEMM_TILE", 0);
     if (force == 4 || (force == 0 && f4 * 1.05 >= f5)) pl.nt5 = 0;
   }
-  const int bn = pl.nt5 ? 160 : 128;
-  const int64_t tiles = ((M + 127) / 128) * ((N + bn - 1) / bn);
   const int bk = KBYTES / (dtype == EMO_F32 ? 4 : 2);
   const int nk = (K + bk - 1) / bk;
+  // fewer 128-row blocks than CUs and a short K (the 8x8 / 16x16 levels, the ReferenceNet pass): splitting K pays an f32
+  // round trip + a second launch and a block is mostly prologue + epilogue -> 64x64 tiles (4 waves of 32x32, 32 KB of
+  // LDS: ~4 co-resident blocks per CU overlap each other's prologue/epilogue).  They read 2 LDS fragments per MFMA, so
+  // long-K shapes (every conv) stay on 128-row tiles + split-K.  V^T outputs also take them: the column-per-lane
+  // store of the transposed epilogue is cheaper from 32x32 wave tiles (measured 91 -> 59 us at M=98304 N=K=320).
+  static const int small_mode = env_int("EMO_GEMM_SMALL", 1), small_slots = env_int("EMO_GEMM_SMALL_SLOTS", 512);
+  static const int small_below = env_int("EMO_GEMM_SMALL_BELOW", 256), small_nk = env_int("EMO_GEMM_SMALL_NK", 24);
+  const int64_t blocks128 = ((M + 127) / 128) * ((N + (pl.nt5 ? 159 : 127)) / (pl.nt5 ? 160 : 128));
+  if (small_mode && !pl.big && !geglu && nk <= small_nk && (blocks128 < small_below || transpose_out)) { pl.small = 1; pl.nt5 = 0; }
+  const int bm = pl.small ? 64 : 128, bn = pl.small ? 64 : (pl.nt5 ? 160 : 128);
+  const int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+  const int64_t slots = pl.small ? small_slots : 512;     // co-resident blocks to aim at
   int s = 1;
-  if (tiles < 192 && nk >= 8 && N % 4 == 0) {
-    s = (int)((512 + tiles - 1) / tiles);        // aim at ~2 blocks per CU
+  if (!pl.big && tiles * 2 <= slots && nk >= 8 && N % 4 == 0) {
+    s = (int)(slots / tiles);                     // whole blocks only: one block more than the slots costs a second round
     const int max_by_k = nk / 4;                  // keep >= 4 stages per slice
     if (s > max_by_k) s = max_by_k;
     if (s > 32) s = 32;
@@ -478,7 +526,9 @@ static GemmPlan plan_gemm(int64_t M, int N, int K, int dtype, int geglu) {
   return pl;
 }
 
-extern "C" int emo_gemm_suggest_split_k(int64_t M, int N, int K, int dtype) { return plan_gemm(M, N, K, dtype, 0).split_k; }
+extern "C" int emo_gemm_suggest_split_k(int64_t M, int N, int K, int dtype, int geglu, int transpose_out) {
+  return plan_gemm(M, N, K, dtype, geglu, transpose_out).split_k;
+}
 extern "C" size_t emo_gemm_workspace_bytes(int64_t M, int N, int split_k) {
   return split_k > 1 ? (size_t)split_k * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
@@ -510,6 +560,7 @@ static int dispatch_tile(const emo_gemm_params& p, const GemmPlan& pl, int S, hi
   return launch_gemm<T, CONV, TRANS, 2, 2, 2, 2, EMO_NS22>(p, S, st);
 #endif
   if (pl.big && S == 1) return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, 2>(p, S, st);   // 2x4 waves of 128x64, 2 x 64 KB ring
+  if (pl.small) return launch_gemm<T, CONV, TRANS, 1, 1, 2, 2, 2>(p, S, st);   // 2x2 waves of 32x32, 2 x 16 KB ring
   if (pl.nt5) return launch_gemm<T, CONV, TRANS, 1, 5, 4, 1, 2>(p, S, st);   // 4x1 waves of 32x160, 2 x 36 KB ring
 #ifndef EMO_NS22
 #define EMO_NS22 2
@@ -550,7 +601,7 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
   if (!p.transpose_out) {
     EMO_CHECK(((uintptr_t)p.C % 16) == 0 && (!p.residual || ((uintptr_t)p.residual % 8) == 0), EMO_ERR_BAD_SHAPE, "emo_gemm: C/residual alignment");
   }
-  GemmPlan pl = plan_gemm(p.M, p.N, p.K, p.dtype, p.geglu);
+  GemmPlan pl = plan_gemm(p.M, p.N, p.K, p.dtype, p.geglu, p.transpose_out);
   const int S = p.split_k > 1 ? p.split_k : 1;
   if (S > 1) {
     EMO_CHECK(p.workspace != nullptr && S <= 65535, EMO_ERR_NULL, "emo_gemm: split_k=%d needs a workspace", S);
@@ -560,7 +611,7 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
   int rc = p.dtype == EMO_F32 ? dispatch_gemm<float>(p, pl, S, st) : dispatch_gemm<bf16_t>(p, pl, S, st);
   if (rc) return rc;
   if (S > 1) {
-    const int64_t total = p.M * (p.geglu ? p.N / 2 : p.N);
+    const int64_t total = p.M * (p.geglu ? p.N / 2 : p.N) / 4;
     int64_t g = (total + 255) / 256; if (g > 4096) g = 4096;
     if (p.dtype == EMO_F32) gemm_splitk_epilogue_kernel<float><<<(int)g, 256, 0, st>>>(p);
     else gemm_splitk_epilogue_kernel<bf16_t><<<(int)g, 256, 0, st>>>(p);

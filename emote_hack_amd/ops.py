@@ -245,7 +245,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
         p.stride, p.upsample2x, p.Ho, p.Wo = conv["stride"], int(conv["upsample2x"]), conv["Ho"], conv["Wo"]
     p.dtype = dt(a)
     lib = _lib.load()
-    sk = lib.emo_gemm_suggest_split_k(M, N, K, p.dtype) if split_k is None else split_k
+    sk = lib.emo_gemm_suggest_split_k(M, N, K, p.dtype, int(bool(geglu)), int(bool(transpose_rows))) if split_k is None else split_k
     ws = None
     if sk > 1:
         ws = torch.empty(lib.emo_gemm_workspace_bytes(M, N, sk) // 4, device=a.device, dtype=torch.float32)

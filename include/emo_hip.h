@@ -122,7 +122,7 @@ typedef struct {
 } emo_gemm_params;
 int emo_gemm(const emo_gemm_params* p, void* stream);
 /* heuristic split factor for (M, N, K) and the workspace it needs */
-int emo_gemm_suggest_split_k(int64_t M, int N, int K, int dtype);
+int emo_gemm_suggest_split_k(int64_t M, int N, int K, int dtype, int geglu, int transpose_out);
 size_t emo_gemm_workspace_bytes(int64_t M, int N, int split_k);
 
 /* ---- attention -------------------------------------------------------------------------------
