@@ -63,8 +63,8 @@ SIGNATURES = {
     "emo_silu": (_i, [_p, _p, _i64, _i, _p]),
     "emo_timestep_embedding": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "emo_groupnorm_workspace_bytes": (C.c_size_t, [_i, _i64, _i, _i]),
-    "emo_groupnorm_stats": (_i, [_p, _i, _p, _p, _i, _i64, _i, _i, _f, _i, _p]),
-    "emo_groupnorm_apply": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _i, _i, _p]),
+    "emo_groupnorm_stats": (_i, [_p, _i, _p, _i, _i64, _i, _i, _i, _p]),
+    "emo_groupnorm_apply": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _f, _i, _i, _p]),
     "emo_layernorm": (_i, [_p, _i, _p, _p, _p, _i, _i64, _i, _f, _p, _i, _i, _i, _p]),
     "emo_gemm": (_i, [C.POINTER(GemmParams), _p]),
     "emo_gemm_suggest_split_k": (_i, [_i64, _i, _i, _i, _i, _i]),

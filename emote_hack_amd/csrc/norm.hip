@@ -4,80 +4,109 @@
 // GroupNorm: reference semantics are nn.GroupNorm applied to a 5-D tensor in the resnets
 // (resnet.py:180,191 -> statistics joint over C/G x F x H x W) and to per-frame 4-D tensors in the
 // transformers (attention.py:124, motion_module.py:147).  Both are "instances of S consecutive rows".
-//   pass 1  gn_partial_kernel : block = (instance n, row-chunk); per-channel sum / sumsq in registers,
-//                               fixed-order LDS reduction -> partial (sum, sumsq) per group  (deterministic)
-//   pass 2  gn_finalize_kernel: combine partials in double -> (mean, rstd)
-//   pass 3  gn_apply_kernel   : y = (x-mean)*rstd*gamma+beta, optional SiLU
+//   pass 1  gn_stats_kernel : block = (instance n, row-chunk); per-channel sum / sumsq in registers,
+//                             fixed-order LDS reduction -> partial (sum, sumsq) per (chunk, group)  (deterministic)
+//   pass 2  gn_apply_kernel : prologue: every block combines the <= 256 chunk partials of its instance in f64, in the same
+//                             fixed order -> (mean, rstd) in LDS (no third launch, no inter-block fence: an agent-scope
+//                             release on this part writes back the whole L2);  y = (x-mean)*rstd*gamma+beta, optional SiLU
 #include "common.h"
 
 static constexpr int GN_THREADS = 256;
 static constexpr int GN_MAXJ = 3;  // column vectors per thread: C <= 256*3*VEC
 
-static inline int gn_nsplit(int64_t S) {
-  int64_t n = (S + 15) / 16;
-  if (n > 1024) n = 1024;
-  if (n < 1) n = 1;
-  return (int)n;
+// Geometry shared by both passes.  Channels wider than one block's 256 column vectors are cut into NC column parts
+// of whole groups (C=2560: two parts of 16 groups), each part handled by its own blocks (blockIdx.y).  A block holds
+// RP = 256 / (column vectors per part) row slots; a thread streams 4-16 rows (more once the block budget binds).
+struct GnGeom { int NC, Cp, Gp, RP, nsplit_stats, nsplit_apply; };
+static inline GnGeom gn_geom(int N, int64_t S, int C, int G, int V) {
+  GnGeom g;
+  g.NC = 1;
+  while ((C / g.NC) / V > GN_THREADS && g.NC < 8 && G % (g.NC * 2) == 0 && (C / (g.NC * 2)) % V == 0) g.NC *= 2;
+  g.Cp = C / g.NC; g.Gp = G / g.NC;
+  const int CVp = g.Cp / V;
+  g.RP = CVp <= GN_THREADS ? GN_THREADS / CVp : 1;
+  // 16 rows per thread; tensors too small to give every CU a block that way go down to 8 / 4 rows per thread (shorter
+  // dependent-load chains).  <= 1024 blocks per launch (the apply pass pays its statistics prologue per block) and
+  // <= 256 chunk partials per instance (every apply block re-reduces them).
+  auto chunks = [&](int64_t hard_cap) {
+    int64_t n = 1;
+    for (int rpt = 16; rpt >= 4; rpt >>= 1) {
+      const int64_t rows_per_block = (int64_t)g.RP * rpt;
+      n = (S + rows_per_block - 1) / rows_per_block;
+      if (n * N * g.NC >= 256) break;
+    }
+    int64_t want = 1024 / ((int64_t)N * g.NC);
+    if (want < 1) want = 1;
+    if (n > want) n = want;
+    if (n > hard_cap) n = hard_cap;
+    if (n < 1) n = 1;
+    return (int)n;
+  };
+  g.nsplit_stats = chunks(256);
+  g.nsplit_apply = chunks(1 << 20);
+  return g;
 }
 extern "C" size_t emo_groupnorm_workspace_bytes(int N, int64_t S, int C, int G) {
-  (void)C;
-  return (size_t)N * gn_nsplit(S) * G * 2 * sizeof(float);
+  // the chunk count depends on the element width through RP; size for the larger of the two
+  const GnGeom a = gn_geom(N, S, C, G, 8), b = gn_geom(N, S, C, G, 4);
+  const int ns = a.nsplit_stats > b.nsplit_stats ? a.nsplit_stats : b.nsplit_stats;
+  return (size_t)N * ns * G * 2 * sizeof(float);
 }
 
+// pass 1: per-(instance, row chunk) group sums
 template <typename T>
-__global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(const T* __restrict__ x, int ldx, float* __restrict__ partials,
-                                                                int64_t S, int C, int G, int nsplit) {
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restrict__ x, int ldx, float* __restrict__ partials,
+                                                              int64_t S, int C, int G, int G_all, int nsplit) {
+  // C, G: this column part's channels / groups (blockIdx.y selects the part); G_all: groups of the whole tensor
   constexpr int V = TT<T>::VEC;
   extern __shared__ float lds[];  // [RP][C][2]
   const int n = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  x += (int64_t)blockIdx.y * C;
   const int CV = C / V;
   const int64_t rows_per = (S + nsplit - 1) / nsplit;
   const int64_t s0 = sp * rows_per;
   int64_t s1 = s0 + rows_per; if (s1 > S) s1 = S;
   const int tid = threadIdx.x;
   const T* base = x + (int64_t)n * S * ldx;
-  float sum[GN_MAXJ][V], sq[GN_MAXJ][V];
-#pragma unroll
-  for (int j = 0; j < GN_MAXJ; j++)
-#pragma unroll
-    for (int e = 0; e < V; e++) { sum[j][e] = 0.f; sq[j][e] = 0.f; }
   int RP;   // row slots in the block
   if (CV <= GN_THREADS) {
     RP = GN_THREADS / CV;
     const int r = tid / CV, cv = tid % CV;
     if (r < RP) {
+      float sum[V], sq[V];
+#pragma unroll
+      for (int e = 0; e < V; e++) { sum[e] = 0.f; sq[e] = 0.f; }
+      const T* col = base + cv * V;
       int64_t s = s0 + r;
-      for (; s + 3 * RP < s1; s += 4 * RP) {   // 4 independent 16-byte loads in flight per thread
-        uint4 v0 = *(const uint4*)(base + s * ldx + cv * V);
-        uint4 v1 = *(const uint4*)(base + (s + RP) * ldx + cv * V);
-        uint4 v2 = *(const uint4*)(base + (s + 2 * RP) * ldx + cv * V);
-        uint4 v3 = *(const uint4*)(base + (s + 3 * RP) * ldx + cv * V);
-        float f[V];
-        unpack16<T>(v0, f);
+      for (; s + 7 * RP < s1; s += 8 * RP) {   // 8 independent 16-byte loads in flight per thread
+        uint4 v[8];
 #pragma unroll
-        for (int e = 0; e < V; e++) { sum[0][e] += f[e]; sq[0][e] += f[e] * f[e]; }
-        unpack16<T>(v1, f);
+        for (int u = 0; u < 8; u++) v[u] = *(const uint4*)(col + (s + u * RP) * ldx);
 #pragma unroll
-        for (int e = 0; e < V; e++) { sum[0][e] += f[e]; sq[0][e] += f[e] * f[e]; }
-        unpack16<T>(v2, f);
+        for (int u = 0; u < 8; u++) {
+          float f[V];
+          unpack16<T>(v[u], f);
 #pragma unroll
-        for (int e = 0; e < V; e++) { sum[0][e] += f[e]; sq[0][e] += f[e] * f[e]; }
-        unpack16<T>(v3, f);
-#pragma unroll
-        for (int e = 0; e < V; e++) { sum[0][e] += f[e]; sq[0][e] += f[e] * f[e]; }
+          for (int e = 0; e < V; e++) { sum[e] += f[e]; sq[e] += f[e] * f[e]; }
+        }
       }
       for (; s < s1; s += RP) {
         float f[V];
-        unpack16<T>(*(const uint4*)(base + s * ldx + cv * V), f);
+        unpack16<T>(*(const uint4*)(col + s * ldx), f);
 #pragma unroll
-        for (int e = 0; e < V; e++) { sum[0][e] += f[e]; sq[0][e] += f[e] * f[e]; }
+        for (int e = 0; e < V; e++) { sum[e] += f[e]; sq[e] += f[e] * f[e]; }
       }
       float* dst = lds + ((int64_t)r * C + cv * V) * 2;
 #pragma unroll
-      for (int e = 0; e < V; e++) { dst[2 * e] = sum[0][e]; dst[2 * e + 1] = sq[0][e]; }
+      for (int e = 0; e < V; e++) { dst[2 * e] = sum[e]; dst[2 * e + 1] = sq[e]; }
     }
   } else {
     RP = 1;
+    float sum[GN_MAXJ][V], sq[GN_MAXJ][V];
+#pragma unroll
+    for (int j = 0; j < GN_MAXJ; j++)
+#pragma unroll
+      for (int e = 0; e < V; e++) { sum[j][e] = 0.f; sq[j][e] = 0.f; }
     for (int64_t s = s0; s < s1; s++) {
 #pragma unroll
       for (int j = 0; j < GN_MAXJ; j++) {
@@ -101,44 +130,38 @@ __global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(const T* __restr
     }
   }
   __syncthreads();
+  // 2G outputs (sum, sumsq per group), TPO adjacent lanes each: fixed-order strided partial sums + shuffle tree
   const int cpg = C / G;
-  for (int g = tid; g < G; g += GN_THREADS) {
-    float a = 0.f, b = 0.f;
-    for (int r = 0; r < RP; r++)
-      for (int c = g * cpg; c < (g + 1) * cpg; c++) { a += lds[((int64_t)r * C + c) * 2]; b += lds[((int64_t)r * C + c) * 2 + 1]; }
-    float* o = partials + (((int64_t)n * nsplit + sp) * G + g) * 2;
-    o[0] = a; o[1] = b;
+  int TPO = 1;
+  while (TPO * 2 * (2 * G) <= GN_THREADS && TPO < 64) TPO *= 2;
+  float* pout = partials + (((int64_t)n * nsplit + sp) * G_all + (int64_t)blockIdx.y * G) * 2;
+  for (int o0 = 0; o0 < 2 * G; o0 += GN_THREADS / TPO) {
+    const int o = o0 + tid / TPO, part = tid % TPO;
+    float a = 0.f;
+    if (o < 2 * G) {
+      const int g = o >> 1, which = o & 1, ne = RP * cpg;
+      for (int e = part; e < ne; e += TPO) {
+        const int r = e / cpg, c = g * cpg + e % cpg;
+        a += lds[((int64_t)r * C + c) * 2 + which];
+      }
+    }
+    for (int d = TPO / 2; d > 0; d >>= 1) a += __shfl_xor(a, d, 64);
+    if (o < 2 * G && part == 0) pout[o] = a;
   }
 }
 
-// one wavefront per (instance, group): lanes stride over the row-chunk partials, f64 accumulate, shuffle reduce
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partials, float* __restrict__ stats, int N, int G,
-                                                          int nsplit, double count, float eps) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (i >= N * G) return;
-  const int n = i / G, g = i % G;
-  double a = 0.0, b = 0.0;
-  for (int sp = lane; sp < nsplit; sp += 64) {
-    const float* p = partials + (((int64_t)n * nsplit + sp) * G + g) * 2;
-    a += (double)p[0]; b += (double)p[1];
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-  if (lane == 0) {
-    double mean = a / count;
-    double var = b / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[2 * i] = (float)mean;
-    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
-  }
-}
+static constexpr int GN_MAXG = 128;   // groups held in the apply pass's LDS statistics table
 
 template <typename T>
-__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ stats,
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ partials,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              T* __restrict__ y, int ldy, int64_t S, int C, int G, int nsplit, int silu) {
+                                                              T* __restrict__ y, int ldy, int64_t S, int C, int G, int G_all,
+                                                              int nsplit_stats, int nsplit, double count, float eps, int silu) {
   constexpr int V = TT<T>::VEC;
+  __shared__ float s_stats[GN_MAXG * 2];
   const int n = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  x += (int64_t)blockIdx.y * C; y += (int64_t)blockIdx.y * C;
+  gamma += (int64_t)blockIdx.y * C; beta += (int64_t)blockIdx.y * C;
   const int CV = C / V, cpg = C / G;
   const int64_t rows_per = (S + nsplit - 1) / nsplit;
   const int64_t s0 = sp * rows_per;
@@ -146,38 +169,88 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
   const int tid = threadIdx.x;
   const T* xb = x + (int64_t)n * S * ldx;
   T* yb = y + (int64_t)n * S * ldy;
-  const float* st = stats + (int64_t)n * G * 2;
-  if (CV <= GN_THREADS) {
-    const int RP = GN_THREADS / CV, r = tid / CV, cv = tid % CV;
-    if (r >= RP) return;
+  // the loads that do not depend on the statistics are issued BEFORE the statistics prologue: gamma / beta and the first
+  // 4 rows of this thread (one memory round trip overlapped instead of three in a row)
+  const bool narrow = CV <= GN_THREADS;
+  const int RP = narrow ? GN_THREADS / CV : 1, r = narrow ? tid / CV : 0, cv = narrow ? tid % CV : 0;
+  const bool active = narrow && r < RP;
+  const T* xc = xb + cv * V;
+  T* yc = yb + cv * V;
+  float gm[V], bt[V];
+  uint4 v[4];
+  int64_t s = s0 + r;
+  bool have = active && s + 3 * RP < s1;
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < V; e += 4) {
+      *(float4*)(gm + e) = *(const float4*)(gamma + cv * V + e);
+      *(float4*)(bt + e) = *(const float4*)(beta + cv * V + e);
+    }
+  }
+  if (have) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = *(const uint4*)(xc + (s + u * RP) * ldx);
+  }
+  // ---- prologue: (mean, rstd) of this instance's groups from the chunk partials: TPG adjacent lanes per group, each a
+  // strided f64 sum, then a shuffle tree - the same order in every block
+  {
+    int TPG = 1;
+    while (TPG * 2 * G <= GN_THREADS && TPG < 64) TPG *= 2;
+    const float* pin = partials + ((int64_t)n * nsplit_stats * G_all + (int64_t)blockIdx.y * G) * 2;
+    for (int g0 = 0; g0 < G; g0 += GN_THREADS / TPG) {
+      const int g = g0 + tid / TPG, part = tid % TPG;
+      double a = 0.0, b = 0.0;
+      if (g < G)
+        for (int q = part; q < nsplit_stats; q += TPG) {
+          const float2 pv = *(const float2*)(pin + ((int64_t)q * G_all + g) * 2);
+          a += (double)pv.x; b += (double)pv.y;
+        }
+      for (int d = TPG / 2; d > 0; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+      if (g < G && part == 0) {
+        const double mean = a / count;
+        double var = b / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_stats[2 * g] = (float)mean;
+        s_stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+      }
+    }
+    __syncthreads();
+  }
+  if (narrow) {
+    if (!active) return;
     float a[V], b[V];
 #pragma unroll
     for (int e = 0; e < V; e++) {
-      int c = cv * V + e, g = c / cpg;
-      float mean = st[2 * g], rstd = st[2 * g + 1];
-      a[e] = rstd * gamma[c]; b[e] = beta[c] - mean * a[e];
+      const int g = (cv * V + e) / cpg;
+      const float mean = s_stats[2 * g], rstd = s_stats[2 * g + 1];
+      a[e] = rstd * gm[e]; b[e] = bt[e] - mean * a[e];
     }
-    int64_t s = s0 + r;
-    for (; s + RP < s1; s += 2 * RP) {   // 2 rows in flight per thread
-      uint4 v0 = *(const uint4*)(xb + s * ldx + cv * V);
-      uint4 v1 = *(const uint4*)(xb + (s + RP) * ldx + cv * V);
-      float f[V], h[V];
-      unpack16<T>(v0, f);
-      unpack16<T>(v1, h);
+    while (have) {   // the next 4 rows are requested before the current 4 are normalised and stored
+      const int64_t sn = s + 4 * RP;
+      const bool hn = sn + 3 * RP < s1;
+      uint4 w[4];
+      if (hn) {
 #pragma unroll
-      for (int e = 0; e < V; e++) {
-        float v = f[e] * a[e] + b[e]; f[e] = silu ? silu_f(v) : v;
-        float u = h[e] * a[e] + b[e]; h[e] = silu ? silu_f(u) : u;
+        for (int u = 0; u < 4; u++) w[u] = *(const uint4*)(xc + (sn + u * RP) * ldx);
       }
-      *(uint4*)(yb + s * ldy + cv * V) = pack16<T>(f);
-      *(uint4*)(yb + (s + RP) * ldy + cv * V) = pack16<T>(h);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        float f[V];
+        unpack16<T>(v[u], f);
+#pragma unroll
+        for (int e = 0; e < V; e++) { const float t = f[e] * a[e] + b[e]; f[e] = silu ? silu_f(t) : t; }
+        *(uint4*)(yc + (s + u * RP) * ldy) = pack16<T>(f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = w[u];
+      s = sn; have = hn;
     }
     for (; s < s1; s += RP) {
       float f[V];
-      unpack16<T>(*(const uint4*)(xb + s * ldx + cv * V), f);
+      unpack16<T>(*(const uint4*)(xc + s * ldx), f);
 #pragma unroll
-      for (int e = 0; e < V; e++) { float v = f[e] * a[e] + b[e]; f[e] = silu ? silu_f(v) : v; }
-      *(uint4*)(yb + s * ldy + cv * V) = pack16<T>(f);
+      for (int e = 0; e < V; e++) { const float t = f[e] * a[e] + b[e]; f[e] = silu ? silu_f(t) : t; }
+      *(uint4*)(yc + s * ldy) = pack16<T>(f);
     }
   } else {
     for (int j = 0; j < GN_MAXJ; j++) {
@@ -187,7 +260,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
 #pragma unroll
       for (int e = 0; e < V; e++) {
         int c = cv * V + e, g = c / cpg;
-        float mean = st[2 * g], rstd = st[2 * g + 1];
+        float mean = s_stats[2 * g], rstd = s_stats[2 * g + 1];
         a[e] = rstd * gamma[c]; b[e] = beta[c] - mean * a[e];
       }
       for (int64_t s = s0; s < s1; s++) {
@@ -207,41 +280,43 @@ static int gn_check(const char* who, int N, int64_t S, int C, int G, int ld, int
   EMO_CHECK(N > 0 && S > 0 && C > 0 && G > 0 && C % G == 0, EMO_ERR_BAD_SHAPE, "%s: N=%d S=%lld C=%d G=%d", who, N, (long long)S, C, G);
   EMO_CHECK(C % V == 0 && ld % V == 0 && ld >= C, EMO_ERR_BAD_SHAPE, "%s: C=%d ld=%d must be multiples of %d", who, C, ld, V);
   EMO_CHECK(C / V <= GN_THREADS * GN_MAXJ, EMO_ERR_UNSUPPORTED, "%s: C=%d too wide", who, C);
+  EMO_CHECK(G <= GN_MAXG, EMO_ERR_UNSUPPORTED, "%s: G=%d groups (max %d)", who, G, GN_MAXG);
   return EMO_OK;
 }
 
-extern "C" int emo_groupnorm_stats(const void* x, int ldx, float* stats, void* partials, int N, int64_t S, int C, int G, float eps,
-                                   int dtype, void* stream) {
-  EMO_CHECK(x && stats && partials, EMO_ERR_NULL, "emo_groupnorm_stats: null pointer");
+extern "C" int emo_groupnorm_stats(const void* x, int ldx, void* partials, int N, int64_t S, int C, int G, int dtype, void* stream) {
+  EMO_CHECK(x && partials, EMO_ERR_NULL, "emo_groupnorm_stats: null pointer");
   int rc = gn_check("emo_groupnorm_stats", N, S, C, G, ldx, dtype);
   if (rc) return rc;
-  const int nsplit = gn_nsplit(S);
-  const int V = dtype == EMO_F32 ? 4 : 8, CV = C / V;
-  const int RP = CV <= GN_THREADS ? GN_THREADS / CV : 1;
-  const size_t lds = (size_t)RP * C * 2 * sizeof(float);
+  const GnGeom gg = gn_geom(N, S, C, G, dtype == EMO_F32 ? 4 : 8);
+  const size_t lds = (size_t)gg.RP * gg.Cp * 2 * sizeof(float);
   EMO_CHECK(lds <= 64 * 1024, EMO_ERR_UNSUPPORTED, "emo_groupnorm_stats: LDS %zu", lds);
   hipStream_t st = as_stream(stream);
-  if (dtype == EMO_F32) gn_partial_kernel<float><<<N * nsplit, GN_THREADS, lds, st>>>((const float*)x, ldx, (float*)partials, S, C, G, nsplit);
-  else gn_partial_kernel<bf16_t><<<N * nsplit, GN_THREADS, lds, st>>>((const bf16_t*)x, ldx, (float*)partials, S, C, G, nsplit);
-  EMO_LAUNCH_CHECK();
-  gn_finalize_kernel<<<(N * G + 3) / 4, 256, 0, st>>>((const float*)partials, stats, N, G, nsplit, (double)S * (C / G), eps);
+  const dim3 grid((unsigned)(N * gg.nsplit_stats), (unsigned)gg.NC);
+  if (dtype == EMO_F32) gn_stats_kernel<float><<<grid, GN_THREADS, lds, st>>>((const float*)x, ldx, (float*)partials, S, gg.Cp, gg.Gp, G, gg.nsplit_stats);
+  else gn_stats_kernel<bf16_t><<<grid, GN_THREADS, lds, st>>>((const bf16_t*)x, ldx, (float*)partials, S, gg.Cp, gg.Gp, G, gg.nsplit_stats);
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
 
-extern "C" int emo_groupnorm_apply(const void* x, int ldx, const float* stats, const float* gamma, const float* beta, void* y,
-                                   int ldy, int N, int64_t S, int C, int G, int silu, int dtype, void* stream) {
-  EMO_CHECK(x && stats && gamma && beta && y, EMO_ERR_NULL, "emo_groupnorm_apply: null pointer");
+extern "C" int emo_groupnorm_apply(const void* x, int ldx, const void* partials, const float* gamma, const float* beta, void* y,
+                                   int ldy, int N, int64_t S, int C, int G, float eps, int silu, int dtype, void* stream) {
+  EMO_CHECK(x && partials && gamma && beta && y, EMO_ERR_NULL, "emo_groupnorm_apply: null pointer");
   int rc = gn_check("emo_groupnorm_apply", N, S, C, G, ldx, dtype);
   if (rc) return rc;
   rc = gn_check("emo_groupnorm_apply", N, S, C, G, ldy, dtype);
   if (rc) return rc;
-  // more, smaller chunks than the stats pass: this pass is pure streaming
-  int64_t want = (S + 7) / 8; if (want > 1024) want = 1024; if (want < 1) want = 1;
-  const int nsplit = (int)want;
+  EMO_CHECK(((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0, EMO_ERR_BAD_SHAPE, "emo_groupnorm_apply: gamma/beta alignment");
+  const GnGeom gg = gn_geom(N, S, C, G, dtype == EMO_F32 ? 4 : 8);
+  const double count = (double)S * (C / G);
   hipStream_t st = as_stream(stream);
-  if (dtype == EMO_F32) gn_apply_kernel<float><<<N * nsplit, GN_THREADS, 0, st>>>((const float*)x, ldx, stats, gamma, beta, (float*)y, ldy, S, C, G, nsplit, silu);
-  else gn_apply_kernel<bf16_t><<<N * nsplit, GN_THREADS, 0, st>>>((const bf16_t*)x, ldx, stats, gamma, beta, (bf16_t*)y, ldy, S, C, G, nsplit, silu);
+  const dim3 grid((unsigned)(N * gg.nsplit_apply), (unsigned)gg.NC);
+  if (dtype == EMO_F32)
+    gn_apply_kernel<float><<<grid, GN_THREADS, 0, st>>>((const float*)x, ldx, (const float*)partials, gamma, beta, (float*)y, ldy, S, gg.Cp, gg.Gp, G,
+                                                         gg.nsplit_stats, gg.nsplit_apply, count, eps, silu);
+  else
+    gn_apply_kernel<bf16_t><<<grid, GN_THREADS, 0, st>>>((const bf16_t*)x, ldx, (const float*)partials, gamma, beta, (bf16_t*)y, ldy, S, gg.Cp,
+                                                          gg.Gp, G, gg.nsplit_stats, gg.nsplit_apply, count, eps, silu);
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }

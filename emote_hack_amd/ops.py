@@ -177,15 +177,13 @@ def group_norm(x: torch.Tensor, gamma, beta, n_inst: int, groups: int, eps: floa
     px, ldx = _rows(x)
     ws = lib.emo_groupnorm_workspace_bytes(n_inst, S, Cc, groups)
     part = torch.empty(max(ws // 4, 1), device=x.device, dtype=torch.float32)
-    stats = torch.empty(n_inst * groups * 2, device=x.device, dtype=torch.float32)
     y = torch.empty(M, Cc, device=x.device, dtype=x.dtype) if out is None else out
     py, ldy = _rows(y)
 
     def run():
-        check(lib.emo_groupnorm_stats(px, ldx, _ptr(stats), _ptr(part), n_inst, S, Cc, groups, float(eps), dt(x), _stream()),
-              "emo_groupnorm_stats")
-        check(lib.emo_groupnorm_apply(px, ldx, _ptr(stats), _ptr(gamma), _ptr(beta), py, ldy, n_inst, S, Cc, groups, int(silu_),
-                                      dt(x), _stream()), "emo_groupnorm_apply")
+        check(lib.emo_groupnorm_stats(px, ldx, _ptr(part), n_inst, S, Cc, groups, dt(x), _stream()), "emo_groupnorm_stats")
+        check(lib.emo_groupnorm_apply(px, ldx, _ptr(part), _ptr(gamma), _ptr(beta), py, ldy, n_inst, S, Cc, groups, float(eps),
+                                      int(silu_), dt(x), _stream()), "emo_groupnorm_apply")
     _launch("groupnorm", 0.0, x.element_size() * 2.0 * M * Cc, run)   # algorithmic: one read + one write
     return y
 

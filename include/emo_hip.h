@@ -75,13 +75,16 @@ int emo_timestep_embedding(const int64_t* timesteps, const float* freqs, void* o
  * GroupNorm over NHWC rows.  An "instance" is a contiguous run of S rows normalised together:
  *   5-D joint statistics (resnet.py:180,191; unet_controlnet.py:476): N=B,   S=F*H*W
  *   per-frame            (attention.py:124; motion_module.py:147)   : N=B*F, S=H*W
- * emo_groupnorm_stats writes (mean, rstd) f32 pairs [N][G][2]; `partials` is a caller workspace of
- * emo_groupnorm_workspace_bytes(N, S, C, G) bytes.  emo_groupnorm_apply normalises (+SiLU). */
+ * Two launches: emo_groupnorm_stats writes row-chunk partial (sum, sumsq) per group into `partials` (caller
+ * workspace of emo_groupnorm_workspace_bytes(N, S, C, G) bytes); emo_groupnorm_apply combines them in f64 in a
+ * fixed order (deterministic; every block recomputes the same (mean, rstd)) and normalises (+SiLU).
+ * gamma / beta are f32, 16-byte aligned. */
 size_t emo_groupnorm_workspace_bytes(int N, int64_t S, int C, int G);
-int emo_groupnorm_stats(const void* x, int ldx, float* stats, void* partials, int N, int64_t S, int C, int G,
-                        float eps, int dtype, void* stream);
-int emo_groupnorm_apply(const void* x, int ldx, const float* stats, const float* gamma, const float* beta,
-                        void* y, int ldy, int N, int64_t S, int C, int G, int silu, int dtype, void* stream);
+int emo_groupnorm_stats(const void* x, int ldx, void* partials, int N, int64_t S, int C, int G, int dtype,
+                        void* stream);
+int emo_groupnorm_apply(const void* x, int ldx, const void* partials, const float* gamma, const float* beta,
+                        void* y, int ldy, int N, int64_t S, int C, int G, float eps, int silu, int dtype,
+                        void* stream);
 
 /* LayerNorm over the last dim (attention.py:279-316, motion_module.py:216-224), eps 1e-5 default.
  * Optional fused temporal positional-encoding add (motion_module.py:246-248,282-283):
