@@ -264,18 +264,26 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
       constexpr int n_side = n_rd + (g_end - g_begin);
       static_for<NMMA>([&](auto Q) {
         constexpr int q = decltype(Q)::value, i = q / WTN, j = q % WTN;
+#ifndef EMO_ABL_NOMMA
         if constexpr (TRANS) acc[i][j] = mma16<T>(fa[cur][i], fb[cur][j], acc[i][j]);   // rows = m, lane = n
         else acc[i][j] = mma16<T>(fb[cur][j], fa[cur][i], acc[i][j]);                   // rows = n, lane = m
+#endif
         __builtin_amdgcn_sched_barrier(0);
         static_for<n_side>([&](auto O) {
           constexpr int o = decltype(O)::value;
           if constexpr ((o * NMMA) / n_side == q) {
             if constexpr (o < n_rd) {
+#ifndef EMO_ABL_NOREAD
               if constexpr (o < WTM) fa[nxt][o] = lds_read16(st + fa_off[o][(kk + 1) % KSTEPS]);
               else fb[nxt][o - WTM] = lds_read16(st + fb_off[o - WTM][(kk + 1) % KSTEPS]);
+#endif
             } else {
               constexpr int g = g_begin + (o - n_rd);
+#ifdef EMO_ABL_NOLOAD
+              if (false) {
+#else
               if (more) {
+#endif
                 if constexpr (g < LA) issue_a(kt_next, slot_next, std::integral_constant<int, g>{});
                 else issue_b(kt_next, slot_next, std::integral_constant<int, g - LA>{});
               }
@@ -345,8 +353,13 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
             }
 #pragma unroll
             for (int e = 0; e < 4; e++) o[e] *= p.out_scale;
+#ifdef EMO_ABL_NOSTORE
+            if (o[0] == 123.456f)
+#endif
+            {
             if constexpr (sizeof(T) == 2) *(uint2*)(C + m * p.ldc + no0) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
             else *(float4*)(C + m * p.ldc + no0) = make_float4(o[0], o[1], o[2], o[3]);
+            }
           } else {   // ragged N / unaligned leading dims: scalar path
 #pragma unroll
             for (int e = 0; e < 4; e++) {
@@ -487,7 +500,10 @@ static GemmPlan plan_gemm(int64_t M, int N, int K, int dtype, int geglu, int tra
   // 256x256 / 8 waves for the big compute-bound shapes (N a multiple of 256, or wide enough that the ragged last
   // tile is small), else 128x160 when N is a multiple of 160 (every SD-1.5 width), else 128x128
   const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
-  pl.big = (dtype == EMO_BF16 && tiles256 >= 224 && (N % 256 == 0 || N >= 1792)) ? 1 : 0;
+  const int bk = KBYTES / (dtype == EMO_F32 ? 4 : 2);
+  const int nk = (K + bk - 1) / bk;
+  static const int big_min_nk = env_int("EMO_GEMM_BIG_MINNK", 0);
+  pl.big = (dtype == EMO_BF16 && tiles256 >= 224 && (N % 256 == 0 || N >= 1792) && nk >= big_min_nk) ? 1 : 0;
   pl.nt5 = (!pl.big && !geglu && N % 160 == 0) ? 1 : 0;
   pl.small = 0;
   if (pl.nt5 && N % 128 == 0) {
@@ -500,8 +516,6 @@ static GemmPlan plan_gemm(int64_t M, int N, int K, int dtype, int geglu, int tra
     static const int force = env_int("EMO_GEMM_TILE", 0);
     if (force == 4 || (force == 0 && f4 * 1.05 >= f5)) pl.nt5 = 0;
   }
-  const int bk = KBYTES / (dtype == EMO_F32 ? 4 : 2);
-  const int nk = (K + bk - 1) / bk;
   // fewer 128-row blocks than CUs and a short K (the 8x8 / 16x16 levels, the ReferenceNet pass): splitting K pays an f32
   // round trip + a second launch and a block is mostly prologue + epilogue -> 64x64 tiles (4 waves of 32x32, 32 KB of
   // LDS: ~4 co-resident blocks per CU overlap each other's prologue/epilogue).  They read 2 LDS fragments per MFMA, so
