@@ -62,6 +62,10 @@ template <int WTM, int WTN, int WVM, int WVN, int NS_> struct GemmTile {
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   static constexpr int LDS_BYTES = NS * STAGE_BYTES;
   static constexpr int LA = A_ROWS / RPI, LB = B_ROWS / RPI, LPS = LA + LB;   // glds per wave per stage
+  // co-resident blocks per CU the launch is sized for (by LDS, <= 4) and the waves per SIMD that needs: the register
+  // budget handed to the compiler (the persistent loop keeps the loader state live across the epilogue)
+  static constexpr int BPC = (160 * 1024 / LDS_BYTES) > 4 ? 4 : ((160 * 1024 / LDS_BYTES) < 1 ? 1 : (160 * 1024 / LDS_BYTES));
+  static constexpr int WPE = (BPC * NW + 3) / 4;
 };
 
 #define EMO_GLDS16(gptr, lptr) \
@@ -78,7 +82,7 @@ __device__ __forceinline__ uint4 lds_read16(unsigned addr) {
 struct ConvRow { int img, iy0, ix0; };
 
 template <typename T, bool CONV, bool TRANS, int WTM, int WTN, int WVM, int WVN, int NS>
-__global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_params p) {
+__global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::WPE)) void gemm_kernel(const emo_gemm_params p) {
   using Tile = GemmTile<WTM, WTN, WVM, WVN, NS>;
   constexpr int NW = Tile::NW;
   constexpr int V = TT<T>::VEC;          // elements per 16 B
@@ -91,66 +95,74 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
   const int wvm = wave / WVN, wvn = wave % WVN;
   const int half = lane >> 5, l31 = lane & 31;
   const int tiles_n = (p.N + BN - 1) / BN;
-  // XCD-aware tile order (bijective): XCD x = b % 8 owns a contiguous run of tiles
-  int tile;
-  {
-    const int nt_all = gridDim.x, b = blockIdx.x;
-    const int qn = nt_all >> 3, rn = nt_all & 7, x = b & 7, idx = b >> 3;
-    tile = (x < rn ? x * (qn + 1) : rn * (qn + 1) + (x - rn) * qn) + idx;
-  }
-  const int64_t bm = (int64_t)(tile / tiles_n) * BM;
-  const int bn = (tile % tiles_n) * BN;
+  const int tiles_m = (int)((p.M + BM - 1) / BM);
+  const int tiles_all = tiles_m * tiles_n;
+  const int G = gridDim.x;                     // persistent: block b works tiles b, b+G, b+2G, ... of the XCD-aware order
+  // XCD-aware tile order (bijective): stream index i runs on XCD i % 8 (G is a multiple of 8 whenever a block has more
+  // than one tile); XCD x owns a contiguous run of tiles (n fastest), so the A rows it re-reads stay in that XCD's L2
+  auto tile_of = [&](int i) {
+    const int qn = tiles_all >> 3, rn = tiles_all & 7, x = i & 7, idx = i >> 3;
+    return (x < rn ? x * (qn + 1) : rn * (qn + 1) + (x - rn) * qn) + idx;
+  };
   const int nsplit = p.split_k > 1 ? p.split_k : 1;
 
   const T* __restrict__ A = (const T*)p.A;
   const T* __restrict__ W = (const T*)p.W;
   const T* zero = (const T*)g_zero_page;
 
-  // ---- loader geometry: glds #i of this wave fills LDS rows (i*4 + wave)*16 .. +16 of the operand; lane l
-  // writes physical chunk (l&3) of row (l>>2), which holds LOGICAL chunk (l&3) ^ ((row>>2)&3)
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int nk_per = (nk_all + nsplit - 1) / nsplit;
+  const int kt0 = blockIdx.y * nk_per;
+  const int nk = (kt0 + nk_per <= nk_all ? nk_per : nk_all - kt0);   // may be <= 0 for a trailing empty slice
+
+  // ---- loader state.  The loader streams (tile, k-stage) pairs NS-1 stages AHEAD of the MFMA loop and does not stop at
+  // tile boundaries: while a tile's epilogue runs, the first stages of the block's next tile are already in flight.
+  // glds #i of this wave fills LDS rows (i*NW + wave)*(64/CPR) .. of the operand; lane l writes physical chunk l%CPR of
+  // row l/CPR, which holds LOGICAL chunk (l%CPR) ^ swz(row)
   const int lrow = lane / CPR, lchunk = lane % CPR;
-  int a_klog[LA];
-  const T* a_base[LA];    // dense: row pointer (k added per stage); conv: unused
+  int a_klog[LA], b_klog[LB];
+#pragma unroll
+  for (int i = 0; i < LA; i++) a_klog[i] = lchunk ^ swz((i * NW + wave) * (64 / CPR) + lrow);
+#pragma unroll
+  for (int i = 0; i < LB; i++) b_klog[i] = lchunk ^ swz((i * NW + wave) * (64 / CPR) + lrow);
   ConvRow a_cr[LA];
   bool a_ok[LA];
+  const T* a_ptr[LA];     // advanced by a_inc / b_inc (BK or 0 elements) per issued stage: 2 VALU adds per glds
+  const T* b_ptr[LB];
+  int a_inc[LA], b_inc[LB];
+  int l_iter = blockIdx.x, l_kt = 0;   // the loader's tile (stream index) and next stage within the slice
+  auto setup_loader = [&](int iter) {
+    const int tile = tile_of(iter);
+    const int64_t lbm = (int64_t)(tile / tiles_n) * BM;
+    const int lbn = (tile % tiles_n) * BN;
 #pragma unroll
-  for (int i = 0; i < LA; i++) {
-    const int row = (i * NW + wave) * (64 / CPR) + lrow;
-    a_klog[i] = lchunk ^ swz(row);
-    const int64_t m = bm + row;
-    a_ok[i] = row < BM && m < p.M;
-    a_base[i] = A + (a_ok[i] ? m : 0) * p.lda;
-    if (CONV) {
-      const int hw = p.Ho * p.Wo;
-      const int64_t mm = a_ok[i] ? m : 0;
-      const int img = (int)(mm / hw), rem = (int)(mm % hw);
-      const int oy = rem / p.Wo, ox = rem % p.Wo;
-      a_cr[i].img = img; a_cr[i].iy0 = oy * p.stride - 1; a_cr[i].ix0 = ox * p.stride - 1;
+    for (int i = 0; i < LA; i++) {
+      const int row = (i * NW + wave) * (64 / CPR) + lrow;
+      const int64_t m = lbm + row;
+      a_ok[i] = row < BM && m < p.M;
+      if (CONV) {
+        const int hw = p.Ho * p.Wo;
+        const int64_t mm = a_ok[i] ? m : 0;
+        const int img = (int)(mm / hw), rem = (int)(mm % hw);
+        const int oy = rem / p.Wo, ox = rem % p.Wo;
+        a_cr[i].img = img; a_cr[i].iy0 = oy * p.stride - 1; a_cr[i].ix0 = ox * p.stride - 1;
+      }
+      a_ptr[i] = a_ok[i] ? A + m * p.lda + a_klog[i] * V + (int64_t)kt0 * BK : zero;
+      a_inc[i] = a_ok[i] ? BK : 0;
     }
-  }
-  int b_klog[LB];
-  const T* b_ptr[LB];     // advanced by b_inc (BK or 0 elements) per issued stage: 2 VALU adds per glds
-  int b_inc[LB];
 #pragma unroll
-  for (int i = 0; i < LB; i++) {
-    const int row = (i * NW + wave) * (64 / CPR) + lrow;
-    b_klog[i] = lchunk ^ swz(row);
-    const int n = bn + row;
-    const bool ok = row < BN && n < p.N;
-    b_ptr[i] = ok ? W + (int64_t)n * p.K + b_klog[i] * V : zero;
-    b_inc[i] = ok ? BK : 0;
-  }
-  const T* a_ptr[LA];
-  int a_inc[LA];
-#pragma unroll
-  for (int i = 0; i < LA; i++) {
-    a_ptr[i] = a_ok[i] ? a_base[i] + a_klog[i] * V : zero;
-    a_inc[i] = a_ok[i] ? BK : 0;
-  }
+    for (int i = 0; i < LB; i++) {
+      const int row = (i * NW + wave) * (64 / CPR) + lrow;
+      const int n = lbn + row;
+      const bool ok = row < BN && n < p.N;
+      b_ptr[i] = ok ? W + (int64_t)n * p.K + b_klog[i] * V + (int64_t)kt0 * BK : zero;
+      b_inc[i] = ok ? BK : 0;
+    }
+  };
   const bool k_ragged = (p.K % BK) != 0;            // only the very last stage can run past K
   const bool cin_aligned = CONV && (p.Cin % BK) == 0; // a stage then lies inside one 3x3 tap (tap is wave-uniform)
 
-  // one glds of operand A (index i < LA) / B (i < LB) of k-stage kt into ring slot `slot`; stages are issued in order
+  // one glds of operand A (index i < LA) / B (i < LB) of k-stage kt (absolute) into ring slot `slot`
   auto issue_a = [&](int kt, int slot, auto I) {
     constexpr int i = decltype(I)::value;
     unsigned char* sa = lds + slot * Tile::STAGE_BYTES;
@@ -185,23 +197,14 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
     EMO_GLDS16(src, sb + (i * NW + wave) * 1024);
     b_ptr[i] += b_inc[i];
   };
-  auto issue = [&](int kt, int slot) {
-    static_for<LA>([&](auto I) { issue_a(kt, slot, I); });
-    static_for<LB>([&](auto I) { issue_b(kt, slot, I); });
+  // after the last glds of a stage: step the loader to the next stage of the stream (next tile when this one is done)
+  auto advance_loader = [&]() {
+    if (++l_kt >= nk) {
+      l_kt = 0;
+      l_iter += G;
+      if (l_iter < tiles_all) setup_loader(l_iter);
+    }
   };
-
-  f32x16 acc[WTM][WTN];
-#pragma unroll
-  for (int i = 0; i < WTM; i++)
-#pragma unroll
-    for (int j = 0; j < WTN; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-  const int nk_all = (p.K + BK - 1) / BK;
-  const int nk_per = (nk_all + nsplit - 1) / nsplit;
-  const int kt0 = blockIdx.y * nk_per;
-  const int nk = (kt0 + nk_per <= nk_all ? nk_per : nk_all - kt0);   // may be <= 0 for a trailing empty slice
 
   // fragment read addresses (LDS byte offsets, stage-relative), swizzled
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
@@ -219,20 +222,42 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
     for (int kk = 0; kk < KSTEPS; kk++) fb_off[j][kk] = Tile::A_BYTES + r * KBYTES + (((kk * 2 + half) ^ swz(r)) * 16);
   }
 
-  if (kt0 > 0) {   // split-K slice: start the incremental pointers at this slice's first stage
+  T* __restrict__ C = (T*)p.C;
+  const T* __restrict__ R = (const T*)p.residual;
+
+  // stream prologue: NS-1 stages in flight
+  int gs = 0;   // stream stage counter of the MFMA loop (ring slot = gs % NS)
+  if (nk > 0) {
+    setup_loader(l_iter);
 #pragma unroll
-    for (int i = 0; i < LA; i++) a_ptr[i] += (int64_t)kt0 * a_inc[i];
-#pragma unroll
-    for (int i = 0; i < LB; i++) b_ptr[i] += (int64_t)kt0 * b_inc[i];
+    for (int s = 0; s < NS - 1; s++)
+      if (l_iter < tiles_all) {
+        static_for<LA>([&](auto I) { issue_a(kt0 + l_kt, s, I); });
+        static_for<LB>([&](auto I) { issue_b(kt0 + l_kt, s, I); });
+        advance_loader();
+      }
   }
+
+  for (int c_iter = blockIdx.x; c_iter < tiles_all; c_iter += G) {
+  const int c_tile = tile_of(c_iter);
+  const int64_t bm = (int64_t)(c_tile / tiles_n) * BM;
+  const int bn = (c_tile % tiles_n) * BN;
+  const int tiles_left = (tiles_all - 1 - c_iter) / G;   // tiles of this block after this one
+
+  f32x16 acc[WTM][WTN];
 #pragma unroll
-  for (int s = 0; s < NS - 1; s++)
-    if (s < nk) issue(kt0 + s, s);
-  for (int kt = 0; kt < nk; kt++) {
-    // stage kt must have landed; up to min(NS-2, nk-1-kt) younger stages may still be in flight
-    const int rem = nk - 1 - kt;
-    if (rem >= NS - 2) wait_vmcnt<(NS - 2) * LPS>();
-    else if (NS > 3 && rem >= 1) {   // draining: rem younger stages in flight
+  for (int i = 0; i < WTM; i++)
+#pragma unroll
+    for (int j = 0; j < WTN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  for (int kt = 0; kt < nk; kt++, gs++) {
+    // stage gs must have landed; up to NS-2 younger stages may still be in flight - fewer at the end of the stream, and none
+    // are counted on at a tile's first stage: the previous tile's epilogue stores sit in the same counter
+    const int rem = nk - 1 - kt + tiles_left * nk;   // younger stages of this block's stream still to come
+    if (rem >= NS - 2 && (kt > 0 || c_iter == (int)blockIdx.x)) wait_vmcnt<(NS - 2) * LPS>();
+    else if (NS > 3 && rem >= 1 && kt > 0) {   // draining: rem younger stages in flight
       if (rem == 1) wait_vmcnt<LPS>();
       else if (NS > 4 && rem == 2) wait_vmcnt<2 * LPS>();
       else if (NS > 5 && rem == 3) wait_vmcnt<3 * LPS>();
@@ -241,10 +266,10 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
       else wait_vmcnt<0>();
     }
     else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();   // everyone's part of stage kt landed; everyone finished reading slot (kt-1)%NS
-    const unsigned st = lds_base + (kt % NS) * Tile::STAGE_BYTES;
-    const bool more = kt + NS - 1 < nk;
-    const int kt_next = kt0 + kt + NS - 1, slot_next = (kt + NS - 1) % NS;
+    __builtin_amdgcn_s_barrier();   // everyone's part of stage gs landed; everyone finished reading slot (gs-1)%NS
+    const unsigned st = lds_base + (gs % NS) * Tile::STAGE_BYTES;
+    const bool more = l_iter < tiles_all;
+    const int kt_next = kt0 + l_kt, slot_next = (gs + NS - 1) % NS;
     // Software-pipelined stage: the only exposed latency is the first k-step's fragment read.  The fragment reads
     // of step kk+1 and the next ring stage's glds (with their address arithmetic) are issued one at a time BETWEEN the
     // MFMAs of step kk, so their issue cost and latency hide under the matrix pipe.
@@ -254,6 +279,14 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
 #pragma unroll
     for (int j = 0; j < WTN; j++) fb[0][j] = lds_read16(st + fb_off[j][0]);
     constexpr int NMMA = WTM * WTN, NRD = WTM + WTN;
+#ifndef EMO_LATE_ISSUE
+    // the whole next ring stage is requested right behind the barrier: it then has this stage's full MFMA time to land
+    // (spreading the glds between the MFMAs left the last ones ~no time: +10-20 % on the K >= 2560 shapes, 8192^3 980 -> 1130 TF/s)
+    if (more) {
+      static_for<LA>([&](auto I) { issue_a(kt_next, slot_next, I); });
+      static_for<LB>([&](auto I) { issue_b(kt_next, slot_next, I); });
+    }
+#endif
     static_for<KSTEPS>([&](auto KK) {
       constexpr int kk = decltype(KK)::value, cur = kk & 1, nxt = cur ^ 1;
       wait_lgkmcnt<0>();                       // fragments of step kk
@@ -279,7 +312,7 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
 #endif
             } else {
               constexpr int g = g_begin + (o - n_rd);
-#ifdef EMO_ABL_NOLOAD
+#if defined(EMO_ABL_NOLOAD) || !defined(EMO_LATE_ISSUE)
               if (false) {
 #else
               if (more) {
@@ -293,10 +326,9 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
         __builtin_amdgcn_sched_barrier(0);
       });
     });
+    if (more) advance_loader();
   }
 
-  T* __restrict__ C = (T*)p.C;
-  const T* __restrict__ R = (const T*)p.residual;
   const int64_t wm0 = bm + wvm * 32 * WTM;
   const int wn0 = bn + wvn * 32 * WTN;
 
@@ -425,6 +457,7 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_kernel(const emo_gemm_par
         }
       }
   }
+  }   // tiles of this block
 }
 
 // split-K second pass: fixed-order reduction of the f32 partials + the same fused epilogue; a thread owns 4 consecutive
@@ -561,12 +594,27 @@ static int launch_gemm(const emo_gemm_params& p, int S, hipStream_t st) {
   }
   const int64_t tiles = ((p.M + Tile::BM - 1) / Tile::BM) * ((p.N + Tile::BN - 1) / Tile::BN);
   if (tiles >= (1ll << 31)) return emo_fail(EMO_ERR_BAD_SHAPE, "emo_gemm: too many tiles");
-  dim3 grid((unsigned)tiles, (unsigned)S);
+  // persistent launch: as many blocks as the chip holds at once (by LDS, <= 4 per CU), each walking its tiles; a
+  // multiple of 8 so that a block's tiles all map to its own XCD
+  static const int persist = env_int("EMO_GEMM_PERSIST", 1);
+  int64_t slots = (256 * Tile::BPC / S) & ~7;
+  if (slots < 8) slots = 8;
+  const int64_t gx = (persist && tiles > slots) ? slots : tiles;
+  dim3 grid((unsigned)gx, (unsigned)S);
   kern<<<grid, Tile::THREADS, Tile::LDS_BYTES, st>>>(p);
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
 
+#ifndef EMO_NS11
+#define EMO_NS11 2
+#endif
+#ifndef EMO_NS15
+#define EMO_NS15 2
+#endif
+#ifndef EMO_NS22
+#define EMO_NS22 2
+#endif
 template <typename T, bool CONV, bool TRANS>
 static int dispatch_tile(const emo_gemm_params& p, const GemmPlan& pl, int S, hipStream_t st) {
   // (4-wave 128x256 / 256x128 tiles were measured 15-35 % slower than the 8-wave 256x256 at equal LDS traffic per MFMA)
@@ -574,8 +622,8 @@ static int dispatch_tile(const emo_gemm_params& p, const GemmPlan& pl, int S, hi
   return launch_gemm<T, CONV, TRANS, 2, 2, 2, 2, EMO_NS22>(p, S, st);
 #endif
   if (pl.big && S == 1) return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, 2>(p, S, st);   // 2x4 waves of 128x64, 2 x 64 KB ring
-  if (pl.small) return launch_gemm<T, CONV, TRANS, 1, 1, 2, 2, 2>(p, S, st);   // 2x2 waves of 32x32, 2 x 16 KB ring
-  if (pl.nt5) return launch_gemm<T, CONV, TRANS, 1, 5, 4, 1, 2>(p, S, st);   // 4x1 waves of 32x160, 2 x 36 KB ring
+  if (pl.small) return launch_gemm<T, CONV, TRANS, 1, 1, 2, 2, EMO_NS11>(p, S, st);   // 2x2 waves of 32x32, 2 x 16 KB ring
+  if (pl.nt5) return launch_gemm<T, CONV, TRANS, 1, 5, 4, 1, EMO_NS15>(p, S, st);   // 4x1 waves of 32x160, 2 x 36 KB ring
 #ifndef EMO_NS22
 #define EMO_NS22 2
 #endif
