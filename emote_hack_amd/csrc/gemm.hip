@@ -79,6 +79,76 @@ __device__ __forceinline__ uint4 lds_read16(unsigned addr) {
   return v;
 }
 
+// Row-major fused epilogue of one 32-row MFMA tile row (lane <-> output row m; register quad g of tile j <-> columns
+// j*32 + 8*g + 4*half + {0..3}): bias, per-batch row bias, GEGLU, residual, scale, 8-byte (bf16) / 16-byte (f32) stores.
+template <typename T, int WTN>
+__device__ __forceinline__ void epilogue_row(const f32x16 (&acc)[WTN], const emo_gemm_params& p, int64_t m, bool m_ok, int wn0, int half,
+                                             T* __restrict__ C, const T* __restrict__ R) {
+  const float* rbias = (p.rowbias && m_ok) ? p.rowbias + (m / p.rows_per_batch) * p.ld_rowbias : nullptr;
+  const int n_out = p.geglu ? p.N / 2 : p.N;
+  const bool vec_ok = (p.N & 3) == 0 && ((p.ldc | (R ? p.ldr : 0)) & 3) == 0 && (!p.rowbias || (p.ld_rowbias & 3) == 0);
+#pragma unroll
+  for (int j = 0; j < WTN; j++) {
+    if (p.geglu && (j & 1)) continue;   // gate tile is consumed with its value tile
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int nw0 = wn0 + j * 32 + 8 * g + 4 * half;              // column in W-row space
+      const int no0 = p.geglu ? ((wn0 + j * 32) >> 1) + 8 * g + 4 * half : nw0;   // output column
+      if (nw0 >= p.N) continue;
+      float o[4] = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+      if (vec_ok) {   // the whole quad is in range (N % 4 == 0)
+        if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
+        if (rbias) { const float4 b4 = *(const float4*)(rbias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
+        if (p.geglu) {
+          float gt[4] = {acc[(j + 1) % WTN][4 * g], acc[(j + 1) % WTN][4 * g + 1], acc[(j + 1) % WTN][4 * g + 2],
+                         acc[(j + 1) % WTN][4 * g + 3]};
+          if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0 + 32); gt[0] += b4.x; gt[1] += b4.y; gt[2] += b4.z; gt[3] += b4.w; }
+#pragma unroll
+          for (int e = 0; e < 4; e++) o[e] *= gelu_for<T>(gt[e]);
+        }
+        if (!m_ok) continue;
+        if (R) {
+          if constexpr (sizeof(T) == 2) {
+            const uint2 rv = *(const uint2*)(R + m * p.ldr + no0);
+            o[0] += __uint_as_float(rv.x << 16); o[1] += __uint_as_float(rv.x & 0xffff0000u);
+            o[2] += __uint_as_float(rv.y << 16); o[3] += __uint_as_float(rv.y & 0xffff0000u);
+          } else {
+            const float4 rv = *(const float4*)(R + m * p.ldr + no0);
+            o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] *= p.out_scale;
+#ifdef EMO_ABL_NOSTORE
+        if (o[0] == 123.456f)
+#endif
+        {
+        if constexpr (sizeof(T) == 2) *(uint2*)(C + m * p.ldc + no0) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+        else *(float4*)(C + m * p.ldc + no0) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      } else {   // ragged N / unaligned leading dims: scalar path
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int nw = nw0 + e;
+          if (nw >= p.N || !m_ok) continue;
+          float v = o[e];
+          if (p.bias) v += p.bias[nw];
+          if (rbias) v += rbias[nw];
+          if (p.geglu) {
+            float gt = acc[(j + 1) % WTN][4 * g + e];
+            if (p.bias) gt += p.bias[nw + 32];
+            v *= gelu_for<T>(gt);
+          }
+          if (no0 + e < n_out) {
+            if (R) v += TT<T>::ld(R + m * p.ldr + no0 + e);
+            TT<T>::st(C + m * p.ldc + no0 + e, v * p.out_scale);
+          }
+        }
+      }
+    }
+  }
+}
+
 struct ConvRow { int img, iy0, ix0; };
 
 template <typename T, bool CONV, bool TRANS, int WTM, int WTN, int WVM, int WVN, int NS>
@@ -350,69 +420,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
           }
         continue;
       }
-      const float* rbias = (p.rowbias && m_ok) ? p.rowbias + (m / p.rows_per_batch) * p.ld_rowbias : nullptr;
-      const int n_out = p.geglu ? p.N / 2 : p.N;
-      const bool vec_ok = (p.N & 3) == 0 && ((p.ldc | (R ? p.ldr : 0)) & 3) == 0 && (!p.rowbias || (p.ld_rowbias & 3) == 0);
-#pragma unroll
-      for (int j = 0; j < WTN; j++) {
-        if (p.geglu && (j & 1)) continue;   // gate tile is consumed with its value tile
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const int nw0 = wn0 + j * 32 + 8 * g + 4 * half;              // column in W-row space
-          const int no0 = p.geglu ? ((wn0 + j * 32) >> 1) + 8 * g + 4 * half : nw0;   // output column
-          if (nw0 >= p.N) continue;
-          float o[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          if (vec_ok) {   // the whole quad is in range (N % 4 == 0)
-            if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
-            if (rbias) { const float4 b4 = *(const float4*)(rbias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
-            if (p.geglu) {
-              float gt[4] = {acc[i][(j + 1) % WTN][4 * g], acc[i][(j + 1) % WTN][4 * g + 1], acc[i][(j + 1) % WTN][4 * g + 2],
-                             acc[i][(j + 1) % WTN][4 * g + 3]};
-              if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0 + 32); gt[0] += b4.x; gt[1] += b4.y; gt[2] += b4.z; gt[3] += b4.w; }
-#pragma unroll
-              for (int e = 0; e < 4; e++) o[e] *= gelu_for<T>(gt[e]);
-            }
-            if (!m_ok) continue;
-            if (R) {
-              if constexpr (sizeof(T) == 2) {
-                const uint2 rv = *(const uint2*)(R + m * p.ldr + no0);
-                o[0] += __uint_as_float(rv.x << 16); o[1] += __uint_as_float(rv.x & 0xffff0000u);
-                o[2] += __uint_as_float(rv.y << 16); o[3] += __uint_as_float(rv.y & 0xffff0000u);
-              } else {
-                const float4 rv = *(const float4*)(R + m * p.ldr + no0);
-                o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
-              }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; e++) o[e] *= p.out_scale;
-#ifdef EMO_ABL_NOSTORE
-            if (o[0] == 123.456f)
-#endif
-            {
-            if constexpr (sizeof(T) == 2) *(uint2*)(C + m * p.ldc + no0) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
-            else *(float4*)(C + m * p.ldc + no0) = make_float4(o[0], o[1], o[2], o[3]);
-            }
-          } else {   // ragged N / unaligned leading dims: scalar path
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-              const int nw = nw0 + e;
-              if (nw >= p.N || !m_ok) continue;
-              float v = o[e];
-              if (p.bias) v += p.bias[nw];
-              if (rbias) v += rbias[nw];
-              if (p.geglu) {
-                float gt = acc[i][(j + 1) % WTN][4 * g + e];
-                if (p.bias) gt += p.bias[nw + 32];
-                v *= gelu_for<T>(gt);
-              }
-              if (no0 + e < n_out) {
-                if (R) v += TT<T>::ld(R + m * p.ldr + no0 + e);
-                TT<T>::st(C + m * p.ldc + no0 + e, v * p.out_scale);
-              }
-            }
-          }
-        }
-      }
+      epilogue_row<T, WTN>(acc[i], p, m, m_ok, wn0, half, C, R);
     }
   } else {
     // TRANS: lane <-> column n; register quad g <-> rows 8*g + 4*half + {0..3} (4 CONSECUTIVE rows), which are 4
@@ -458,6 +466,236 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
       }
   }
   }   // tiles of this block
+}
+
+// ------------------------------------------------------------------------------------------ 3x3 conv, halo reuse
+// Stride-1 3x3 convolution (resnet.py:30-38 - 44 of the 54 convs of a UNet pass) without the 9x re-read of the im2col
+// loader.  A block owns an 8x16 patch of output pixels of one frame (= 128 GEMM rows) x 128 output channels.  K runs
+// channel-chunk major: for every 128-byte channel chunk the (8+2)x(16+2) input HALO of the patch is brought into LDS ONCE
+// (23 KB instead of 9 x 16 KB of im2col rows) and the 9 taps read their A fragments from it at shifted pixel positions;
+// only the weight tile (128 x 128 B per tap) streams per stage.  LDS-DMA traffic per MFMA drops by ~40 % - the
+// direct-to-LDS path (~9 TB/s chip-wide measured) is what bounds the im2col kernel.
+//   * LDS: 2 halo buffers (chunk c+1 arrives in 6 pieces during the first 6 taps of chunk c) + a 2-deep weight ring
+//     = 78 KB -> 2 blocks per CU.  LDS "rows" of the halo are halo pixels; same XOR chunk swizzle as the GEMM.
+//   * persistent blocks, continuous loader stream across tiles, weights one stage ahead (requested right behind the
+//     barrier), vmcnt(0) + one s_barrier per tap-stage.
+//   * epilogue = the GEMM's row-major fused epilogue (bias, temb row bias, residual), rows mapped through the patch.
+// Needs Cin % (128 B of channels) == 0, H % 8 == 0, W % 16 == 0; everything else stays on the im2col loader.
+struct Halo {
+  static constexpr int PH = 8, PW = 16, HW_ = PW + 2, HPIX = (PH + 2) * (PW + 2);   // 180 halo pixels
+  static constexpr int PIECES = (HPIX + 7) / 8;                 // 1 KB glds pieces of 8 pixels: 23
+  static constexpr int LH = (PIECES + 3) / 4;                   // pieces per wave: 6 (the last round is partial)
+  static constexpr int HALO_BYTES = PIECES * 1024;              // 23 KB
+  static constexpr int BN = 128, LB = BN / 32;                  // weight tile rows, glds per wave per stage
+  static constexpr int B_BYTES = BN * KBYTES;                   // 16 KB
+  static constexpr int B_OFF = 2 * HALO_BYTES;
+  static constexpr int LDS_BYTES = 2 * HALO_BYTES + 2 * B_BYTES;   // 79872
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const emo_gemm_params p) {
+  constexpr int V = TT<T>::VEC, BK = KBYTES / (int)sizeof(T);
+  constexpr int WTM = 2, WTN = 2, NW = 4, LH = Halo::LH, LB = Halo::LB, BN = Halo::BN;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wvm = wave >> 1, wvn = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  const int tpx = p.W_ / Halo::PW, tpy = p.H / Halo::PH, tpi = tpx * tpy;   // patches per frame
+  const int tiles_m = (int)(p.M / ((int64_t)p.H * p.W_)) * tpi;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_all = tiles_m * tiles_n;
+  const int G = gridDim.x;
+  auto tile_of = [&](int i) {
+    const int qn = tiles_all >> 3, rn = tiles_all & 7, x = i & 7, idx = i >> 3;
+    return (x < rn ? x * (qn + 1) : rn * (qn + 1) + (x - rn) * qn) + idx;
+  };
+  const int nchunks = p.Cin / BK;
+  const int nk = nchunks * 9;            // tap-stages per tile
+
+  const T* __restrict__ A = (const T*)p.A;
+  const T* __restrict__ W = (const T*)p.W;
+  const T* zero = (const T*)g_zero_page;
+  const int lrow = lane / CPR, lchunk = lane % CPR;
+
+  // ---- halo loader: piece pi = i*4 + wave covers halo pixels pi*8 .. +8 (lane -> pixel pi*8 + lane/8, chunk lane%8)
+  int h_y[LH], h_x[LH], h_klog[LH];
+  bool h_piece[LH];
+#pragma unroll
+  for (int i = 0; i < LH; i++) {
+    const int pi = i * NW + wave, hp = pi * 8 + lrow;
+    h_piece[i] = pi < Halo::PIECES;
+    h_klog[i] = lchunk ^ swz(hp);
+    h_y[i] = hp < Halo::HPIX ? hp / Halo::HW_ : -100000;   // pad pixels of the last piece read the zero page
+    h_x[i] = hp % Halo::HW_;
+  }
+  const T* h_ptr[LH];
+  int h_inc[LH];
+  int h_iter = blockIdx.x, h_c = 0, h_count = 0;   // halo loader: tile, chunk, running chunk counter (buffer = count % 2)
+  auto setup_halo = [&](int iter) {
+    const int tile = tile_of(iter);
+    const int tm = tile / tiles_n;
+    const int img = tm / tpi, rem = tm % tpi;
+    const int y0 = (rem / tpx) * Halo::PH - 1, x0 = (rem % tpx) * Halo::PW - 1;
+#pragma unroll
+    for (int i = 0; i < LH; i++) {
+      const int iy = y0 + h_y[i], ix = x0 + h_x[i];
+      const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W_;
+      h_ptr[i] = ok ? A + (((int64_t)img * p.H + iy) * p.W_ + ix) * p.lda + h_klog[i] * V : zero;
+      h_inc[i] = ok ? BK : 0;
+    }
+  };
+  auto issue_halo = [&](auto I) {
+    constexpr int i = decltype(I)::value;
+    if (h_piece[i]) {
+      EMO_GLDS16(h_ptr[i], lds + (h_count & 1) * Halo::HALO_BYTES + (i * NW + wave) * 1024);
+      h_ptr[i] += h_inc[i];
+    }
+  };
+  auto advance_halo = [&]() {   // after the last piece of a chunk
+    h_count++;
+    if (++h_c >= nchunks) {
+      h_c = 0;
+      h_iter += G;
+      if (h_iter < tiles_all) setup_halo(h_iter);
+    }
+  };
+
+  // ---- weight loader: stage (c, t) of a tile reads W[n][t*Cin + c*BK ..+BK)
+  int b_klog[LB];
+  const T* b_base[LB];
+  bool b_ok[LB];
+#pragma unroll
+  for (int i = 0; i < LB; i++) b_klog[i] = lchunk ^ swz((i * NW + wave) * (64 / CPR) + lrow);
+  int l_iter = blockIdx.x, l_c = 0, l_t = 0;
+  auto setup_b = [&](int iter) {
+    const int tile = tile_of(iter);
+    const int lbn = (tile % tiles_n) * BN;
+#pragma unroll
+    for (int i = 0; i < LB; i++) {
+      const int n = lbn + (i * NW + wave) * (64 / CPR) + lrow;
+      b_ok[i] = n < p.N;
+      b_base[i] = b_ok[i] ? W + (int64_t)n * p.K + b_klog[i] * V : zero;
+    }
+  };
+  auto issue_b = [&](int slot) {
+    const int koff = l_t * p.Cin + l_c * BK;
+#pragma unroll
+    for (int i = 0; i < LB; i++)
+      EMO_GLDS16(b_ok[i] ? b_base[i] + koff : zero, lds + Halo::B_OFF + slot * Halo::B_BYTES + (i * NW + wave) * 1024);
+  };
+  auto advance_b = [&]() {
+    if (++l_t >= 9) {
+      l_t = 0;
+      if (++l_c >= nchunks) {
+        l_c = 0;
+        l_iter += G;
+        if (l_iter < tiles_all) setup_b(l_iter);
+      }
+    }
+  };
+
+  // ---- fragment addressing
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  int hp0[WTM];   // halo pixel of tap (0,0) for this lane's output pixel of MFMA tile row i
+#pragma unroll
+  for (int i = 0; i < WTM; i++) hp0[i] = ((wvm * WTM + i) * 2 + (l31 >> 4)) * Halo::HW_ + (l31 & 15);
+  unsigned fb_off[WTN][KSTEPS];
+#pragma unroll
+  for (int j = 0; j < WTN; j++) {
+    const int r = wvn * 32 * WTN + j * 32 + l31;
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; kk++) fb_off[j][kk] = Halo::B_OFF + r * KBYTES + (((kk * 2 + half) ^ swz(r)) * 16);
+  }
+
+  T* __restrict__ C = (T*)p.C;
+  const T* __restrict__ R = (const T*)p.residual;
+
+  // ---- stream prologue: halo of the first chunk, weights of the first stage
+  setup_halo(h_iter);
+  static_for<LH>([&](auto I) { issue_halo(I); });
+  advance_halo();
+  setup_b(l_iter);
+  issue_b(0);
+  advance_b();
+
+  int gs = 0, gc = 0;   // running tap-stage / chunk counters of the MFMA loop (weight slot = gs % 2, halo buffer = gc % 2)
+  for (int c_iter = blockIdx.x; c_iter < tiles_all; c_iter += G) {
+    const int c_tile = tile_of(c_iter);
+    f32x16 acc[WTM][WTN];
+#pragma unroll
+    for (int i = 0; i < WTM; i++)
+#pragma unroll
+      for (int j = 0; j < WTN; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    for (int c = 0; c < nchunks; c++, gc++) {
+      const unsigned stH = lds_base + (gc & 1) * Halo::HALO_BYTES;
+      for (int t = 0; t < 9; t++, gs++) {
+        wait_vmcnt<0>();                  // this stage's weights (and, at t == 0, the whole halo) have landed
+        __builtin_amdgcn_s_barrier();     // ... for every wave; everyone is done with the previous stage's slot
+        // next stage's weights, then one piece of the next chunk's halo (pieces 0..5 ride on taps 0..5)
+        if (l_iter < tiles_all) { issue_b((gs + 1) & 1); advance_b(); }
+        if (t < LH && h_iter < tiles_all) {
+          switch (t) {
+            case 0: issue_halo(std::integral_constant<int, 0>{}); break;
+            case 1: issue_halo(std::integral_constant<int, 1>{}); break;
+            case 2: issue_halo(std::integral_constant<int, 2>{}); break;
+            case 3: issue_halo(std::integral_constant<int, 3>{}); break;
+            case 4: issue_halo(std::integral_constant<int, 4>{}); break;
+            default: issue_halo(std::integral_constant<int, 5>{}); break;
+          }
+          if (t == LH - 1) advance_halo();
+        }
+        const unsigned stB = lds_base + (gs & 1) * Halo::B_BYTES;
+        // A fragment addresses of this tap: halo pixel (y + ky, x + kx)
+        const int toff = (t / 3) * Halo::HW_ + (t % 3);
+        unsigned fa_base[WTM], fa_key[WTM];
+#pragma unroll
+        for (int i = 0; i < WTM; i++) {
+          const int hp = hp0[i] + toff;
+          fa_base[i] = stH + hp * KBYTES;
+          fa_key[i] = swz(hp);
+        }
+        uint4 fa[2][WTM], fb[2][WTN];
+#pragma unroll
+        for (int i = 0; i < WTM; i++) fa[0][i] = lds_read16(fa_base[i] + ((half ^ fa_key[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < WTN; j++) fb[0][j] = lds_read16(stB + fb_off[j][0]);
+        constexpr int NMMA = WTM * WTN, NRD = WTM + WTN;
+        static_for<KSTEPS>([&](auto KK) {
+          constexpr int kk = decltype(KK)::value, cur = kk & 1, nxt = cur ^ 1;
+          wait_lgkmcnt<0>();
+          __builtin_amdgcn_sched_barrier(0);
+          constexpr int n_rd = (kk + 1 < KSTEPS) ? NRD : 0;
+          static_for<NMMA>([&](auto Q) {
+            constexpr int q = decltype(Q)::value, i = q / WTN, j = q % WTN;
+            acc[i][j] = mma16<T>(fb[cur][j], fa[cur][i], acc[i][j]);   // rows = n, lane = m
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (q < n_rd) {
+              if constexpr (q < WTM) fa[nxt][q] = lds_read16(fa_base[q] + ((((kk + 1) * 2 + half) ^ fa_key[q]) << 4));
+              else fb[nxt][q - WTM] = lds_read16(stB + fb_off[q - WTM][kk + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        });
+      }
+    }
+
+    // ---- epilogue: MFMA tile row i of this wave = patch rows 2*(wvm*2+i), +1 (16 pixels each)
+    const int tm = c_tile / tiles_n;
+    const int img = tm / tpi, rem = tm % tpi;
+    const int y0 = (rem / tpx) * Halo::PH, x0 = (rem % tpx) * Halo::PW;
+    const int wn0 = (c_tile % tiles_n) * BN + wvn * 32 * WTN;
+#pragma unroll
+    for (int i = 0; i < WTM; i++) {
+      const int y = y0 + (wvm * WTM + i) * 2 + (l31 >> 4), x = x0 + (l31 & 15);
+      const int64_t m = ((int64_t)img * p.H + y) * p.W_ + x;
+      epilogue_row<T, WTN>(acc[i], p, m, true, wn0, half, C, R);
+    }
+  }
 }
 
 // split-K second pass: fixed-order reduction of the f32 partials + the same fused epilogue; a thread owns 4 consecutive
@@ -663,8 +901,29 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
   if (!p.transpose_out) {
     EMO_CHECK(((uintptr_t)p.C % 16) == 0 && (!p.residual || ((uintptr_t)p.residual % 8) == 0), EMO_ERR_BAD_SHAPE, "emo_gemm: C/residual alignment");
   }
-  GemmPlan pl = plan_gemm(p.M, p.N, p.K, p.dtype, p.geglu, p.transpose_out);
   const int S = p.split_k > 1 ? p.split_k : 1;
+  {
+    static const int halo_mode = env_int("EMO_CONV_HALO", 1);
+    const int bk = KBYTES / (p.dtype == EMO_F32 ? 4 : 2);
+    if (halo_mode && conv && p.stride == 1 && !p.upsample2x && !p.transpose_out && !p.geglu && S == 1 && p.Cin % bk == 0 &&
+        p.H % Halo::PH == 0 && p.W_ % Halo::PW == 0 && (p.N & 3) == 0) {
+      static bool once = false;
+      if (!once) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo::LDS_BYTES);
+        hipError_t e2 = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo::LDS_BYTES);
+        if (e1 != hipSuccess || e2 != hipSuccess) return emo_fail(EMO_ERR_HIP, "emo_gemm: hipFuncSetAttribute(halo conv)");
+        once = true;
+      }
+      const int64_t tiles = (p.M / 128) * ((p.N + Halo::BN - 1) / Halo::BN);
+      const int64_t gx = tiles > 512 ? 512 : tiles;
+      hipStream_t st = as_stream(stream);
+      if (p.dtype == EMO_F32) conv3x3_halo_kernel<float><<<(unsigned)gx, 256, Halo::LDS_BYTES, st>>>(p);
+      else conv3x3_halo_kernel<bf16_t><<<(unsigned)gx, 256, Halo::LDS_BYTES, st>>>(p);
+      EMO_LAUNCH_CHECK();
+      return EMO_OK;
+    }
+  }
+  GemmPlan pl = plan_gemm(p.M, p.N, p.K, p.dtype, p.geglu, p.transpose_out);
   if (S > 1) {
     EMO_CHECK(p.workspace != nullptr && S <= 65535, EMO_ERR_NULL, "emo_gemm: split_k=%d needs a workspace", S);
     EMO_CHECK(p.N % 4 == 0, EMO_ERR_BAD_SHAPE, "emo_gemm: split-K needs N %% 4 == 0");

@@ -167,6 +167,26 @@ def test_conv3x3(dtype, n, H, W, Cin, Cout, stride, up):
     close(got, ref.permute(0, 2, 3, 1).reshape(-1, Cout), dtype)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,H,W,Cin,Cout", [(2, 8, 16, 64, 128), (3, 16, 32, 128, 320), (1, 24, 16, 192, 64), (13, 16, 16, 64, 132)])
+def test_conv3x3_halo_path(dtype, n, H, W, Cin, Cout):
+    """Stride-1 3x3 with H % 8 == 0, W % 16 == 0, Cin a multiple of the 128-byte channel chunk: the halo-reuse kernel
+    (csrc/gemm.hip conv3x3_halo_kernel), with the resnet epilogue (bias + temb row bias + residual; resnet.py:188,197)."""
+    o = ops()
+    x = q(seeded_randn((n, Cin, H, W), 31), dtype)
+    wt, bias = q(seeded_randn((Cout, Cin, 3, 3), 32) / math.sqrt(9 * Cin), dtype), 0.1 * seeded_randn((Cout,), 33)
+    res = q(seeded_randn((n, Cout, H, W), 34), dtype)
+    rb = seeded_randn((n, Cout), 35)
+    ref = F.conv2d(x, wt, bias, padding=1) + rb[:, :, None, None] + res
+    rows = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous()
+    wp = wt.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)
+    rrows = res.permute(0, 2, 3, 1).reshape(-1, Cout).contiguous()
+    got, Ho, Wo = o.conv3x3(rows.to(DEV).to(dtype), wp.to(DEV).to(dtype).contiguous(), bias.to(DEV), n, H, W,
+                            rowbias=rb.to(DEV), rows_per_batch=H * W, residual=rrows.to(DEV).to(dtype), split_k=1)
+    assert (Ho, Wo) == (H, W)
+    close(got, ref.permute(0, 2, 3, 1).reshape(-1, Cout), dtype)
+
+
 def attn_ref(qh, k, v, scale):
     s = torch.matmul(qh, k.transpose(-1, -2)) * scale
     return torch.matmul(s.softmax(-1), v)
