@@ -25,6 +25,8 @@
 static constexpr int ATT_THREADS = 256, BQ = 128, TK = 64;
 
 __device__ __attribute__((aligned(16))) unsigned int g_att_zero_page[4] = {0, 0, 0, 0};
+__device__ __attribute__((aligned(16))) unsigned int g_att_ones_bf16[4] = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+__device__ __attribute__((aligned(16))) unsigned int g_att_ones_f32[4] = {0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u};
 
 template <typename T, int DCH>
 struct AttCfg {
@@ -48,6 +50,12 @@ __device__ __forceinline__ uint4 lds_read16(unsigned addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
   return v;
 }
+__device__ __forceinline__ float max3f(float a, float b, float c) {   // no NaNs in play: skip fmaxf's canonicalisation
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
 // G = glds per wave per tile, NSR = ring depth, QT = 32-query tiles per wave (2 halves the LDS fragment traffic per MFMA)
@@ -65,9 +73,21 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attent
   const int d = p.d;
   const int dch_real = d / V;  // d*sizeof(T) % 16 == 0 checked on the host
   const T* zero = (const T*)g_att_zero_page;
+  const T* ones = sizeof(T) == 2 ? (const T*)g_att_ones_bf16 : (const T*)g_att_ones_f32;
 
   // ---- zero the whole ring once: V^T pad rows (n >= d) are never written by the loader and must be 0
-  for (int i = tid * 16; i < NSR * stage_bytes; i += ATT_THREADS * 16) *(uint4*)(smem + i) = make_uint4(0, 0, 0, 0);
+  // ... except V^T row d, which is all ONES when the head dim leaves a pad row (d < NT*32: 40, 80): row d of O^T = V^T P^T
+  // is then the softmax denominator sum_k P[q][k], accumulated by the matrix pipe instead of 32 VALU adds per tile
+  const bool ones_row = d < NT * 32;
+  {
+    const int ones_begin = K_CHUNKS * 16 + d * VROW, ones_end = ones_begin + VCH * 16;
+    const unsigned one_bits = sizeof(T) == 2 ? 0x3f803f80u : 0x3f800000u;
+    for (int i = tid * 16; i < NSR * stage_bytes; i += ATT_THREADS * 16) {
+      const int off = i % stage_bytes;
+      const unsigned v = (ones_row && off >= ones_begin && off < ones_end) ? one_bits : 0u;
+      *(uint4*)(smem + i) = make_uint4(v, v, v, v);
+    }
+  }
 
   // ---- Q fragments: QT tiles of 32 query rows per wave; row q, chunks (2*kk + half)
   constexpr int BQW = 32 * QT;              // query rows per wave
@@ -100,6 +120,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attent
     } else {
       const int qv = pos - K_CHUNKS, n = qv / VCHP, c = qv % VCHP;
       if (n < d && c < VCH) { ld_kind[g] = 2; ld_a[g] = n; ld_c[g] = c; }
+      else if (ones_row && n == d && c < VCH) ld_kind[g] = 3;   // the all-ones row (the loader rewrites it every tile)
     }
   }
 
@@ -132,6 +153,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attent
         const int key0 = k0 + ld_c[g] * V;
         if (key0 < Lk) src = vbase + (int64_t)ld_a[g] * ldvt + key0;   // a chunk straddling Lk is cleaned in LDS below
       }
+      else if (ld_kind[g] == 3) src = ones;
       EMO_GLDS16(src, st + (g * 4 + wave) * 1024);
     }
   };
@@ -164,9 +186,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attent
       wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
+#ifndef EMO_ATT_ABL_NOLOAD
     if constexpr (NSR > 1) {
       if (t + NSR - 1 < ntiles) issue(t + NSR - 1, (t + NSR - 1) % NSR);
     }
+#endif
     const bool s1 = t >= tiles0;
     const int k0 = (s1 ? t - tiles0 : t) * TK;
     const int Lk = s1 ? p.Lk1 : p.Lk0;
@@ -221,23 +245,38 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attent
           if (key + 32 >= Lk) s1[r] = -1e30f;
         }
       }
-      float mx = fmaxf(s0[0], s1[0]);
+      float mx = max3f(s0[0], s1[0], s0[1]);
+      mx = max3f(mx, s1[1], s0[2]);
+      mx = max3f(mx, s1[2], s0[3]);
+      mx = fmaxf(mx, s1[3]);
 #pragma unroll
-      for (int r = 1; r < 16; r++) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+      for (int r = 4; r < 16; r += 2) { mx = max3f(mx, s0[r], s1[r]); mx = max3f(mx, s0[r + 1], s1[r + 1]); }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[t], mx);
-      const float alpha = exp2f((m_run[t] - m_new) * c_exp);
+      const float alpha = __builtin_amdgcn_exp2f((m_run[t] - m_new) * c_exp);   // raw v_exp_f32: arguments are <= 0, no denormal care
       m_run[t] = m_new;
       const float m_sc = m_new * c_exp;
-      float psum = 0.f;
       float p0[16], p1[16];
+      {
+        const v2f cc = {c_exp, c_exp}, mm = {m_sc, m_sc};
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        p0[r] = exp2f(s0[r] * c_exp - m_sc);
-        p1[r] = exp2f(s1[r] * c_exp - m_sc);
-        psum += p0[r] + p1[r];
+        for (int r = 0; r < 16; r += 2) {
+          const v2f a = {s0[r], s0[r + 1]}, b = {s1[r], s1[r + 1]};
+          const v2f ea = a * cc - mm, eb = b * cc - mm;      // v_pk_fma_f32
+#ifdef EMO_ATT_ABL_NOEXP
+          p0[r] = ea.x; p0[r + 1] = ea.y; p1[r] = eb.x; p1[r + 1] = eb.y;
+#else
+          p0[r] = __builtin_amdgcn_exp2f(ea.x); p0[r + 1] = __builtin_amdgcn_exp2f(ea.y);
+          p1[r] = __builtin_amdgcn_exp2f(eb.x); p1[r + 1] = __builtin_amdgcn_exp2f(eb.y);
+#endif
+        }
       }
-      l_run[t] = l_run[t] * alpha + psum;
+      if (!ones_row) {   // no pad row (d = 160): the denominator is summed on the VALU
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) psum += p0[r] + p1[r];
+        l_run[t] = l_run[t] * alpha + psum;
+      }
       if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // skip the O rescale when no lane's max moved
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
@@ -281,7 +320,12 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attent
 #pragma unroll
         for (int t = 0; t < QT; t++)
 #pragma unroll
-          for (int nt = 0; nt < NT; nt++) o[t][nt] = mma16<T>(vf[sp][nt], pf[t][st][sp], o[t][nt]);
+          for (int nt = 0; nt < NT; nt++) {
+#ifdef EMO_ATT_ABL_NOPV
+            if (sp == 0 && nt == 0)
+#endif
+            o[t][nt] = mma16<T>(vf[sp][nt], pf[t][st][sp], o[t][nt]);
+          }
     }
     if constexpr (NSR == 1) __builtin_amdgcn_s_barrier();   // synchronous ring: nobody may still read slot 0
   }
@@ -289,7 +333,20 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attent
   // ---- normalise and store: lane holds O[q][n], n = nt*32 + 8*(r>>2) + 4*half + (r&3)
 #pragma unroll
   for (int t = 0; t < QT; t++) {
-    const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32, 64);
+    float l_tot;
+    if (ones_row) {
+      // row d of O^T: tile d/32, local row rr = d%32 = 8*(r>>2) + 4*half + (r&3)
+      const int nt_d = d >> 5, rr = d & 31, r_d = ((rr >> 3) << 2) | (rr & 3), half_d = (rr >> 2) & 1;
+      float lsel = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          if (nt == nt_d && r == r_d) lsel = o[t][nt][r];
+      l_tot = __shfl(lsel, half_d * 32 + l31, 64);
+    } else {
+      l_tot = l_run[t] + __shfl_xor(l_run[t], 32, 64);
+    }
     const float inv = 1.0f / l_tot;
     if (q_ok[t]) {
       T* orow = (T*)p.out + ((int64_t)b * p.Lq + qrow_idx[t]) * p.ldo + head * d;

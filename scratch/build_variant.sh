@@ -1,9 +1,14 @@
 #!/bin/bash
-# usage: build_variant.sh NAME "-DFLAG ..."   -> scratch/variants/NAME.so (gemm.hip rebuilt with the flags, other objects from lib/)
+# usage: build_variant.sh NAME SRC "-DFLAG ..."   -> emote_hack_amd/lib/variants/NAME.so (SRC.hip rebuilt with the flags, other objects from lib/)
 set -e
 cd "$(dirname "$0")/.."
-N=$1; shift
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-variable -Wno-pass-failed $@ -c emote_hack_amd/csrc/gemm.hip -o /tmp/emo_variant_$N.o
+N=$1; SRC=$2; shift; shift
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-variable -Wno-pass-failed $@ -c emote_hack_amd/csrc/$SRC.hip -o /tmp/emo_variant_$N.o
 L=emote_hack_amd/lib
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $L/elementwise.o $L/norm.o /tmp/emo_variant_$N.o $L/attention.o $L/temporal.o $L/conditioning.o -o emote_hack_amd/lib/variants/$N.so
-echo built emote_hack_amd/lib/variants/$N.so
+OBJS=""
+for o in elementwise norm gemm attention temporal conditioning; do
+  if [ "$o" == "$SRC" ]; then OBJS="$OBJS /tmp/emo_variant_$N.o"; else OBJS="$OBJS $L/$o.o"; fi
+done
+mkdir -p $L/variants
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $L/variants/$N.so
+echo built $L/variants/$N.so
