@@ -13,8 +13,8 @@
 //                    a lane's 8 consecutive P registers are 8 consecutive keys.
 //   KV tiles stream through an LDS RING filled by asynchronous global_load_lds_dwordx4 (no VGPR staging):
 //   tiles t+1 (and t+2) are in flight while tile t is consumed; counted `s_waitcnt vmcnt`, one raw s_barrier
-//   per tile.  The LDS image is lane-linear, so rows are padded to an ODD number of 16-byte chunks by sourcing
-//   the pad chunk from a zero page (conflict-free ds_read_b128 and a zero K/V pad for free); fragment reads
+//   per tile.  The LDS image is lane-linear, so K rows are padded to an ODD number of 16-byte chunks by sourcing
+//   the pad chunk from a zero page, V^T rows are XOR-swizzled (conflict-free ds_read_b128 either way); fragment reads
 //   are inline-asm ds_read_b128 with hand-counted lgkmcnt (hipcc would drain vmcnt(0) before every C++ LDS
 //   read while a glds is in flight).
 // Two KV segments: [self / context keys of the batch row] ++ [a bank shared by seg1_div consecutive
@@ -35,7 +35,11 @@ struct AttCfg {
   static constexpr int NT = (DPAD + 31) / 32;
   static constexpr int DCHP = DCH + 1;                         // odd chunk count per K row
   static constexpr int VCH = TK * (int)sizeof(T) / 16;         // real 16-B chunks per V^T row
-  static constexpr int VCHP = VCH + 1;                         // odd
+  static constexpr int VCHP = VCH;                             // V^T rows are not padded: XOR chunk swizzle instead (vkey)
+  static constexpr int VRPB = 256 / (VCH * 16) > 0 ? 256 / (VCH * 16) : 1;   // V^T rows per 256-byte LDS bank row
+  // 16-byte chunk c of V^T row n lives at chunk position c ^ vkey(n): the 16 rows of a ds_read_b128 lane group hit 16
+  // distinct 16-byte slots (same scheme as the GEMM operand swizzle)
+  __device__ static __forceinline__ int vkey(int n) { return (n / VRPB) & (VCH - 1); }
   static constexpr int KROW = DCHP * 16, VROW = VCHP * 16;     // bytes
   static constexpr int K_CHUNKS = TK * DCHP;
   static constexpr int STEPS = 32 / (2 * V);                   // mma16 steps per 32-key sub-tile
@@ -60,7 +64,7 @@ __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1)
 
 // G = glds per wave per tile, NSR = ring depth, QT = 32-query tiles per wave (2 halves the LDS fragment traffic per MFMA)
 template <typename T, int DCH, int G, int NSR, int QT>
-__global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attention_params p, int stage_bytes) {
+__global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) void attention_kernel(const emo_attention_params p, int stage_bytes) {
   using Cfg = AttCfg<T, DCH>;
   constexpr int V = Cfg::V, NT = Cfg::NT, KROW = Cfg::KROW, VROW = Cfg::VROW, STEPS = Cfg::STEPS;
   constexpr int DCHP = Cfg::DCHP, VCH = Cfg::VCH, VCHP = Cfg::VCHP, K_CHUNKS = Cfg::K_CHUNKS;
@@ -118,9 +122,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attent
       const int row = pos / DCHP, c = pos % DCHP;
       if (c < dch_real) { ld_kind[g] = 1; ld_a[g] = (row & 32) | swap23(row & 31); ld_c[g] = c; }
     } else {
-      const int qv = pos - K_CHUNKS, n = qv / VCHP, c = qv % VCHP;
-      if (n < d && c < VCH) { ld_kind[g] = 2; ld_a[g] = n; ld_c[g] = c; }
-      else if (ones_row && n == d && c < VCH) ld_kind[g] = 3;   // the all-ones row (the loader rewrites it every tile)
+      const int qv = pos - K_CHUNKS, n = qv / VCHP, c = (qv % VCHP) ^ Cfg::vkey(n);
+      if (n < d) { ld_kind[g] = 2; ld_a[g] = n; ld_c[g] = c; }
+      else if (ones_row && n == d) ld_kind[g] = 3;   // the all-ones row (the loader rewrites the part its rounds cover)
     }
   }
 
@@ -135,26 +139,42 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attent
   const T* kbase1 = nseg == 2 ? (const T*)p.k1 + (int64_t)kb1 * p.Lk1 * p.ldk1 + head * d : nullptr;
   const T* vbase1 = nseg == 2 ? (const T*)p.v1t + ((int64_t)kb1 * p.heads * d + (int64_t)head * d) * p.ldv1t : nullptr;
 
-  auto issue = [&](int t, int slot) {
-    const bool s1 = t >= tiles0;
-    const int k0 = (s1 ? t - tiles0 : t) * TK;
-    const int Lk = s1 ? p.Lk1 : p.Lk0;
+  // per-glds source pointers, advanced by a constant per tile (K chunk: TK rows, V^T chunk: TK keys); only the last tile
+  // of a segment (it may run past Lk) recomputes addresses with bounds checks.  Tiles are issued strictly in order.
+  const T* ld_ptr[G];
+  int64_t ld_inc[G];
+  auto setup_segment = [&](bool s1) {
     const int64_t ldk = s1 ? p.ldk1 : p.ldk0, ldvt = s1 ? p.ldv1t : p.ldv0t;
     const T* kbase = s1 ? kbase1 : kbase0;
     const T* vbase = s1 ? vbase1 : vbase0;
-    unsigned char* st = smem + slot * stage_bytes;
 #pragma unroll
     for (int g = 0; g < G; g++) {
-      const T* src = zero;
-      if (ld_kind[g] == 1) {
-        const int key = k0 + ld_a[g];
-        if (key < Lk) src = kbase + (int64_t)key * ldk + ld_c[g] * V;
-      } else if (ld_kind[g] == 2) {
-        const int key0 = k0 + ld_c[g] * V;
-        if (key0 < Lk) src = vbase + (int64_t)ld_a[g] * ldvt + key0;   // a chunk straddling Lk is cleaned in LDS below
+      if (ld_kind[g] == 1) { ld_ptr[g] = kbase + (int64_t)ld_a[g] * ldk + ld_c[g] * V; ld_inc[g] = (int64_t)TK * ldk; }
+      else if (ld_kind[g] == 2) { ld_ptr[g] = vbase + (int64_t)ld_a[g] * ldvt + ld_c[g] * V; ld_inc[g] = TK; }
+      else { ld_ptr[g] = ld_kind[g] == 3 ? ones : zero; ld_inc[g] = 0; }
+    }
+  };
+  setup_segment(false);
+  auto issue = [&](int t, int slot) {
+    const bool s1 = t >= tiles0;
+    if (s1 && t == tiles0) setup_segment(true);
+    const int k0 = (s1 ? t - tiles0 : t) * TK;
+    const int Lk = s1 ? p.Lk1 : p.Lk0;
+    unsigned char* st = smem + slot * stage_bytes;
+    if (k0 + TK <= Lk) {
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        EMO_GLDS16(ld_ptr[g], st + (g * 4 + wave) * 1024);
+        ld_ptr[g] += ld_inc[g];
       }
-      else if (ld_kind[g] == 3) src = ones;
-      EMO_GLDS16(src, st + (g * 4 + wave) * 1024);
+    } else {   // last tile of the segment
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        const T* src = ld_ptr[g];
+        if (ld_kind[g] == 1) { if (k0 + ld_a[g] >= Lk) src = zero; }
+        else if (ld_kind[g] == 2) { if (k0 + ld_c[g] * V >= Lk) src = zero; }   // a chunk straddling Lk is cleaned in LDS below
+        EMO_GLDS16(src, st + (g * 4 + wave) * 1024);
+      }
     }
   };
 
@@ -202,7 +222,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attent
       const int cpart = (Lk - k0) / V, efirst = (Lk - k0) % V;
       unsigned char* vs = smem + (t % NSR) * stage_bytes + K_CHUNKS * 16;
       for (int n = tid; n < d; n += ATT_THREADS) {
-        uint4* ptr = (uint4*)(vs + n * VROW + cpart * 16);
+        uint4* ptr = (uint4*)(vs + n * VROW + (cpart ^ Cfg::vkey(n)) * 16);
         float f[V];
         unpack16<T>(*ptr, f);
 #pragma unroll
@@ -307,7 +327,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const emo_attent
         const int r0 = sp * V;
         const int key_off = st * 32 + 16 * (r0 >> 3) + 8 * half + (r0 & 7);
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++) vf[sp][nt] = lds_read16(vs_base + (nt * 32 + l31) * VROW + key_off * (int)sizeof(T));
+        for (int nt = 0; nt < NT; nt++) {
+          const int n = nt * 32 + l31;
+          vf[sp][nt] = lds_read16(vs_base + n * VROW + (((key_off * (int)sizeof(T)) >> 4) ^ Cfg::vkey(n)) * 16);
+        }
         if constexpr (STEPS * NT > 15) {           // lgkmcnt is a 4-bit counter: drain per step for the widest heads
           wait_lgkmcnt<0>();
           __builtin_amdgcn_sched_barrier(0);
