@@ -14,10 +14,31 @@
 
 static constexpr int TA_THREADS = 256;
 
+// <q, k> over one 16-byte chunk pair
+template <typename T> __device__ __forceinline__ float dot16(const uint4& a, const uint4& b, float acc);
+template <> __device__ __forceinline__ float dot16<float>(const uint4& a, const uint4& b, float acc) {
+  acc += __uint_as_float(a.x) * __uint_as_float(b.x);
+  acc += __uint_as_float(a.y) * __uint_as_float(b.y);
+  acc += __uint_as_float(a.z) * __uint_as_float(b.z);
+  acc += __uint_as_float(a.w) * __uint_as_float(b.w);
+  return acc;
+}
+template <> __device__ __forceinline__ float dot16<bf16_t>(const uint4& a, const uint4& b, float acc) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.x), __builtin_bit_cast(bf2, b.x), acc, false);   // v_dot2_f32_bf16
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.y), __builtin_bit_cast(bf2, b.y), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.z), __builtin_bit_cast(bf2, b.z), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.w), __builtin_bit_cast(bf2, b.w), acc, false);
+  return acc;
+}
+
+// All index arithmetic is thread-fixed or incremental: the first version decomposed a flat index with runtime div / mod in
+// every loop iteration and was VALU-bound on that (124 us for 252 MB at the 64x64 level).
 template <typename T>
 __global__ __launch_bounds__(TA_THREADS) void temporal_attention_kernel(const T* __restrict__ qkv, int64_t ldqkv, T* __restrict__ out,
                                                                         int64_t ldo, int F, int HW, int C, int d, int hpb, int P,
-                                                                        float scale) {
+                                                                        float scale, int JW, int FP) {
+  // JW = min(P * CT / V, 256): threads per staged row;  FP = 16 or 32 >= F: padded score grid side
   constexpr int V = TT<T>::VEC;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int CT = hpb * d;                       // channels handled by this block
@@ -25,76 +46,95 @@ __global__ __launch_bounds__(TA_THREADS) void temporal_attention_kernel(const T*
   unsigned char* Qs = smem;
   unsigned char* Ks = Qs + F * ROW;
   unsigned char* Vs = Ks + F * ROW;
-  float* S = (float*)(Vs + F * ROW);            // [P][hpb][F][F]
+  float* S = (float*)(Vs + F * ROW);            // [P * hpb][F][F]
 
   const int tid = threadIdx.x;
   const int pix0 = blockIdx.x * P, hg = blockIdx.y, b = blockIdx.z;
   const int c0 = hg * CT;
-  const int CTV = CT / V;
+  const int CTV = CT / V, PC = P * CTV;         // 16-byte vectors per staged row
+  // JW threads share a row (JW = P * CT / V when that is <= 256: one div per thread, every lane busy; else 256)
+  const int jl = tid % JW, rstep = TA_THREADS / JW, r0 = tid / JW;   // r0 >= rstep: idle tail lanes
 
-  // ---- stage
-  for (int i = tid; i < 3 * F * P * CTV; i += TA_THREADS) {
-    int cv = i % CTV; int r = i / CTV;
-    int p = r % P; r /= P;
-    int f = r % F; int which = r / F;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (pix0 + p < HW)
-      v = *(const uint4*)(qkv + ((int64_t)(b * F + f) * HW + pix0 + p) * ldqkv + which * C + c0 + cv * V);
-    *(uint4*)(smem + (which * F + f) * ROW + (p * CT + cv * V) * (int)sizeof(T)) = v;
-  }
-  __syncthreads();
-
-  // ---- phase A: scores
-  const int dv = d / V;
-  for (int i = tid; i < P * hpb * F * F; i += TA_THREADS) {
-    int fk = i % F; int r = i / F;
-    int fq = r % F; r /= F;
-    int hh = r % hpb; int p = r / hpb;
-    const unsigned char* qp = Qs + fq * ROW + (p * CT + hh * d) * (int)sizeof(T);
-    const unsigned char* kp = Ks + fk * ROW + (p * CT + hh * d) * (int)sizeof(T);
-    float acc = 0.f;
-    for (int c = 0; c < dv; c++) {
-      float a[V], k[V];
-      unpack16<T>(*(const uint4*)(qp + c * 16), a);
-      unpack16<T>(*(const uint4*)(kp + c * 16), k);
-#pragma unroll
-      for (int e = 0; e < V; e++) acc += a[e] * k[e];
+  // ---- stage: rows (which, f) of the block's [3][F] rows, vector j = p * CTV + cv; thread -> (j, f = r0, r0 + rstep, ..):
+  // the q / k / v vectors of up to 4 frames (12 loads) are in flight per thread before the first LDS store
+  for (int j0 = 0; j0 < PC; j0 += JW) {
+    const int j = j0 + jl;
+    if (j >= PC || r0 >= rstep) break;
+    const int pp = j / CTV, cv = j - pp * CTV;
+    const bool pix_ok = pix0 + pp < HW;
+    const T* src = qkv + ((int64_t)(b * F + r0) * HW + (pix_ok ? pix0 + pp : 0)) * ldqkv + c0 + cv * V;
+    const int64_t fstep = (int64_t)rstep * HW * ldqkv;
+    unsigned char* dst = smem + j * 16;
+#pragma unroll 4
+    for (int f = r0; f < F; f += rstep) {
+      uint4 vq = make_uint4(0, 0, 0, 0), vk = vq, vv = vq;
+      if (pix_ok) { vq = *(const uint4*)src; vk = *(const uint4*)(src + C); vv = *(const uint4*)(src + 2 * C); }
+      *(uint4*)(dst + f * ROW) = vq;
+      *(uint4*)(dst + (F + f) * ROW) = vk;
+      *(uint4*)(dst + (2 * F + f) * ROW) = vv;
+      src += fstep;
     }
-    S[i] = acc * scale;
   }
   __syncthreads();
 
-  // ---- phase B: softmax rows
-  for (int i = tid; i < P * hpb * F; i += TA_THREADS) {
-    float* row = S + (int64_t)i * F;
+  // ---- phase A: scores.  Thread -> (fq, fk) on the padded FP x FP grid; loop over the (pixel, head) pairs, whose q / k
+  // vectors are d consecutive channels at (ph * d) of the staged rows
+  const int dv = d / V, NPH = P * hpb;
+  for (int pr = tid; pr < FP * FP; pr += TA_THREADS) {
+    const int fq = pr / FP, fk = pr & (FP - 1);
+    if (fq < F && fk < F) {
+      const unsigned char* qp = Qs + fq * ROW;
+      const unsigned char* kp = Ks + fk * ROW;
+      float* sp = S + fq * F + fk;
+      for (int ph = 0; ph < NPH; ph++) {
+        float acc = 0.f;
+        for (int c = 0; c < dv; c++) acc = dot16<T>(*(const uint4*)(qp + c * 16), *(const uint4*)(kp + c * 16), acc);
+        *sp = acc * scale;
+        qp += d * (int)sizeof(T); kp += d * (int)sizeof(T); sp += F * F;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase B: softmax rows; probabilities are cast to the value dtype (orig_attention.py:675)
+  for (int i = tid; i < NPH * F; i += TA_THREADS) {
+    float* row = S + i * F;
     float mx = -1e30f;
     for (int k = 0; k < F; k++) mx = fmaxf(mx, row[k]);
     float sum = 0.f;
     for (int k = 0; k < F; k++) { float e = __expf(row[k] - mx); row[k] = e; sum += e; }
     const float inv = 1.0f / sum;
-    for (int k = 0; k < F; k++) row[k] *= inv;
+    for (int k = 0; k < F; k++) {
+      float w = row[k] * inv;
+      if constexpr (sizeof(T) == 2) w = bf2f(f2bf(w));
+      row[k] = w;
+    }
   }
   __syncthreads();
 
-  // ---- phase C: out = P . V
-  for (int i = tid; i < F * P * CTV; i += TA_THREADS) {
-    int cv = i % CTV; int r = i / CTV;
-    int p = r % P; int fq = r / P;
-    if (pix0 + p >= HW) continue;
+  // ---- phase C: out = P . V: thread -> vector j of output rows fq = r0, r0 + rstep, ...
+  for (int j0 = 0; j0 < PC; j0 += JW) {
+    const int j = j0 + jl;
+    if (j >= PC || r0 >= rstep) break;
+    const int pp = j / CTV, cv = j - pp * CTV;
+    if (pix0 + pp >= HW) continue;
     const int hh = (cv * V) / d;
-    const float* prow = S + ((int64_t)(p * hpb + hh) * F + fq) * F;
-    float acc[V];
+    const float* pbase = S + (pp * hpb + hh) * F * F;
+    const unsigned char* vp = Vs + j * 16;
+    for (int fq = r0; fq < F; fq += rstep) {
+      const float* prow = pbase + fq * F;
+      float acc[V];
 #pragma unroll
-    for (int e = 0; e < V; e++) acc[e] = 0.f;
-    for (int fk = 0; fk < F; fk++) {
-      float vv[V];
-      unpack16<T>(*(const uint4*)(Vs + fk * ROW + (p * CT + cv * V) * (int)sizeof(T)), vv);
-      float w = prow[fk];
-      if constexpr (sizeof(T) == 2) w = bf2f(f2bf(w));  // probabilities are cast to the value dtype (orig_attention.py:675)
+      for (int e = 0; e < V; e++) acc[e] = 0.f;
+      for (int fk = 0; fk < F; fk++) {
+        float vv[V];
+        unpack16<T>(*(const uint4*)(vp + fk * ROW), vv);
+        const float w = prow[fk];
 #pragma unroll
-      for (int e = 0; e < V; e++) acc[e] += w * vv[e];
+        for (int e = 0; e < V; e++) acc[e] += w * vv[e];
+      }
+      *(uint4*)(out + ((int64_t)(b * F + fq) * HW + pix0 + pp) * ldo + c0 + cv * V) = pack16<T>(acc);
     }
-    *(uint4*)(out + ((int64_t)(b * F + fq) * HW + pix0 + p) * ldo + c0 + cv * V) = pack16<T>(acc);
   }
 }
 
@@ -117,11 +157,13 @@ extern "C" int emo_temporal_attention(const void* qkv, int64_t ldqkv, void* out,
   EMO_CHECK(lds <= 64 * 1024, EMO_ERR_UNSUPPORTED, "emo_temporal_attention: LDS %zu", lds);
   EMO_CHECK(B <= 65535 && heads / hpb <= 65535, EMO_ERR_BAD_SHAPE, "emo_temporal_attention: grid limits");
   dim3 grid((HW + P - 1) / P, heads / hpb, B);
+  const int JW = P * hpb * d / V < TA_THREADS ? P * hpb * d / V : TA_THREADS;
+  const int FP = F <= 16 ? 16 : 32;
   hipStream_t st = as_stream(stream);
   if (dtype == EMO_F32)
-    temporal_attention_kernel<float><<<grid, TA_THREADS, lds, st>>>((const float*)qkv, ldqkv, (float*)out, ldo, F, HW, C, d, hpb, P, scale);
+    temporal_attention_kernel<float><<<grid, TA_THREADS, lds, st>>>((const float*)qkv, ldqkv, (float*)out, ldo, F, HW, C, d, hpb, P, scale, JW, FP);
   else
-    temporal_attention_kernel<bf16_t><<<grid, TA_THREADS, lds, st>>>((const bf16_t*)qkv, ldqkv, (bf16_t*)out, ldo, F, HW, C, d, hpb, P, scale);
+    temporal_attention_kernel<bf16_t><<<grid, TA_THREADS, lds, st>>>((const bf16_t*)qkv, ldqkv, (bf16_t*)out, ldo, F, HW, C, d, hpb, P, scale, JW, FP);
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
