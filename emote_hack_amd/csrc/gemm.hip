@@ -103,8 +103,15 @@ __device__ __forceinline__ void epilogue_row(const f32x16 (&acc)[WTN], const emo
           float gt[4] = {acc[(j + 1) % WTN][4 * g], acc[(j + 1) % WTN][4 * g + 1], acc[(j + 1) % WTN][4 * g + 2],
                          acc[(j + 1) % WTN][4 * g + 3]};
           if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0 + 32); gt[0] += b4.x; gt[1] += b4.y; gt[2] += b4.z; gt[3] += b4.w; }
+          if constexpr (sizeof(T) == 2) {
+            float g0, g1, g2, g3;
+            gelu_erf_poly2(gt[0], gt[1], g0, g1);
+            gelu_erf_poly2(gt[2], gt[3], g2, g3);
+            o[0] *= g0; o[1] *= g1; o[2] *= g2; o[3] *= g3;
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; e++) o[e] *= gelu_for<T>(gt[e]);
+            for (int e = 0; e < 4; e++) o[e] *= gelu_for<T>(gt[e]);
+          }
         }
         if (!m_ok) continue;
         if (R) {
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
   constexpr int V = TT<T>::VEC;          // elements per 16 B
   constexpr int BK = KBYTES / (int)sizeof(T);
   constexpr int BM = Tile::BM, BN = Tile::BN, LA = Tile::LA, LB = Tile::LB, LPS = Tile::LPS;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  extern __shared__ __attribute__((aligned(128))) unsigned char lds[];   // 128: the XOR k-step addressing below
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -190,16 +197,16 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
   // glds #i of this wave fills LDS rows (i*NW + wave)*(64/CPR) .. of the operand; lane l writes physical chunk l%CPR of
   // row l/CPR, which holds LOGICAL chunk (l%CPR) ^ swz(row)
   const int lrow = lane / CPR, lchunk = lane % CPR;
-  int a_klog[LA], b_klog[LB];
-#pragma unroll
-  for (int i = 0; i < LA; i++) a_klog[i] = lchunk ^ swz((i * NW + wave) * (64 / CPR) + lrow);
-#pragma unroll
-  for (int i = 0; i < LB; i++) b_klog[i] = lchunk ^ swz((i * NW + wave) * (64 / CPR) + lrow);
+  // the swizzle key of row (i*NW + wave)*(64/CPR) + lrow does not depend on the round i (NW*(64/CPR)/RPB is a multiple of
+  // CPR): one logical chunk index per lane serves every glds of A and B
+  static_assert((NW * (64 / CPR) / RPB) % CPR == 0, "swizzle key must be round-independent");
+  const int klog = lchunk ^ swz(wave * (64 / CPR) + lrow);
   ConvRow a_cr[LA];
-  bool a_ok[LA];
-  const T* a_ptr[LA];     // advanced by a_inc / b_inc (BK or 0 elements) per issued stage: 2 VALU adds per glds
+  bool a_ok[LA];          // conv loader only
+  // Dense operands: rows past M / N are CLAMPED to the last valid row (their products land in accumulator rows / columns
+  // that are never stored), so every pointer advances by the same BK per stage - no per-row increments or validity flags.
+  const T* a_ptr[LA];
   const T* b_ptr[LB];
-  int a_inc[LA], b_inc[LB];
   int l_iter = blockIdx.x, l_kt = 0;   // the loader's tile (stream index) and next stage within the slice
   auto setup_loader = [&](int iter) {
     const int tile = tile_of(iter);
@@ -216,17 +223,16 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
         const int img = (int)(mm / hw), rem = (int)(mm % hw);
         const int oy = rem / p.Wo, ox = rem % p.Wo;
         a_cr[i].img = img; a_cr[i].iy0 = oy * p.stride - 1; a_cr[i].ix0 = ox * p.stride - 1;
+      } else {
+        const int64_t mc = m < p.M ? m : p.M - 1;
+        a_ptr[i] = A + mc * p.lda + klog * V + (int64_t)kt0 * BK;
       }
-      a_ptr[i] = a_ok[i] ? A + m * p.lda + a_klog[i] * V + (int64_t)kt0 * BK : zero;
-      a_inc[i] = a_ok[i] ? BK : 0;
     }
 #pragma unroll
     for (int i = 0; i < LB; i++) {
       const int row = (i * NW + wave) * (64 / CPR) + lrow;
-      const int n = lbn + row;
-      const bool ok = row < BN && n < p.N;
-      b_ptr[i] = ok ? W + (int64_t)n * p.K + b_klog[i] * V + (int64_t)kt0 * BK : zero;
-      b_inc[i] = ok ? BK : 0;
+      const int n = lbn + row < p.N ? lbn + row : p.N - 1;
+      b_ptr[i] = W + (int64_t)n * p.K + klog * V + (int64_t)kt0 * BK;
     }
   };
   const bool k_ragged = (p.K % BK) != 0;            // only the very last stage can run past K
@@ -239,14 +245,14 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
     const bool tail = k_ragged && (kt + 1) * BK > p.K;
     if constexpr (!CONV) {
       const T* src = a_ptr[i];
-      if (tail && kt * BK + a_klog[i] * V >= p.K) src = zero;
+      if (tail && kt * BK + klog * V >= p.K) src = zero;
       EMO_GLDS16(src, sa + (i * NW + wave) * 1024);
-      a_ptr[i] += a_inc[i];
+      a_ptr[i] += BK;
     } else {
       const int Hin = p.upsample2x ? 2 * p.H : p.H, Win = p.upsample2x ? 2 * p.W_ : p.W_;
-      const int k0 = kt * BK + a_klog[i] * V;
+      const int k0 = kt * BK + klog * V;
       int tap, ci;
-      if (cin_aligned) { tap = (kt * BK) / p.Cin; ci = kt * BK - tap * p.Cin + a_klog[i] * V; }   // tap is wave-uniform (SALU)
+      if (cin_aligned) { tap = (kt * BK) / p.Cin; ci = kt * BK - tap * p.Cin + klog * V; }   // tap is wave-uniform (SALU)
       else { tap = k0 / p.Cin; ci = k0 - tap * p.Cin; }
       const int ky = tap / 3, kx = tap - ky * 3;
       int iy = a_cr[i].iy0 + ky, ix = a_cr[i].ix0 + kx;
@@ -263,9 +269,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
     unsigned char* sb = lds + slot * Tile::STAGE_BYTES + Tile::A_BYTES;
     const bool tail = k_ragged && (kt + 1) * BK > p.K;
     const T* src = b_ptr[i];
-    if (tail && kt * BK + b_klog[i] * V >= p.K) src = zero;
+    if (tail && kt * BK + klog * V >= p.K) src = zero;
     EMO_GLDS16(src, sb + (i * NW + wave) * 1024);
-    b_ptr[i] += b_inc[i];
+    b_ptr[i] += BK;
   };
   // after the last glds of a stage: step the loader to the next stage of the stream (next tile when this one is done)
   auto advance_loader = [&]() {
@@ -278,18 +284,19 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
 
   // fragment read addresses (LDS byte offsets, stage-relative), swizzled
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-  unsigned fa_off[WTM][KSTEPS], fb_off[WTN][KSTEPS];
+  // k-step kk reads chunk (kk*2 + half) ^ swz(r) = ((half ^ swz(r)) ^ (kk << 1)): with 128-byte aligned stages the address
+  // of step kk is the step-0 address XOR (kk << 5) - one register per fragment row instead of KSTEPS
+  static_assert(KSTEPS * 32 <= KBYTES && (Tile::STAGE_BYTES % 128) == 0 && (Tile::A_BYTES % 128) == 0, "XOR k-step addressing");
+  unsigned fa0[WTM], fb0[WTN];
 #pragma unroll
   for (int i = 0; i < WTM; i++) {
     const int r = wvm * 32 * WTM + i * 32 + l31;
-#pragma unroll
-    for (int kk = 0; kk < KSTEPS; kk++) fa_off[i][kk] = r * KBYTES + (((kk * 2 + half) ^ swz(r)) * 16);
+    fa0[i] = lds_base + r * KBYTES + ((half ^ swz(r)) * 16);
   }
 #pragma unroll
   for (int j = 0; j < WTN; j++) {
     const int r = wvn * 32 * WTN + j * 32 + l31;
-#pragma unroll
-    for (int kk = 0; kk < KSTEPS; kk++) fb_off[j][kk] = Tile::A_BYTES + r * KBYTES + (((kk * 2 + half) ^ swz(r)) * 16);
+    fb0[j] = lds_base + Tile::A_BYTES + r * KBYTES + ((half ^ swz(r)) * 16);
   }
 
   T* __restrict__ C = (T*)p.C;
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
     }
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // everyone's part of stage gs landed; everyone finished reading slot (gs-1)%NS
-    const unsigned st = lds_base + (gs % NS) * Tile::STAGE_BYTES;
+    const unsigned st = (gs % NS) * Tile::STAGE_BYTES;   // stage offset (fa0 / fb0 carry the LDS base)
     const bool more = l_iter < tiles_all;
     const int kt_next = kt0 + l_kt, slot_next = (gs + NS - 1) % NS;
     // Software-pipelined stage: the only exposed latency is the first k-step's fragment read.  The fragment reads
@@ -345,9 +352,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
     // MFMAs of step kk, so their issue cost and latency hide under the matrix pipe.
     uint4 fa[2][WTM], fb[2][WTN];
 #pragma unroll
-    for (int i = 0; i < WTM; i++) fa[0][i] = lds_read16(st + fa_off[i][0]);
+    for (int i = 0; i < WTM; i++) fa[0][i] = lds_read16(st + fa0[i]);
 #pragma unroll
-    for (int j = 0; j < WTN; j++) fb[0][j] = lds_read16(st + fb_off[j][0]);
+    for (int j = 0; j < WTN; j++) fb[0][j] = lds_read16(st + fb0[j]);
     constexpr int NMMA = WTM * WTN, NRD = WTM + WTN;
 #ifndef EMO_LATE_ISSUE
     // the whole next ring stage is requested right behind the barrier: it then has this stage's full MFMA time to land
@@ -377,8 +384,8 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
           if constexpr ((o * NMMA) / n_side == q) {
             if constexpr (o < n_rd) {
 #ifndef EMO_ABL_NOREAD
-              if constexpr (o < WTM) fa[nxt][o] = lds_read16(st + fa_off[o][(kk + 1) % KSTEPS]);
-              else fb[nxt][o - WTM] = lds_read16(st + fb_off[o - WTM][(kk + 1) % KSTEPS]);
+              if constexpr (o < WTM) fa[nxt][o] = lds_read16((st + fa0[o]) ^ (((kk + 1) % KSTEPS) << 5));
+              else fb[nxt][o - WTM] = lds_read16((st + fb0[o - WTM]) ^ (((kk + 1) % KSTEPS) << 5));
 #endif
             } else {
               constexpr int g = g_begin + (o - n_rd);
