@@ -51,6 +51,7 @@ static constexpr int RPB = 256 / KBYTES;         // LDS rows per 256-byte bank r
 __device__ __forceinline__ int swz(int row) { return (row / RPB) & (CPR - 1); }
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0, 0, 0, 0};
+__device__ int g_gemm_lds_epi = 1;   // experiment switch (EMO_GEMM_LDS_EPI=0): 0 = row-per-lane epilogue everywhere
 
 template <int WTM, int WTN, int WVM, int WVN, int NS_> struct GemmTile {
   static constexpr int NS = NS_;   // LDS ring depth
@@ -152,6 +153,108 @@ __device__ __forceinline__ void epilogue_row(const f32x16 (&acc)[WTN], const emo
           }
         }
       }
+    }
+  }
+}
+
+// bf16 epilogue through LDS: the row-per-lane stores of epilogue_row touch 64 different 128-byte lines with 8 bytes each per
+// wave instruction (and so do its residual loads) - on the memory-bound short-K shapes the epilogue then runs at the L2
+// REQUEST rate, ~3 TB/s.  Here a wave stages its 32-row tile rows (bias / temb / GEGLU applied, rounded to bf16 like the
+// reference's Linear output) in a private region of the ring slot the main loop has just released, reads them back
+// row-major - 16 bytes per lane, consecutive lanes along the row - adds the residual from an equally coalesced 16-byte
+// load and stores full lines.  LDS ops are inline asm with counted lgkmcnt (a C++ LDS access would make hipcc drain the
+// next tile's prefetched stage first).
+__device__ __forceinline__ void lds_write8(unsigned addr, unsigned lo, unsigned hi) {
+  const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+template <int WTM, int WTN, int NW, int XBYTES, bool GEGLU>
+__device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], const emo_gemm_params& p, int64_t wm0, int wn0, int wave, int lane,
+                                             unsigned xbase, bf16_t* __restrict__ C, const bf16_t* __restrict__ R) {
+  constexpr int OTW = GEGLU ? WTN / 2 : WTN;                  // 32-column output tiles per wave row
+  constexpr int JMAX = (XBYTES / (NW * 32) - 16) / 64;        // tiles per pass that fit this wave's share of the slot
+  constexpr int JG = JMAX < OTW ? JMAX : OTW;
+  static_assert(JG >= 1, "transpose slot too small");
+  constexpr int PITCH = JG * 64 + 16;                          // bytes per staged row (+16: rows on different banks)
+  const int half = lane >> 5, l31 = lane & 31;
+  const unsigned xw = xbase + wave * (32 * PITCH);
+  const int n_out = GEGLU ? p.N / 2 : p.N;
+  const int oc0 = GEGLU ? (wn0 >> 1) : wn0;                    // first output column of this wave
+#pragma unroll
+  for (int i = 0; i < WTM; i++) {
+    const int64_t m_lane = wm0 + i * 32 + l31;
+    const float* rbias = (p.rowbias && m_lane < p.M) ? p.rowbias + (m_lane / p.rows_per_batch) * p.ld_rowbias : nullptr;
+#pragma unroll
+    for (int ot0 = 0; ot0 < OTW; ot0 += JG) {
+      constexpr int dummy = 0; (void)dummy;
+      constexpr int NIT = 2 * JG;                              // 16-byte chunks per lane per pass: 32 rows * 4*nt chunks / 64 lanes
+      const int nt = (OTW - ot0) < JG ? (OTW - ot0) : JG;     // tiles in this pass (compile-time after unrolling)
+      const int cw = nt * 4;                                   // 16-byte chunks per staged row
+      // ---- residual loads of the whole pass first (coalesced 16-byte chunks; chunk idx -> (row, c)): their latency hides
+      // under phase 1
+      uint4 rv[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        rv[it] = make_uint4(0, 0, 0, 0);
+        const int idx = it * 64 + lane;
+        const int row = idx / cw, c = idx - row * cw;
+        const int64_t m = wm0 + i * 32 + row;
+        const int col = oc0 + ot0 * 32 + c * 8;
+        if (R && it < 2 * nt && m < p.M && col < n_out) rv[it] = *(const uint4*)(R + m * p.ldr + col);
+      }
+      // ---- phase 1: lane <-> row, quads of 4 columns -> LDS
+#pragma unroll
+      for (int t = 0; t < JG; t++) {
+        if (ot0 + t >= OTW) break;
+        const int jv = GEGLU ? 2 * (ot0 + t) : (ot0 + t);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int nw0 = wn0 + jv * 32 + 8 * g + 4 * half;    // column in W-row space
+          float o[4] = {acc[i][jv][4 * g], acc[i][jv][4 * g + 1], acc[i][jv][4 * g + 2], acc[i][jv][4 * g + 3]};
+          if (nw0 < p.N) {
+            if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
+            if (rbias) { const float4 b4 = *(const float4*)(rbias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
+            if constexpr (GEGLU) {
+              float gt[4] = {acc[i][jv + 1][4 * g], acc[i][jv + 1][4 * g + 1], acc[i][jv + 1][4 * g + 2], acc[i][jv + 1][4 * g + 3]};
+              if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0 + 32); gt[0] += b4.x; gt[1] += b4.y; gt[2] += b4.z; gt[3] += b4.w; }
+              float g0, g1, g2, g3;
+              gelu_erf_poly2(gt[0], gt[1], g0, g1);
+              gelu_erf_poly2(gt[2], gt[3], g2, g3);
+              o[0] *= g0; o[1] *= g1; o[2] *= g2; o[3] *= g3;
+            }
+          }
+          lds_write8(xw + l31 * PITCH + t * 64 + (8 * g + 4 * half) * 2, pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+        }
+      }
+      wait_lgkmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase 2: read back row-major, add the residual, store full lines
+      uint4 xv[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int idx = it * 64 + lane;
+        const int row = idx / cw, c = idx - row * cw;
+        if (it < 2 * nt) xv[it] = lds_read16(xw + row * PITCH + c * 16);
+      }
+      wait_lgkmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int idx = it * 64 + lane;
+        const int row = idx / cw, c = idx - row * cw;
+        const int64_t m = wm0 + i * 32 + row;
+        const int col = oc0 + ot0 * 32 + c * 8;
+        if (it < 2 * nt && m < p.M && col < n_out) {
+          float x[8], r[8];
+          unpack16<bf16_t>(xv[it], x);
+          unpack16<bf16_t>(rv[it], r);
+#pragma unroll
+          for (int e = 0; e < 8; e++) x[e] = (x[e] + r[e]) * p.out_scale;
+          *(uint4*)(C + m * p.ldc + col) = pack16<bf16_t>(x);
+        }
+      }
+      wait_lgkmcnt<0>();   // (all reads retired before the next pass overwrites the region)
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -301,6 +404,11 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
 
   T* __restrict__ C = (T*)p.C;
   const T* __restrict__ R = (const T*)p.residual;
+  // coalesced LDS-staged epilogue (bf16, row-major, single pass): needs whole 16-byte chunks everywhere
+  const int n_out_all = p.geglu ? p.N / 2 : p.N;
+  const bool use_lds_epi = !TRANS && sizeof(T) == 2 && nsplit == 1 && nk > 0 && g_gemm_lds_epi && (n_out_all & 7) == 0 && (p.N & 3) == 0 &&
+                           (p.ldc & 7) == 0 && (!R || (p.ldr & 7) == 0) && (!p.rowbias || (p.ld_rowbias & 3) == 0) &&
+                           (!p.geglu || (WTN % 2 == 0));
 
   // stream prologue: NS-1 stages in flight
   int gs = 0;   // stream stage counter of the MFMA loop (ring slot = gs % NS)
@@ -409,7 +517,23 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
   const int64_t wm0 = bm + wvm * 32 * WTM;
   const int wn0 = bn + wvn * 32 * WTN;
 
-  if constexpr (!TRANS) {
+  bool lds_epilogue = false;
+  if constexpr (!TRANS && sizeof(T) == 2) {
+    lds_epilogue = use_lds_epi;
+    if (lds_epilogue) {
+      // the slot the last stage was read from is free once every wave has finished that stage (the other slot holds the
+      // next tile's prefetched first stage); it is rewritten by the loader only behind the next stage's barrier
+      __builtin_amdgcn_s_barrier();
+      const unsigned xbase = lds_base + ((gs + NS - 1) % NS) * Tile::STAGE_BYTES;
+      if (p.geglu) {
+        if constexpr (WTN % 2 == 0) epilogue_lds<WTM, WTN, NW, Tile::STAGE_BYTES, true>(acc, p, wm0, wn0, wave, lane, xbase, (bf16_t*)C, (const bf16_t*)R);
+      } else {
+        epilogue_lds<WTM, WTN, NW, Tile::STAGE_BYTES, false>(acc, p, wm0, wn0, wave, lane, xbase, (bf16_t*)C, (const bf16_t*)R);
+      }
+    }
+  }
+  if (lds_epilogue) {
+  } else if constexpr (!TRANS) {
     // lane <-> output row m; register quad g of tile j <-> columns j*32 + 8*g + 4*half + {0..3}
 #pragma unroll
     for (int i = 0; i < WTM; i++) {
@@ -427,7 +551,11 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
           }
         continue;
       }
+#ifndef EMO_ABL_NOEPI
       epilogue_row<T, WTN>(acc[i], p, m, m_ok, wn0, half, C, R);
+#else
+      if (acc[i][0][0] == 123.456f) epilogue_row<T, WTN>(acc[i], p, m, m_ok, wn0, half, C, R);
+#endif
     }
   } else {
     // TRANS: lane <-> column n; register quad g <-> rows 8*g + 4*half + {0..3} (4 CONSECUTIVE rows), which are 4
@@ -842,6 +970,12 @@ static int launch_gemm(const emo_gemm_params& p, int S, hipStream_t st) {
   // persistent launch: as many blocks as the chip holds at once (by LDS, <= 4 per CU), each walking its tiles; a
   // multiple of 8 so that a block's tiles all map to its own XCD
   static const int persist = env_int("EMO_GEMM_PERSIST", 1);
+  static const int lds_epi_set = [] {
+    const int v = env_int("EMO_GEMM_LDS_EPI", 1);
+    if (v != 1) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_lds_epi), &v, sizeof(int));
+    return v;
+  }();
+  (void)lds_epi_set;
   int64_t slots = (256 * Tile::BPC / S) & ~7;
   if (slots < 8) slots = 8;
   const int64_t gx = (persist && tiles > slots) ? slots : tiles;
@@ -865,6 +999,12 @@ static int dispatch_tile(const emo_gemm_params& p, const GemmPlan& pl, int S, hi
   // (4-wave 128x256 / 256x128 tiles were measured 15-35 % slower than the 8-wave 256x256 at equal LDS traffic per MFMA)
 #ifdef EMO_FORCE22
   return launch_gemm<T, CONV, TRANS, 2, 2, 2, 2, EMO_NS22>(p, S, st);
+#endif
+#ifdef EMO_FORCE_2224   // experiment: 128x256 tile, 8 waves of 64x64
+  if (!CONV && !TRANS && S == 1) return launch_gemm<T, CONV, TRANS, 2, 2, 2, 4, 2>(p, S, st);
+#endif
+#ifdef EMO_FORCE_1542   // experiment: 128x320 tile, 8 waves of 32x160
+  if (!CONV && !TRANS && S == 1 && !p.geglu) return launch_gemm<T, CONV, TRANS, 1, 5, 4, 2, 2>(p, S, st);
 #endif
   if (pl.big && S == 1) return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, 2>(p, S, st);   // 2x4 waves of 128x64, 2 x 64 KB ring
   if (pl.small) return launch_gemm<T, CONV, TRANS, 1, 1, 2, 2, EMO_NS11>(p, S, st);   // 2x2 waves of 32x32, 2 x 16 KB ring
