@@ -259,6 +259,22 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], cons
   }
 }
 
+// Accumulators start at the bias (row-major layout: register quad g of tile j <-> columns j*32 + 8*g + 4*half + {0..3}):
+// the epilogue then has no bias loads (an L2 round trip per pass with only 2-4 waves per SIMD to hide it) or adds.
+template <int WTM, int WTN>
+__device__ __forceinline__ void init_acc_bias(f32x16 (&acc)[WTM][WTN], const float* __restrict__ bias, int wn0, int half, int N) {
+#pragma unroll
+  for (int j = 0; j < WTN; j++)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int n0 = wn0 + j * 32 + 8 * g + 4 * half;
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias && n0 < N) b4 = *(const float4*)(bias + n0);   // N % 4 == 0 checked by the caller
+#pragma unroll
+      for (int i = 0; i < WTM; i++) { acc[i][j][4 * g] = b4.x; acc[i][j][4 * g + 1] = b4.y; acc[i][j][4 * g + 2] = b4.z; acc[i][j][4 * g + 3] = b4.w; }
+    }
+}
+
 struct ConvRow { int img, iy0, ix0; };
 
 template <typename T, bool CONV, bool TRANS, int WTM, int WTN, int WVM, int WVN, int NS>
@@ -404,6 +420,10 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
 
   T* __restrict__ C = (T*)p.C;
   const T* __restrict__ R = (const T*)p.residual;
+  // row-major single-pass outputs start their accumulators at the bias; the epilogues then see bias == nullptr
+  const bool bias_in_acc = !TRANS && nsplit == 1 && p.bias != nullptr && (p.N & 3) == 0;
+  emo_gemm_params pe = p;
+  if (bias_in_acc) pe.bias = nullptr;
   // coalesced LDS-staged epilogue (bf16, row-major, single pass): needs whole 16-byte chunks everywhere
   const int n_out_all = p.geglu ? p.N / 2 : p.N;
   const bool use_lds_epi = !TRANS && sizeof(T) == 2 && nsplit == 1 && nk > 0 && g_gemm_lds_epi && (n_out_all & 7) == 0 && (p.N & 3) == 0 &&
@@ -430,12 +450,16 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
   const int tiles_left = (tiles_all - 1 - c_iter) / G;   // tiles of this block after this one
 
   f32x16 acc[WTM][WTN];
+  if (bias_in_acc) {
+    init_acc_bias<WTM, WTN>(acc, p.bias, bn + wvn * 32 * WTN, half, p.N);
+  } else {
 #pragma unroll
-  for (int i = 0; i < WTM; i++)
+    for (int i = 0; i < WTM; i++)
 #pragma unroll
-    for (int j = 0; j < WTN; j++)
+      for (int j = 0; j < WTN; j++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  }
 
   for (int kt = 0; kt < nk; kt++, gs++) {
     // stage gs must have landed; up to NS-2 younger stages may still be in flight - fewer at the end of the stream, and none
@@ -526,9 +550,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
       __builtin_amdgcn_s_barrier();
       const unsigned xbase = lds_base + ((gs + NS - 1) % NS) * Tile::STAGE_BYTES;
       if (p.geglu) {
-        if constexpr (WTN % 2 == 0) epilogue_lds<WTM, WTN, NW, Tile::STAGE_BYTES, true>(acc, p, wm0, wn0, wave, lane, xbase, (bf16_t*)C, (const bf16_t*)R);
+        if constexpr (WTN % 2 == 0) epilogue_lds<WTM, WTN, NW, Tile::STAGE_BYTES, true>(acc, pe, wm0, wn0, wave, lane, xbase, (bf16_t*)C, (const bf16_t*)R);
       } else {
-        epilogue_lds<WTM, WTN, NW, Tile::STAGE_BYTES, false>(acc, p, wm0, wn0, wave, lane, xbase, (bf16_t*)C, (const bf16_t*)R);
+        epilogue_lds<WTM, WTN, NW, Tile::STAGE_BYTES, false>(acc, pe, wm0, wn0, wave, lane, xbase, (bf16_t*)C, (const bf16_t*)R);
       }
     }
   }
@@ -552,9 +576,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
         continue;
       }
 #ifndef EMO_ABL_NOEPI
-      epilogue_row<T, WTN>(acc[i], p, m, m_ok, wn0, half, C, R);
+      epilogue_row<T, WTN>(acc[i], pe, m, m_ok, wn0, half, C, R);
 #else
-      if (acc[i][0][0] == 123.456f) epilogue_row<T, WTN>(acc[i], p, m, m_ok, wn0, half, C, R);
+      if (acc[i][0][0] == 123.456f) epilogue_row<T, WTN>(acc[i], pe, m, m_ok, wn0, half, C, R);
 #endif
     }
   } else {
@@ -746,6 +770,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const emo_gemm_par
 
   T* __restrict__ C = (T*)p.C;
   const T* __restrict__ R = (const T*)p.residual;
+  emo_gemm_params pe = p;     // the accumulators start at the bias: the epilogue sees none
+  pe.bias = nullptr;
 
   // ---- stream prologue: halo of the first chunk, weights of the first stage
   setup_halo(h_iter);
@@ -759,12 +785,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const emo_gemm_par
   for (int c_iter = blockIdx.x; c_iter < tiles_all; c_iter += G) {
     const int c_tile = tile_of(c_iter);
     f32x16 acc[WTM][WTN];
-#pragma unroll
-    for (int i = 0; i < WTM; i++)
-#pragma unroll
-      for (int j = 0; j < WTN; j++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    init_acc_bias<WTM, WTN>(acc, p.bias, (c_tile % tiles_n) * BN + wvn * 32 * WTN, half, p.N);   // zeros without a bias
 
     for (int c = 0; c < nchunks; c++, gc++) {
       const unsigned stH = lds_base + (gc & 1) * Halo::HALO_BYTES;
@@ -828,7 +849,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const emo_gemm_par
     for (int i = 0; i < WTM; i++) {
       const int y = y0 + (wvm * WTM + i) * 2 + (l31 >> 4), x = x0 + (l31 & 15);
       const int64_t m = ((int64_t)img * p.H + y) * p.W_ + x;
-      epilogue_row<T, WTN>(acc[i], p, m, true, wn0, half, C, R);
+      epilogue_row<T, WTN>(acc[i], pe, m, true, wn0, half, C, R);
     }
   }
 }
