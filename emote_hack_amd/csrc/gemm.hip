@@ -168,8 +168,9 @@ __device__ __forceinline__ void lds_write8(unsigned addr, unsigned lo, unsigned 
   const unsigned long long v = ((unsigned long long)hi << 32) | lo;
   asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
-template <int WTM, int WTN, int NW, int XBYTES, bool GEGLU>
-__device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], const emo_gemm_params& p, int64_t wm0, int wn0, int wave, int lane,
+// m_of(i, row) -> global output row of row `row` (0..31) of this wave's MFMA tile row i, or -1 if it does not exist
+template <int WTM, int WTN, int NW, int XBYTES, bool GEGLU, typename MF>
+__device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], const emo_gemm_params& p, MF m_of, int wn0, int wave, int lane,
                                              unsigned xbase, bf16_t* __restrict__ C, const bf16_t* __restrict__ R) {
   constexpr int OTW = GEGLU ? WTN / 2 : WTN;                  // 32-column output tiles per wave row
   constexpr int JMAX = (XBYTES / (NW * 32) - 16) / 64;        // tiles per pass that fit this wave's share of the slot
@@ -182,8 +183,8 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], cons
   const int oc0 = GEGLU ? (wn0 >> 1) : wn0;                    // first output column of this wave
 #pragma unroll
   for (int i = 0; i < WTM; i++) {
-    const int64_t m_lane = wm0 + i * 32 + l31;
-    const float* rbias = (p.rowbias && m_lane < p.M) ? p.rowbias + (m_lane / p.rows_per_batch) * p.ld_rowbias : nullptr;
+    const int64_t m_lane = m_of(i, l31);
+    const float* rbias = (p.rowbias && m_lane >= 0) ? p.rowbias + (m_lane / p.rows_per_batch) * p.ld_rowbias : nullptr;
 #pragma unroll
     for (int ot0 = 0; ot0 < OTW; ot0 += JG) {
       constexpr int dummy = 0; (void)dummy;
@@ -198,9 +199,9 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], cons
         rv[it] = make_uint4(0, 0, 0, 0);
         const int idx = it * 64 + lane;
         const int row = idx / cw, c = idx - row * cw;
-        const int64_t m = wm0 + i * 32 + row;
+        const int64_t m = it < 2 * nt ? m_of(i, row) : -1;
         const int col = oc0 + ot0 * 32 + c * 8;
-        if (R && it < 2 * nt && m < p.M && col < n_out) rv[it] = *(const uint4*)(R + m * p.ldr + col);
+        if (R && m >= 0 && col < n_out) rv[it] = *(const uint4*)(R + m * p.ldr + col);
       }
       // ---- phase 1: lane <-> row, quads of 4 columns -> LDS
 #pragma unroll
@@ -242,9 +243,9 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], cons
       for (int it = 0; it < NIT; it++) {
         const int idx = it * 64 + lane;
         const int row = idx / cw, c = idx - row * cw;
-        const int64_t m = wm0 + i * 32 + row;
+        const int64_t m = it < 2 * nt ? m_of(i, row) : -1;
         const int col = oc0 + ot0 * 32 + c * 8;
-        if (it < 2 * nt && m < p.M && col < n_out) {
+        if (m >= 0 && col < n_out) {
           float x[8], r[8];
           unpack16<bf16_t>(xv[it], x);
           unpack16<bf16_t>(rv[it], r);
@@ -549,10 +550,11 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
       // next tile's prefetched first stage); it is rewritten by the loader only behind the next stage's barrier
       __builtin_amdgcn_s_barrier();
       const unsigned xbase = lds_base + ((gs + NS - 1) % NS) * Tile::STAGE_BYTES;
+      auto m_of = [&](int i, int row) -> int64_t { const int64_t m = wm0 + i * 32 + row; return m < p.M ? m : -1; };
       if (p.geglu) {
-        if constexpr (WTN % 2 == 0) epilogue_lds<WTM, WTN, NW, Tile::STAGE_BYTES, true>(acc, pe, wm0, wn0, wave, lane, xbase, (bf16_t*)C, (const bf16_t*)R);
+        if constexpr (WTN % 2 == 0) epilogue_lds<WTM, WTN, NW, Tile::STAGE_BYTES, true>(acc, pe, m_of, wn0, wave, lane, xbase, (bf16_t*)C, (const bf16_t*)R);
       } else {
-        epilogue_lds<WTM, WTN, NW, Tile::STAGE_BYTES, false>(acc, pe, wm0, wn0, wave, lane, xbase, (bf16_t*)C, (const bf16_t*)R);
+        epilogue_lds<WTM, WTN, NW, Tile::STAGE_BYTES, false>(acc, pe, m_of, wn0, wave, lane, xbase, (bf16_t*)C, (const bf16_t*)R);
       }
     }
   }
@@ -770,8 +772,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const emo_gemm_par
 
   T* __restrict__ C = (T*)p.C;
   const T* __restrict__ R = (const T*)p.residual;
-  emo_gemm_params pe = p;     // the accumulators start at the bias: the epilogue sees none
+  emo_gemm_params pe = p;     // the accumulators start at bias + temb row bias: the epilogue sees neither
   pe.bias = nullptr;
+  pe.rowbias = nullptr;
+  const bool lds_epi = sizeof(T) == 2 && g_gemm_lds_epi && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!R || (p.ldr & 7) == 0);
 
   // ---- stream prologue: halo of the first chunk, weights of the first stage
   setup_halo(h_iter);
@@ -786,6 +790,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const emo_gemm_par
     const int c_tile = tile_of(c_iter);
     f32x16 acc[WTM][WTN];
     init_acc_bias<WTM, WTN>(acc, p.bias, (c_tile % tiles_n) * BN + wvn * 32 * WTN, half, p.N);   // zeros without a bias
+    if (p.rowbias) {   // temb row bias (resnet.py:188): one row per frame, a patch lies inside one frame
+      const int tm0 = c_tile / tiles_n;
+      const int64_t m0 = (int64_t)(tm0 / tpi) * p.H * p.W_;
+      const float* rb = p.rowbias + (m0 / p.rows_per_batch) * p.ld_rowbias;
+      const int wnb = (c_tile % tiles_n) * BN + wvn * 32 * WTN;
+#pragma unroll
+      for (int j = 0; j < WTN; j++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int n0 = wnb + j * 32 + 8 * g + 4 * half;
+          if (n0 < p.N) {
+            const float4 b4 = *(const float4*)(rb + n0);
+#pragma unroll
+            for (int i = 0; i < WTM; i++) { acc[i][j][4 * g] += b4.x; acc[i][j][4 * g + 1] += b4.y; acc[i][j][4 * g + 2] += b4.z; acc[i][j][4 * g + 3] += b4.w; }
+          }
+        }
+    }
 
     for (int c = 0; c < nchunks; c++, gc++) {
       const unsigned stH = lds_base + (gc & 1) * Halo::HALO_BYTES;
@@ -845,11 +866,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const emo_gemm_par
     const int img = tm / tpi, rem = tm % tpi;
     const int y0 = (rem / tpx) * Halo::PH, x0 = (rem % tpx) * Halo::PW;
     const int wn0 = (c_tile % tiles_n) * BN + wvn * 32 * WTN;
+    bool staged = false;
+    if constexpr (sizeof(T) == 2) {
+      if (lds_epi) {
+        // the halo buffer of the chunk just finished is free once every wave is past its last tap; the halo loader
+        // rewrites it only behind the next stage's barrier
+        __builtin_amdgcn_s_barrier();
+        auto m_of = [&](int i, int row) -> int64_t {
+          return ((int64_t)img * p.H + y0 + (wvm * WTM + i) * 2 + (row >> 4)) * p.W_ + x0 + (row & 15);
+        };
+        epilogue_lds<WTM, WTN, NW, Halo::HALO_BYTES, false>(acc, pe, m_of, wn0, wave, lane, lds_base + ((gc + 1) & 1) * Halo::HALO_BYTES,
+                                                            (bf16_t*)C, (const bf16_t*)R);
+        staged = true;
+      }
+    }
+    if (!staged) {
 #pragma unroll
-    for (int i = 0; i < WTM; i++) {
-      const int y = y0 + (wvm * WTM + i) * 2 + (l31 >> 4), x = x0 + (l31 & 15);
-      const int64_t m = ((int64_t)img * p.H + y) * p.W_ + x;
-      epilogue_row<T, WTN>(acc[i], pe, m, true, wn0, half, C, R);
+      for (int i = 0; i < WTM; i++) {
+        const int y = y0 + (wvm * WTM + i) * 2 + (l31 >> 4), x = x0 + (l31 & 15);
+        const int64_t m = ((int64_t)img * p.H + y) * p.W_ + x;
+        epilogue_row<T, WTN>(acc[i], pe, m, true, wn0, half, C, R);
+      }
     }
   }
 }
@@ -1074,7 +1111,8 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
     static const int halo_mode = env_int("EMO_CONV_HALO", 1);
     const int bk = KBYTES / (p.dtype == EMO_F32 ? 4 : 2);
     if (halo_mode && conv && p.stride == 1 && !p.upsample2x && !p.transpose_out && !p.geglu && S == 1 && p.Cin % bk == 0 &&
-        p.H % Halo::PH == 0 && p.W_ % Halo::PW == 0 && (p.N & 3) == 0) {
+        p.H % Halo::PH == 0 && p.W_ % Halo::PW == 0 && (p.N & 3) == 0 &&
+        (!p.rowbias || (p.rows_per_batch % (p.H * p.W_) == 0 && (p.ld_rowbias & 3) == 0))) {
       static bool once = false;
       if (!once) {
         hipError_t e1 = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo::LDS_BYTES);
