@@ -42,7 +42,7 @@ class AttentionParams(C.Structure):
         ("k0", C.c_void_p), ("ldk0", C.c_int64), ("v0t", C.c_void_p), ("ldv0t", C.c_int64), ("Lk0", C.c_int),
         ("k1", C.c_void_p), ("ldk1", C.c_int64), ("v1t", C.c_void_p), ("ldv1t", C.c_int64), ("Lk1", C.c_int),
         ("seg0_div", C.c_int),
-        ("seg1_div", C.c_int), ("seg1_first_batch", C.c_int),
+        ("seg1_div", C.c_int), ("seg1_first_batch", C.c_int), ("seg1_skip", C.c_int),
         ("out", C.c_void_p), ("ldo", C.c_int64),
         ("B", C.c_int), ("Lq", C.c_int), ("heads", C.c_int), ("d", C.c_int),
         ("scale", C.c_float),

@@ -269,7 +269,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, H: int, W: int, 
 
 # ----------------------------------------------------------------------------- attention
 def attention(q, k0, v0t, Lk0, *, B, Lq, heads, d, scale, seg0_div=1, k1=None, v1t=None, Lk1=0, seg1_div=1,
-              seg1_first_batch=0) -> torch.Tensor:
+              seg1_first_batch=0, seg1_skip=0) -> torch.Tensor:
     """q (B*Lq, >=heads*d) rows view; k0 rows view; v0t (Bk, heads*d, ld) V^T tensors."""
     _need_cuda(q, k0, v0t)
     p = AttentionParams()
@@ -282,7 +282,7 @@ def attention(q, k0, v0t, Lk0, *, B, Lq, heads, d, scale, seg0_div=1, k1=None, v
     if k1 is not None:
         pk1, ldk1 = _rows(k1)
         p.k1, p.ldk1, p.v1t, p.ldv1t, p.Lk1 = pk1.value, ldk1, v1t.data_ptr(), v1t.stride(1), Lk1
-        p.seg1_div, p.seg1_first_batch = seg1_div, seg1_first_batch
+        p.seg1_div, p.seg1_first_batch, p.seg1_skip = seg1_div, seg1_first_batch, seg1_skip
     else:
         p.seg1_div = 1
     p.out, p.ldo = out.data_ptr(), out.stride(0)

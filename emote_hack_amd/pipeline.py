@@ -24,6 +24,8 @@ from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import Callable, List, Optional, Union
 
+import os
+
 import torch
 
 from . import ops
@@ -66,8 +68,13 @@ class EMOAnimationPipeline:
 
     # ------------------------------------------------------------------ ReferenceNet banks
     def _write_banks(self, appearance_encoder, writer, ref_lat_rep, t, text_embeddings):
+        """ReferenceNet write pass (:711-716).  The reference runs it on [uncond-text, cond-text] copies of the image, but
+        the reader never uses the uncond bank row: for the uc rows `hidden_states_c` is overwritten by the bank-free
+        uc attention (mutual_self_attention.py:243-256), and the ReferenceNet is batch-independent.  Only the cond half
+        is computed; outputs are bit-identical (tests/test_gpu_unet.py loop parity against the full oracle)."""
         writer.clear()
-        appearance_encoder(ref_lat_rep.unsqueeze(2), t, encoder_hidden_states=text_embeddings, return_dict=False)
+        h = ref_lat_rep.shape[0] // 2
+        appearance_encoder(ref_lat_rep[h:].unsqueeze(2), t, encoder_hidden_states=text_embeddings[h:], return_dict=False)
         return writer
 
     def _pack_banks(self, writer):
@@ -126,7 +133,7 @@ class EMOAnimationPipeline:
         if st.use_graphs:
             st.graph_pool = torch.cuda.graph_pool_handle()
             st.writer_pool = torch.cuda.graph_pool_handle()   # own pool: the write pass may run concurrently with the down path
-            st.overlap = (not st.dist_pre) and fusion_blocks == "midup"
+            st.overlap = (not st.dist_pre) and fusion_blocks == "midup" and os.environ.get("EMO_NO_OVERLAP") != "1"
             st.side = torch.cuda.Stream() if st.overlap else None
         if audio_features is not None:
             audio_features = audio_features.to(dev)

@@ -51,8 +51,14 @@ class ReferenceAttentionControl:
                 if not lst:
                     continue
                 t = lst[0] if len(lst) == 1 else torch.cat(lst, dim=1)  # cat of several writes along tokens (:239)
+                # Under CFG the bank row of an uncond batch is dead: hidden_states_c of the uc rows is overwritten by the
+                # bank-free uc path (:243-256).  A writer that ran on the cond images only hands over B/2 rows.
+                c.bank_skip = 0
                 if t.shape[0] < c.B:
-                    raise ValueError(f"bank has {t.shape[0]} rows but the UNet batch is {c.B}")
+                    if self.do_classifier_free_guidance and t.shape[0] == c.B - c.B // 2:
+                        c.bank_skip = c.B // 2
+                    else:
+                        raise ValueError(f"bank has {t.shape[0]} rows but the UNet batch is {c.B}")
                 c.bank_rows = t.shape[0]
                 c.banks[p] = t.reshape(-1, t.shape[-1])
             _ = nb

@@ -51,6 +51,7 @@ class _Ctx:
         self.bank_rows = 0          # B_ref
         self.written = {}
         self.uc_batches = 0         # number of leading (b f) batches that skip the bank
+        self.bank_skip = 0          # leading bank rows that were not materialised (cond-only ReferenceNet pass under CFG)
         self.active = ()
 
 
@@ -300,7 +301,7 @@ class UNet3DConditionModel:
             bank = c.banks[p]
             Lb = bank.shape[0] // c.bank_rows
             kb, vbt = self._kv(bank, w[tb + ".attn1.k"], w[tb + ".attn1.v"], Lb)
-            kw = dict(k1=kb, v1t=vbt, Lk1=Lb, seg1_div=c.F, seg1_first_batch=c.uc_batches)
+            kw = dict(k1=kb, v1t=vbt, Lk1=Lb, seg1_div=c.F, seg1_first_batch=c.uc_batches, seg1_skip=c.bank_skip)
         att = ops.attention(qk[:, :C_], qk[:, C_:], vt, HW, B=nb, Lq=HW, heads=heads, d=d, scale=scale, **kw)
         h = ops.gemm(att, w[tb + ".attn1.o.w"], w[tb + ".attn1.o.b"], residual=h)
         # --- cross attention to the text / audio context

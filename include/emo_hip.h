@@ -137,14 +137,16 @@ size_t emo_gemm_workspace_bytes(int64_t M, int N, int split_k);
  *   v0t: V^T [B][heads*d][ldv0t] (keys contiguous, ldv0t >= Lk0, multiple of 8)
  *   k1/v1t: optional second KV segment shared by `seg1_div` consecutive batches (the ReferenceNet
  *           bank repeated over frames, mutual_self_attention.py:238-241): batch b reads bank row
- *           b / seg1_div; batches b < seg1_first_batch skip it (uc rows, :243-256). */
+ *           b / seg1_div - seg1_skip; batches b < seg1_first_batch skip it (uc rows, :243-256).
+ *           seg1_skip = leading bank rows that were never materialised: under classifier-free guidance the
+ *           bank row of the uncond batch is overwritten by the uc path (:243-256) and need not exist. */
 typedef struct {
   const void* q; int64_t ldq;
   const void* k0; int64_t ldk0; const void* v0t; int64_t ldv0t; int Lk0;
   const void* k1; int64_t ldk1; const void* v1t; int64_t ldv1t; int Lk1;
   int seg0_div;   /* batch b reads k0/v0t row-block b / seg0_div (1 = per-batch keys; F = a text context
                      shared by the F frames of a clip, attention.py:118-119 without the repeat) */
-  int seg1_div; int seg1_first_batch;
+  int seg1_div; int seg1_first_batch; int seg1_skip;
   void* out; int64_t ldo;
   int B; int Lq; int heads; int d;
   float scale;
