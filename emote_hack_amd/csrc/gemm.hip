@@ -181,6 +181,7 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], cons
   const unsigned xw = xbase + wave * (32 * PITCH);
   const int n_out = GEGLU ? p.N / 2 : p.N;
   const int oc0 = GEGLU ? (wn0 >> 1) : wn0;                    // first output column of this wave
+  const bool plain = R == nullptr && p.out_scale == 1.0f;
 #pragma unroll
   for (int i = 0; i < WTM; i++) {
     const int64_t m_lane = m_of(i, l31);
@@ -246,12 +247,16 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], cons
         const int64_t m = it < 2 * nt ? m_of(i, row) : -1;
         const int col = oc0 + ot0 * 32 + c * 8;
         if (m >= 0 && col < n_out) {
-          float x[8], r[8];
-          unpack16<bf16_t>(xv[it], x);
-          unpack16<bf16_t>(rv[it], r);
+          if (plain) {   // no residual, no scale: the staged bf16 chunk is the result
+            *(uint4*)(C + m * p.ldc + col) = xv[it];
+          } else {
+            float x[8], r[8];
+            unpack16<bf16_t>(xv[it], x);
+            unpack16<bf16_t>(rv[it], r);
 #pragma unroll
-          for (int e = 0; e < 8; e++) x[e] = (x[e] + r[e]) * p.out_scale;
-          *(uint4*)(C + m * p.ldc + col) = pack16<bf16_t>(x);
+            for (int e = 0; e < 8; e++) x[e] = (x[e] + r[e]) * p.out_scale;
+            *(uint4*)(C + m * p.ldc + col) = pack16<bf16_t>(x);
+          }
         }
       }
       wait_lgkmcnt<0>();   // (all reads retired before the next pass overwrites the region)
