@@ -1063,6 +1063,12 @@ static int dispatch_tile(const emo_gemm_params& p, const GemmPlan& pl, int S, hi
 #ifdef EMO_FORCE22
   return launch_gemm<T, CONV, TRANS, 2, 2, 2, 2, EMO_NS22>(p, S, st);
 #endif
+#ifdef EMO_FORCE_3222   // experiment: 192x128 tile, 4 waves of 96x64, 2 blocks per CU
+  if (!CONV && !TRANS && S == 1) return launch_gemm<T, CONV, TRANS, 3, 2, 2, 2, 2>(p, S, st);
+#endif
+#ifdef EMO_FORCE_2322   // experiment: 128x192 tile, 4 waves of 64x96, 2 blocks per CU
+  if (!CONV && !TRANS && S == 1 && !p.geglu) return launch_gemm<T, CONV, TRANS, 2, 3, 2, 2, 2>(p, S, st);
+#endif
 #ifdef EMO_FORCE_2224   // experiment: 128x256 tile, 8 waves of 64x64
   if (!CONV && !TRANS && S == 1) return launch_gemm<T, CONV, TRANS, 2, 2, 2, 4, 2>(p, S, st);
 #endif

@@ -260,7 +260,7 @@ class UNet3DConditionModel:
         self._w = w
 
     # ------------------------------------------------------------------ blocks (all HIP launches)
-    def _resnet(self, r, x, temb_all, c: _Ctx, H, W, scale=1.0):
+    def _resnet(self, r, x, temb_all, c: _Ctx, H, W, scale=1.0, out=None):
         """resnet.py:177-207.  GN statistics are JOINT over the F frames of a batch row (5-D GroupNorm)."""
         w, p = self._w, r.prefix
         G, eps = self.config["norm_num_groups"], self.config["norm_eps"]
@@ -271,7 +271,7 @@ class UNet3DConditionModel:
                               rowbias=temb_all[:, off:off + r.cout], rows_per_batch=c.F * H * W)
         h = ops.group_norm(h, w[p + ".norm2.g"], w[p + ".norm2.b"], c.B, G, eps, True, out=h)
         sc = ops.gemm(x, w[p + ".sc.w"], w[p + ".sc.b"]) if r.has_shortcut else x
-        out, _, _ = ops.conv3x3(h, w[p + ".conv2.w"], w[p + ".conv2.b"], n_img, H, W, residual=sc, out_scale=1.0 / scale)
+        out, _, _ = ops.conv3x3(h, w[p + ".conv2.w"], w[p + ".conv2.b"], n_img, H, W, residual=sc, out_scale=1.0 / scale, out=out)
         return out
 
     def _kv(self, rows, wk, wv, L):
@@ -280,7 +280,7 @@ class UNet3DConditionModel:
         vt = ops.gemm(rows, wv, transpose_rows=L, transpose_ld=_round_up(L, 8))
         return k, vt
 
-    def _transformer(self, a, x, ctx_rows, ctx_len, ctx_div, c: _Ctx, H, W):
+    def _transformer(self, a, x, ctx_rows, ctx_len, ctx_div, c: _Ctx, H, W, out=None):
         """attention.py:112-161 + 276-320, and the write/read hooks of mutual_self_attention.py:199-284."""
         w, p = self._w, a.prefix
         tb = p + ".transformer_blocks.0"
@@ -314,9 +314,9 @@ class UNet3DConditionModel:
         n3 = ops.layer_norm(h, w[tb + ".norm3.g"], w[tb + ".norm3.b"])
         g = ops.gemm(n3, w[tb + ".ff1.w"], w[tb + ".ff1.b"], geglu=True)
         h = ops.gemm(g, w[tb + ".ff2.w"], w[tb + ".ff2.b"], residual=h)
-        return ops.gemm(h, w[p + ".proj_out.w"], w[p + ".proj_out.b"], residual=x)
+        return ops.gemm(h, w[p + ".proj_out.w"], w[p + ".proj_out.b"], residual=x, out=out)
 
-    def _motion(self, mo, x, c: _Ctx, H, W):
+    def _motion(self, mo, x, c: _Ctx, H, W, out=None):
         """motion_module.py:139-163,215-227,275-334 (VanillaTemporalModule)."""
         w = self._w
         p = mo.prefix + ".temporal_transformer"
@@ -337,7 +337,7 @@ class UNet3DConditionModel:
         n = ops.layer_norm(h, w[tb + ".ff_norm.g"], w[tb + ".ff_norm.b"])
         g = ops.gemm(n, w[tb + ".ff1.w"], w[tb + ".ff1.b"], geglu=True)
         h = ops.gemm(g, w[tb + ".ff2.w"], w[tb + ".ff2.b"], residual=h)
-        return ops.gemm(h, w[p + ".proj_out.w"], w[p + ".proj_out.b"], residual=x)
+        return ops.gemm(h, w[p + ".proj_out.w"], w[p + ".proj_out.b"], residual=x, out=out)
 
     # ------------------------------------------------------------------ forward (three stages so that the sampler can
     # overlap the ReferenceNet pass with the bank-independent down path on a second HIP stream)
@@ -388,25 +388,58 @@ class UNet3DConditionModel:
         s.ctx_rows = ops.convert(ctx.float().reshape(-1, ctx.shape[2]), dtp)
         s.ctrl = (down_block_additional_residuals, mid_block_additional_residual)
         x = ops.ncfhw_to_rows(sample, dtp, cpad=_round_up(Cin, 8))
-        s.x, _, _ = ops.conv3x3(x, w["conv_in.w"], w["conv_in.b"], B * F, H, W)
-        s.skips = [s.x]
+        # Zero-copy skip connections: every skip tensor is produced straight into the RIGHT columns of the buffer the up
+        # path will read as cat([hidden, skip]) (unet_3d_blocks.py:627-629), and the up path's producers write `hidden`
+        # into its LEFT columns - the concatenation never runs.  (ControlNet residuals re-materialise the skips: old path.)
+        s.zero_copy = down_block_additional_residuals is None
+        s.skips, s.n_pushed = [], 0
+        s.x, _, _ = ops.conv3x3(x, w["conv_in.w"], w["conv_in.b"], B * F, H, W, out=self._skip_slot(s, B * F * H * W, self.spec.down[0].resnets[0].cin))
+        self._push_skip(s, s.x)
         s.h, s.w = H, W
         return s
+
+    # ---- skip-connection plumbing
+    def _up_resnets(self):
+        return [r for blk in self.spec.up for r in blk.resnets]
+
+    def _skip_slot(self, s, rows, c2):
+        """View for the next skip tensor (c2 channels): the right columns of its future concat buffer."""
+        if not s.zero_copy:
+            return None
+        ups = self._up_resnets()
+        c1 = ups[len(ups) - 1 - s.n_pushed].cin - c2
+        assert c1 > 0, (c1, c2)
+        s.pending = torch.empty(rows, c1 + c2, device=self.device, dtype=self.dtype)
+        return s.pending[:, c1:]
+
+    def _push_skip(self, s, x):
+        s.skips.append(s.pending if s.zero_copy else x)
+        s.n_pushed += 1
+
+    @staticmethod
+    def _hidden_slot(s, skips, c1):
+        """View for the up path's next `hidden` (c1 channels): the left columns of the buffer on top of the skip stack."""
+        if not s.zero_copy or not skips:
+            return None
+        assert skips[-1].shape[1] > c1
+        return skips[-1][:, :c1]
 
     def _run_down(self, s):
         w, spec, dtp, dev = self._w, self.spec, self.dtype, self.device
         x, c, h_, w_ = s.x, s.c, s.h, s.w
         for blk in spec.down:
             for r, a, mo in zip(blk.resnets, blk.attentions, blk.motions):
-                x = self._resnet(r, x, s.temb_all, c, h_, w_)
+                slot = self._skip_slot(s, x.shape[0], r.cout)          # the sub-block's last op writes the skip in place
+                x = self._resnet(r, x, s.temb_all, c, h_, w_, out=slot if (a is None and mo is None) else None)
                 if a is not None:
-                    x = self._transformer(a, x, s.ctx_rows, s.ctx_len, s.ctx_div, c, h_, w_)
+                    x = self._transformer(a, x, s.ctx_rows, s.ctx_len, s.ctx_div, c, h_, w_, out=slot if mo is None else None)
                 if mo is not None:
-                    x = self._motion(mo, x, c, h_, w_)
-                s.skips.append(x)
+                    x = self._motion(mo, x, c, h_, w_, out=slot)
+                self._push_skip(s, x)
             if blk.sampler:
-                x, h_, w_ = ops.conv3x3(x, w[blk.sampler + ".w"], w[blk.sampler + ".b"], s.B * s.F, h_, w_, stride=2)
-                s.skips.append(x)
+                slot = self._skip_slot(s, x.shape[0] // 4, x.shape[1])
+                x, h_, w_ = ops.conv3x3(x, w[blk.sampler + ".w"], w[blk.sampler + ".b"], s.B * s.F, h_, w_, stride=2, out=slot)
+                self._push_skip(s, x)
         down_res, mid_res = s.ctrl
         if down_res is not None and mid_res is not None:
             s.skips = [ops.add(sk, ops.ncfhw_to_rows(r.to(dev), dtp)) for sk, r in zip(s.skips, down_res)]  # unet_controlnet.py:430-439
@@ -422,20 +455,28 @@ class UNet3DConditionModel:
         x = self._transformer(spec.mid.attentions[0], x, s.ctx_rows, s.ctx_len, s.ctx_div, c, h_, w_)
         if spec.mid.motions[0] is not None:
             x = self._motion(spec.mid.motions[0], x, c, h_, w_)
-        x = self._resnet(spec.mid.resnets[1], x, s.temb_all, c, h_, w_, sc)
+        skips = s.skips
+        x = self._resnet(spec.mid.resnets[1], x, s.temb_all, c, h_, w_, sc, out=self._hidden_slot(s, skips, spec.mid.resnets[1].cout))
         if down_res is not None and mid_res is not None:
             x = ops.add(x, ops.ncfhw_to_rows(mid_res.to(dev), dtp))
-        skips = s.skips
         for blk in spec.up:
-            for r, a, mo in zip(blk.resnets, blk.attentions, blk.motions):
-                x = ops.concat_cols(x, skips.pop())  # unet_3d_blocks.py:627-629
-                x = self._resnet(r, x, s.temb_all, c, h_, w_)
+            n_res = len(blk.resnets)
+            for ri, (r, a, mo) in enumerate(zip(blk.resnets, blk.attentions, blk.motions)):
+                if s.zero_copy:
+                    x = skips.pop()                       # [hidden | skip] is already in place
+                else:
+                    x = ops.concat_cols(x, skips.pop())  # unet_3d_blocks.py:627-629
+                # the op that produces the next `hidden` writes it into the next concat buffer - unless an upsampler follows
+                last = ri == n_res - 1 and blk.sampler
+                slot = None if last else self._hidden_slot(s, skips, r.cout)
+                x = self._resnet(r, x, s.temb_all, c, h_, w_, out=slot if (a is None and mo is None) else None)
                 if a is not None:
-                    x = self._transformer(a, x, s.ctx_rows, s.ctx_len, s.ctx_div, c, h_, w_)
+                    x = self._transformer(a, x, s.ctx_rows, s.ctx_len, s.ctx_div, c, h_, w_, out=slot if mo is None else None)
                 if mo is not None:
-                    x = self._motion(mo, x, c, h_, w_)
+                    x = self._motion(mo, x, c, h_, w_, out=slot)
             if blk.sampler:
-                x, h_, w_ = ops.conv3x3(x, w[blk.sampler + ".w"], w[blk.sampler + ".b"], B * F, h_, w_, upsample2x=True)
+                x, h_, w_ = ops.conv3x3(x, w[blk.sampler + ".w"], w[blk.sampler + ".b"], B * F, h_, w_, upsample2x=True,
+                                        out=None if not s.zero_copy or not skips else self._hidden_slot(s, skips, x.shape[1]))
         rc = self._reference_control
         if rc is not None:
             rc._finish(c, self)
