@@ -115,6 +115,31 @@ def test_gemm_bias_residual(dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,geglu,res", [(8192 + 37, 2560, 320, True, False),     # 256x256 tiles, ragged last row panel, GEGLU
+                                             (70000, 640, 192, False, True),          # > 512 tiles: several tiles per persistent block
+                                             (40000, 320, 320, False, True),          # 128x160 tiles
+                                             (33000, 1280, 128, False, False)])       # 256x256, plain copy epilogue
+def test_gemm_persistent_many_tiles(dtype, M, N, K, geglu, res):
+    """The persistent loop (a block walks several tiles, the loader streams across tile boundaries), the LDS-staged
+    coalesced epilogue and the bias-initialised accumulators, against a torch f32 matmul on the same device."""
+    o = ops()
+    g = torch.Generator(device="cpu").manual_seed(123)
+    a = q(torch.randn(M, K, generator=g), dtype).to(DEV)
+    w = q(torch.randn(N, K, generator=g) / math.sqrt(K), dtype).to(DEV)
+    bias = (0.1 * torch.randn(N, generator=g)).to(DEV)
+    n_out = N // 2 if geglu else N
+    r = q(torch.randn(M, n_out, generator=g), dtype).to(DEV) if res else None
+    y = a.float() @ w.float().t() + bias
+    if geglu:   # weight rows interleaved (32 value, 32 gate): undo on the reference side
+        y = y.reshape(M, N // 64, 2, 32)
+        y = (y[:, :, 0] * F.gelu(y[:, :, 1])).reshape(M, n_out)
+    if res:
+        y = y + r.float()
+    got = o.gemm(a.to(dtype), w.to(dtype), bias, geglu=geglu, residual=r.to(dtype) if res else None)
+    close(got, y.cpu(), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_asymmetric_identity(dtype):
     """A = I with an asymmetric W catches a transposed C-write (guide: always A=I-check with asymmetric B)."""
     o = ops()
@@ -233,6 +258,11 @@ def test_attention_bank_segment_and_shared_context(dtype):
                       heads=heads, d=d, scale=d ** -0.5, k1=dv(bk.reshape(-1, C_)), v1t=dv(bv.permute(0, 2, 1).contiguous()),
                       Lk1=Lb, seg1_div=Fr, seg1_first_batch=Fr)
     close(got, ref, dtype)
+    # cond-only bank (seg1_skip): the uncond bank row is never read, so a bank that holds the cond rows only gives the same
+    got_c = o.attention(dv(qq.reshape(-1, C_)), dv(kk.reshape(-1, C_)), dv(vv.permute(0, 2, 1).contiguous()), L, B=nb, Lq=L,
+                        heads=heads, d=d, scale=d ** -0.5, k1=dv(bk[1:].reshape(-1, C_)), v1t=dv(bv[1:].permute(0, 2, 1).contiguous()),
+                        Lk1=Lb, seg1_div=Fr, seg1_first_batch=Fr, seg1_skip=1)
+    assert torch.equal(got_c, got)
     # shared context: batch b reads context row b // Fr
     ck, cv = q(seeded_randn((Bc, 7, C_), 32), dtype), q(seeded_randn((Bc, 7, C_), 33), dtype)
     ref2 = torch.cat([attn_ref(sp(qq[b:b + 1]), sp(ck[b // Fr:b // Fr + 1]), sp(cv[b // Fr:b // Fr + 1]), d ** -0.5)
