@@ -8,33 +8,42 @@
 // (resnet.py:98) and nearest-x2-upsample-folded (resnet.py:74-82: the interpolate is folded into the
 // load indexing, the upsampled tensor never exists).
 //
-// Structure (v3):
-//   * block = 4 waves; a wave owns WTM x WTN MFMA 32x32 tiles: 2x2 waves of 64x64 (BM=BN=128) or 4x1 waves of
-//     32x160 (BM=128, BN=160: every channel count of the SD-1.5 UNet is a multiple of 160, so N=320 is two
-//     full tiles instead of 2.5 of 128), or 2x4 = 8 waves of 128x64 (256x256) for the big compute-bound shapes.
-//   * K is streamed in 128-BYTE stages (bf16: 64, f32: 32 k-values; one full L2 line per row per stage - with
-//     64-byte rows every L2 request used half a line and the 128x128 tile sat on the L2 request rate) through an LDS
-//     ring filled by ASYNCHRONOUS direct-to-LDS loads (global_load_lds_dwordx4, no VGPR round trip), counted
-//     `s_waitcnt vmcnt`, one raw s_barrier per stage.
+// Structure (v6):
+//   * PERSISTENT blocks: a launch has as many blocks as the chip holds at once (by LDS, <= 4 per CU; a multiple of 8),
+//     block b walks tiles b, b+G, ... of an XCD-aware order (block b runs on XCD b%8; each XCD owns a contiguous run of
+//     tiles, n fastest, so the A rows it re-reads stay in that XCD's L2).
+//   * a wave owns WTM x WTN MFMA 32x32 tiles: 2x4 = 8 waves of 128x64 (256x256, the big compute-bound shapes), 2x2 waves
+//     of 64x64 (128x128), 4x1 waves of 32x160 (128x160: every channel count of the SD-1.5 UNet is a multiple of 160),
+//     2x2 waves of 32x32 (64x64: few-block short-K shapes and V^T outputs, 4 co-resident blocks per CU).
+//   * K is streamed in 128-BYTE stages (bf16: 64, f32: 32 k-values; one full L2 line per row per stage) through a
+//     2-deep LDS ring filled by ASYNCHRONOUS direct-to-LDS loads (global_load_lds_dwordx4, no VGPR round trip).  The
+//     loader state is a stream of (tile, stage) pairs that runs one stage AHEAD of the MFMA loop and does not stop at tile
+//     boundaries: a tile's epilogue runs with the next tile's first stage in flight.  The whole next stage is requested
+//     right behind the per-stage s_barrier (it then has the full MFMA time of this stage to land).
 //   * software-pipelined stage: after the barrier only the first k-step's fragment read is exposed; the reads of
-//     step kk+1 and the next stage's glds (with their address arithmetic) are issued one at a time BETWEEN the MFMAs
-//     of step kk (compile-time `static_for` so every register-array index is a constant: a runtime index sends the
-//     arrays to scratch and breaks the asm-read/wait protocol).
+//     step kk+1 are issued one at a time BETWEEN the MFMAs of step kk (compile-time `static_for` so every register-array
+//     index is a constant: a runtime index sends the arrays to scratch and breaks the asm-read/wait protocol).
 //   * the LDS image of a stage is lane-linear (a glds writes wave-base + lane*16), so the 16-byte chunk position is
 //     XOR-swizzled with (row / rows-per-bank-row) on the SOURCE address and on the fragment read: the ds_read_b128 of
-//     a 16-lane group then hits 16 distinct 16-byte slots (conflict-free, SQ_LDS_BANK_CONFLICT = 0 measured).
+//     a 16-lane group then hits 16 distinct 16-byte slots (conflict-free, SQ_LDS_BANK_CONFLICT = 0 measured).  One
+//     swizzle key per lane serves every glds; the k-step fragment addresses are the step-0 address XOR (kk << 5).
 //   * fragment reads are inline-asm ds_read_b128 with hand-counted lgkmcnt: hipcc drains vmcnt(0) in front of
 //     every C++-level LDS read while a glds is in flight, which would serialise the ring.
-//   * out-of-range rows / K tails / conv zero padding source a 16-byte zero page instead of branching.
-//   * row-major store: the MFMA is issued with the operands SWAPPED (acc = W_frag x A_frag), so a lane ends up
-//     with 4 consecutive output COLUMNS of one row per register quad -> 8-byte (bf16) / 16-byte (f32)
-//     row-per-lane stores instead of 2-byte column-per-lane stores.  V^T store (TRANS): operands unswapped,
-//     a lane holds 4 consecutive ROWS of one column.
-//   * XCD-aware tile order: block b runs on XCD b%8; tiles are dealt so that each XCD walks a contiguous run
-//     of tiles (n fastest) and the A rows it re-reads stay in that XCD's L2.
+//   * dense operands: rows past M / N are clamped to the last valid row (never stored), so every source pointer steps
+//     by one constant per stage; K tails and the conv loader's zero padding source a 16-byte zero page.
+//   * the MFMA is issued with the operands SWAPPED (acc = W_frag x A_frag), so a lane ends up with 4 consecutive
+//     output COLUMNS of one row per register quad.  V^T store (TRANS): operands unswapped, a lane holds 4 consecutive
+//     ROWS of one column.
+//   * EPILOGUE (what bounds the short-K shapes): accumulators start at the bias; bf16 row-major outputs are staged
+//     through the ring slot the main loop has just released and written back as full 128-byte lines, 16 bytes per lane,
+//     with equally coalesced residual loads issued ahead of the staging phase (epilogue_lds); everything else (f32,
+//     ragged N, split-K partials, V^T) uses the row-per-lane / column-per-lane paths.
 //   bf16: v_mfma_f32_32x32x16_bf16, f32 accumulate.   f32: v_mfma_f32_32x32x2_f32 (exact f32 fma chain).
 // Epilogue fused: bias, per-batch row bias (temb), GEGLU, residual, scale, row-major or V^T store.
 // Split-K (small M): f32 partial slabs + a fixed-order reduce/epilogue kernel (deterministic).
+// conv3x3_halo_kernel (below): the stride-1 3x3 convs with input-halo reuse instead of the im2col loader.
+// EMO_ABL_* / EMO_FORCE_* / EMO_LATE_ISSUE macros and the EMO_GEMM_* environment knobs are measurement hooks (ablations and
+// tile-choice overrides quoted in DESIGN.md 7), not product configuration.
 #include <stdlib.h>
 #include "common.h"
 
