@@ -231,7 +231,9 @@ class EMOAnimationPipeline:
             return
         if state == "warm":
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool if pool is not None else st.graph_pool):
+            # thread_local: only this thread's calls are checked during capture - the RCCL watchdog thread of a multi-GPU
+            # run polls events concurrently and must not invalidate the capture
+            with torch.cuda.graph(g, pool=pool if pool is not None else st.graph_pool, capture_error_mode="thread_local"):
                 fn()
             st.graphs[key] = g
             state = g
