@@ -116,11 +116,16 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = world > 1
+    force_dist = world == 1 and os.environ.get("EMO_FORCE_DIST") == "1"   # single-GPU run of the multi-GPU code path (diagnostic)
+    dist = world > 1 or force_dist
     if dist:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("nccl", device_id=dev)
+        if force_dist:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            td.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            td.init_process_group("nccl", device_id=dev)
 
     from emote_hack_amd import DDPMScheduler, ops
     from emote_hack_amd.pipeline import EMOAnimationPipeline

@@ -123,7 +123,9 @@ class EMOAnimationPipeline:
         nb = math.ceil(len(queue) / st.cbs)
         st.global_context = [queue[i * st.cbs:(i + 1) * st.cbs] for i in range(nb)]
         st.frame_idx = {tuple(c): torch.tensor(c, dtype=torch.int32, device=dev) for ctx in st.global_context for c in ctx}
-        st.dist_pre, st.rank_pre, st.world_pre = bool(dist) and world_size > 1, rank, world_size
+        # EMO_FORCE_DIST=1: take the multi-GPU code path even at world_size 1 (single-GPU functional test of that path)
+        force_dist = bool(dist) and os.environ.get("EMO_FORCE_DIST") == "1"
+        st.dist_pre, st.rank_pre, st.world_pre = (bool(dist) and world_size > 1) or force_dist, rank, world_size
         st.my_contexts = st.global_context[rank::world_size] if st.dist_pre else st.global_context          # :757
         st.ctx_index = [[torch.tensor(c, dtype=torch.int64, device=dev) for c in ctx] for ctx in st.my_contexts]
         st.t_table = torch.tensor(st.timesteps, dtype=torch.int64, device=dev)   # INT timestep table, bit-exact
@@ -141,7 +143,8 @@ class EMOAnimationPipeline:
         st.counter = torch.empty(st.f_tot, device=dev, dtype=torch.float32)
         st.guidance_scale, st.eta, st.seed = guidance_scale, eta, seed
         st.audio_features, st.speed_embeddings = audio_features, speed_embeddings
-        st.dist, st.rank, st.world_size = bool(dist) and world_size > 1, rank, world_size
+        st.dist, st.rank, st.world_size = (bool(dist) and world_size > 1) or force_dist, rank, world_size
+        st.t_ref = torch.zeros(1, dtype=torch.int64, device=dev)   # timestep of the ReferenceNet pass this rank computes
         st.return_eps, st.eps_trace = return_eps, []
         st.bank_group, st.bank_shapes, st.bank_group_start, st.bank_now = None, None, -1, None
         return st
@@ -154,14 +157,21 @@ class EMOAnimationPipeline:
         import torch.distributed as td
         ws = st.world_size
         mine = min(si + st.rank, len(st.timesteps) - 1)   # tail group: surplus ranks recompute the last step (unused)
-        self._write_banks(st.appearance_encoder, st.writer, st.ref_rep, st.t_table[mine:mine + 1], st.text)
-        st.bank_shapes = [tuple(st.writer.bank[p][0].shape) for p in st.writer.order]
-        send = self._pack_banks(st.writer)
+        st.t_ref.copy_(st.t_table[mine:mine + 1], non_blocking=True)
+        # the pass goes through the same warm -> capture -> replay sequence as the UNet parts (its ~450 launches cost
+        # ~20 ms of host time when enqueued from Python)
+        self._run(st, "writer_dist", lambda: self._part_writer_dist(st), pool=st.writer_pool)
+        send = st.send
         recv = torch.empty(ws * send.numel(), device=send.device, dtype=send.dtype)   # flat: valid for RCCL and gloo
         td.all_gather_into_tensor(recv, send)
         st.bank_group, st.bank_group_start = recv.view(ws, send.numel()), si
         if getattr(st, "bank_now", None) is None:
             st.bank_now = torch.empty_like(send)
+
+    def _part_writer_dist(self, st):
+        self._write_banks(st.appearance_encoder, st.writer, st.ref_rep, st.t_ref, st.text)
+        st.bank_shapes = [tuple(st.writer.bank[p][0].shape) for p in st.writer.order]
+        st.send = self._pack_banks(st.writer)
 
     # ---- the two GPU-heavy parts of a step; both read the timestep from the device buffer st.t_buf so that they
     #      can be captured once into HIP graphs and replayed for the other 49 steps

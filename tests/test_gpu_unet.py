@@ -116,6 +116,36 @@ def test_denoise_loop_vs_golden(kind, graphs):
     torch.testing.assert_close(lat.cpu(), g[f"{kind}/latents"], rtol=2e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("graphs", [False, True])
+def test_denoise_loop_multi_gpu_code_path_single_rank(graphs, monkeypatch):
+    """The multi-GPU branch of the loop (ReferenceNet passes dealt over ranks + all_gather of the packed banks, all_reduce of
+    the window accumulators, graph-captured write pass) on ONE rank over RCCL: same goldens as the single-process loop."""
+    import socket
+    import torch.distributed as td
+    from emote_hack_amd import DDPMScheduler
+    from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
+    from emote_hack_amd.pipeline import EMOAnimationPipeline
+    if td.is_initialized():
+        pytest.skip("a process group already exists")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    monkeypatch.setenv("EMO_FORCE_DIST", "1")
+    td.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        g = load_file(os.path.join(G, "loop_tiny.safetensors"))
+        ref = build(cases.TINY, torch.float32, cases.REF_PREFIX, cls=AppearanceEncoderModel, has_out=False)
+        unet = build(cases.TINY_MOTION, torch.float32)
+        pipe = EMOAnimationPipeline(unet=unet, scheduler=DDPMScheduler())
+        lat, eps = pipe.denoise(seeded_randn((1, 4, 8, 16, 16), 5).to(DEV), seeded_randn((1, 4, 16, 16), 3), seeded_randn((2, 5, 32), 2),
+                                appearance_encoder=ref, num_inference_steps=3, guidance_scale=7.5, context_frames=4,
+                                context_stride=1, context_overlap=2, seed=0, return_eps=True, use_graphs=graphs,
+                                dist=True, rank=0, world_size=1)
+        torch.testing.assert_close(lat.cpu(), g["ddpm/latents"], rtol=2e-3, atol=2e-4)
+    finally:
+        td.destroy_process_group()
+
+
 def test_pipeline_call_signature_and_errors():
     from emote_hack_amd import DDIMScheduler
     from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
