@@ -73,7 +73,20 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  const int qt = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  // XCD-aware work order: block L of the flat launch runs on XCD L % 8.  Work items are (b, head, q-tile) with the q-tile
+  // fastest; XCD x takes a contiguous run of them, so the q-tiles that share one (b, head)'s K / V mostly share one L2
+  // instead of pulling the same 0.6 MB through all eight.
+  int qt, head, b;
+  {
+    const int nqt = (p.Lq + BQ * QT - 1) / (BQ * QT);
+    const int total = gridDim.x, L = blockIdx.x;
+    const int qn = total >> 3, rn = total & 7, x = L & 7, idx = L >> 3;
+    const int wi = (x < rn ? x * (qn + 1) : rn * (qn + 1) + (x - rn) * qn) + idx;
+    qt = wi % nqt;
+    const int hb = wi / nqt;
+    head = hb % p.heads;
+    b = hb / p.heads;
+  }
   const int d = p.d;
   const int dch_real = d / V;  // d*sizeof(T) % 16 == 0 checked on the host
   const T* zero = (const T*)g_att_zero_page;
@@ -415,7 +428,9 @@ static int launch_attention3(const emo_attention_params& p, hipStream_t st) {
       once = true;
     }
   }
-  dim3 grid((p.Lq + BQ * QT - 1) / (BQ * QT), p.heads, p.B);
+  const int64_t nblk = (int64_t)((p.Lq + BQ * QT - 1) / (BQ * QT)) * p.heads * p.B;
+  if (nblk >= (1ll << 31)) return emo_fail(EMO_ERR_BAD_SHAPE, "emo_attention: too many blocks");
+  dim3 grid((unsigned)nblk);
   kern<<<grid, ATT_THREADS, lds, st>>>(p, L::STAGE_BYTES);
   EMO_LAUNCH_CHECK();
   return EMO_OK;
