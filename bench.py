@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event instrumentation pass")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel from Python instead of replaying HIP graphs")
@@ -131,7 +131,7 @@ def main():
     from emote_hack_amd.pipeline import EMOAnimationPipeline
     from emote_hack_amd.synth import seeded_randn
 
-    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[a.dtype]
     unet, ref = build_models(dev, dtype)
     F_WIN = 12
     f_tot = F_WIN * world

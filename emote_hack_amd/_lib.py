@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EMO_HIP_LIB") or os.path.join(HERE, "lib", "libemo_hip.so")
 
-EMO_F32, EMO_BF16 = 0, 1
+EMO_F32, EMO_BF16, EMO_F16 = 0, 1, 2
 
 
 class EmoHipError(RuntimeError):

@@ -27,6 +27,11 @@ static constexpr int ATT_THREADS = 256, BQ = 128, TK = 64;
 __device__ __attribute__((aligned(16))) unsigned int g_att_zero_page[4] = {0, 0, 0, 0};
 __device__ __attribute__((aligned(16))) unsigned int g_att_ones_bf16[4] = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
 __device__ __attribute__((aligned(16))) unsigned int g_att_ones_f32[4] = {0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u};
+__device__ __attribute__((aligned(16))) unsigned int g_att_ones_f16[4] = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+template <typename T> struct OnesBits;   // 1.0 in T, replicated to 32 bits
+template <> struct OnesBits<float> { static constexpr unsigned value = 0x3f800000u; };
+template <> struct OnesBits<bf16_t> { static constexpr unsigned value = 0x3f803f80u; };
+template <> struct OnesBits<f16_t> { static constexpr unsigned value = 0x3c003c00u; };
 
 template <typename T, int DCH>
 struct AttCfg {
@@ -90,7 +95,8 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
   const int d = p.d;
   const int dch_real = d / V;  // d*sizeof(T) % 16 == 0 checked on the host
   const T* zero = (const T*)g_att_zero_page;
-  const T* ones = sizeof(T) == 2 ? (const T*)g_att_ones_bf16 : (const T*)g_att_ones_f32;
+  const T* ones = std::is_same<T, float>::value ? (const T*)g_att_ones_f32
+                  : (std::is_same<T, bf16_t>::value ? (const T*)g_att_ones_bf16 : (const T*)g_att_ones_f16);
 
   // ---- zero the whole ring once: V^T pad rows (n >= d) are never written by the loader and must be 0
   // ... except V^T row d, which is all ONES when the head dim leaves a pad row (d < NT*32: 40, 80): row d of O^T = V^T P^T
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
   const bool ones_row = d < NT * 32;
   {
     const int ones_begin = K_CHUNKS * 16 + d * VROW, ones_end = ones_begin + VCH * 16;
-    const unsigned one_bits = sizeof(T) == 2 ? 0x3f803f80u : 0x3f800000u;
+    const unsigned one_bits = OnesBits<T>::value;
     for (int i = tid * 16; i < NSR * stage_bytes; i += ATT_THREADS * 16) {
       const int off = i % stage_bytes;
       const unsigned v = (ones_row && off >= ones_begin && off < ones_end) ? one_bits : 0u;
@@ -320,10 +326,10 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
       for (int sp = 0; sp < STEPS; sp++) {
         const int r0 = sp * V;
         if constexpr (sizeof(T) == 2) {
-          pf[t][0][sp] = make_uint4(pack_bf2(p0[r0], p0[r0 + 1]), pack_bf2(p0[r0 + 2], p0[r0 + 3]), pack_bf2(p0[r0 + 4], p0[r0 + 5]),
-                                    pack_bf2(p0[r0 + 6], p0[r0 + 7]));
-          pf[t][1][sp] = make_uint4(pack_bf2(p1[r0], p1[r0 + 1]), pack_bf2(p1[r0 + 2], p1[r0 + 3]), pack_bf2(p1[r0 + 4], p1[r0 + 5]),
-                                    pack_bf2(p1[r0 + 6], p1[r0 + 7]));
+          pf[t][0][sp] = make_uint4(pack2<T>(p0[r0], p0[r0 + 1]), pack2<T>(p0[r0 + 2], p0[r0 + 3]), pack2<T>(p0[r0 + 4], p0[r0 + 5]),
+                                    pack2<T>(p0[r0 + 6], p0[r0 + 7]));
+          pf[t][1][sp] = make_uint4(pack2<T>(p1[r0], p1[r0 + 1]), pack2<T>(p1[r0 + 2], p1[r0 + 3]), pack2<T>(p1[r0 + 4], p1[r0 + 5]),
+                                    pack2<T>(p1[r0 + 6], p1[r0 + 7]));
         } else {
           pf[t][0][sp] = make_uint4(__float_as_uint(p0[r0]), __float_as_uint(p0[r0 + 1]), __float_as_uint(p0[r0 + 2]), __float_as_uint(p0[r0 + 3]));
           pf[t][1][sp] = make_uint4(__float_as_uint(p1[r0]), __float_as_uint(p1[r0 + 1]), __float_as_uint(p1[r0 + 2]), __float_as_uint(p1[r0 + 3]));
@@ -394,7 +400,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
           if (n0 < d) {
             float v0 = o[t][nt][4 * g] * inv, v1 = o[t][nt][4 * g + 1] * inv, v2 = o[t][nt][4 * g + 2] * inv, v3 = o[t][nt][4 * g + 3] * inv;
             if constexpr (sizeof(T) == 2) {
-              *(uint2*)(orow + n0) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
+              *(uint2*)(orow + n0) = make_uint2(pack2<T>(v0, v1), pack2<T>(v2, v3));
             } else {
               *(float4*)(orow + n0) = make_float4(v0, v1, v2, v3);
             }
@@ -487,8 +493,8 @@ extern "C" int emo_attention(const emo_attention_params* pp, void* stream) {
   EMO_CHECK(pp, EMO_ERR_NULL, "emo_attention: null params");
   const emo_attention_params& p = *pp;
   EMO_CHECK(p.q && p.k0 && p.v0t && p.out, EMO_ERR_NULL, "emo_attention: null pointer");
-  EMO_CHECK(p.dtype == EMO_F32 || p.dtype == EMO_BF16, EMO_ERR_BAD_DTYPE, "emo_attention: dtype %d", p.dtype);
-  const int V = p.dtype == EMO_F32 ? 4 : 8;
+  EMO_CHECK(emo_dtype_ok(p.dtype), EMO_ERR_BAD_DTYPE, "emo_attention: dtype %d", p.dtype);
+  const int V = emo_dtype_vec(p.dtype);
   EMO_CHECK(p.B > 0 && p.Lq > 0 && p.Lk0 > 0 && p.heads > 0 && p.d > 0, EMO_ERR_BAD_SHAPE, "emo_attention: bad shape");
   EMO_CHECK(p.d % V == 0, EMO_ERR_BAD_SHAPE, "emo_attention: head dim %d must be a multiple of %d", p.d, V);
   EMO_CHECK(p.ldq % V == 0 && p.ldk0 % V == 0 && p.ldv0t % V == 0 && p.ldo % 4 == 0, EMO_ERR_BAD_SHAPE, "emo_attention: leading dims");
@@ -502,5 +508,6 @@ extern "C" int emo_attention(const emo_attention_params* pp, void* stream) {
               "emo_attention: segment-1 geometry");
   }
   hipStream_t st = as_stream(stream);
-  return p.dtype == EMO_F32 ? dispatch_attention<float>(p, st) : dispatch_attention<bf16_t>(p, st);
+  EMO_DISPATCH(p.dtype, "emo_attention", return dispatch_attention<T>(p, st));
+  return EMO_OK;
 }

@@ -8,6 +8,7 @@
 #include "../../include/emo_hip.h"
 
 typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef _Float16 f16_t;         // IEEE half (a distinct C++ type: the kernels are templated on the element type)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -39,12 +40,42 @@ template <> struct TT<float> {
   static constexpr int VEC = 4;
   __device__ static __forceinline__ float ld(const float* p) { return *p; }
   __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+  __device__ static __forceinline__ float ld_val(float v) { return v; }
 };
 template <> struct TT<bf16_t> {
   static constexpr int VEC = 8;
   __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
   __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+  __device__ static __forceinline__ float ld_val(float v) { return bf2f(f2bf(v)); }
 };
+
+template <> struct TT<f16_t> {
+  static constexpr int VEC = 8;
+  __device__ static __forceinline__ float ld(const f16_t* p) { return (float)*p; }
+  __device__ static __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)v; }
+  __device__ static __forceinline__ float ld_val(float v) { return (float)(f16_t)v; }
+};
+typedef _Float16 f16x2_native __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {   // round to nearest even (v_cvt_f16_f32), not pkrtz
+  f16x2_native v = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+// two f32 -> one packed 32-bit word of T (T = bf16_t or f16_t)
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) { return pack_bf2(lo, hi); }
+template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) { return pack_h2(lo, hi); }
+// four 2-byte elements (8 bytes) -> f32
+template <typename T> __device__ __forceinline__ void unpack4(const uint2& v, float* o);
+template <> __device__ __forceinline__ void unpack4<bf16_t>(const uint2& v, float* o) {
+  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+  o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack4<f16_t>(const uint2& v, float* o) {
+  const f16x2_native a = __builtin_bit_cast(f16x2_native, v.x), b = __builtin_bit_cast(f16x2_native, v.y);
+  o[0] = (float)a.x; o[1] = (float)a.y; o[2] = (float)b.x; o[3] = (float)b.y;
+}
+// round an f32 through T (the reference casts attention probabilities to the value dtype)
+template <typename T> __device__ __forceinline__ float round_through(float v) { return TT<T>::ld_val(v); }
 
 // unpack a 16-byte vector of T into floats (VEC of them)
 template <typename T> __device__ __forceinline__ void unpack16(const uint4& v, float* out);
@@ -57,12 +88,22 @@ template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& v, flo
   o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
   o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
 }
+template <> __device__ __forceinline__ void unpack16<f16_t>(const uint4& v, float* o) {
+  const f16x2_native a = __builtin_bit_cast(f16x2_native, v.x), b = __builtin_bit_cast(f16x2_native, v.y);
+  const f16x2_native c = __builtin_bit_cast(f16x2_native, v.z), d = __builtin_bit_cast(f16x2_native, v.w);
+  o[0] = (float)a.x; o[1] = (float)a.y; o[2] = (float)b.x; o[3] = (float)b.y;
+  o[4] = (float)c.x; o[5] = (float)c.y; o[6] = (float)d.x; o[7] = (float)d.y;
+}
 template <typename T> __device__ __forceinline__ uint4 pack16(const float* in);
 template <> __device__ __forceinline__ uint4 pack16<float>(const float* i) {
   return make_uint4(__float_as_uint(i[0]), __float_as_uint(i[1]), __float_as_uint(i[2]), __float_as_uint(i[3]));
 }
 template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* i) {
   return make_uint4(pack_bf2(i[0], i[1]), pack_bf2(i[2], i[3]), pack_bf2(i[4], i[5]), pack_bf2(i[6], i[7]));
+}
+
+template <> __device__ __forceinline__ uint4 pack16<f16_t>(const float* i) {
+  return make_uint4(pack_h2(i[0], i[1]), pack_h2(i[2], i[3]), pack_h2(i[4], i[5]), pack_h2(i[6], i[7]));
 }
 
 // One "mma16" step: A and B fragments are 16 bytes per lane (bf16: 8 k-values, f32: 4 k-values) of the
@@ -74,6 +115,10 @@ template <> __device__ __forceinline__ f32x16 mma16<bf16_t>(const uint4& a, cons
   union { uint4 u; s16x8 s; } ua, ub; ua.u = a; ub.u = b;
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, ua.s),
                                                  __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, ub.s), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16 mma16<f16_t>(const uint4& a, const uint4& b, f32x16 c) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 template <> __device__ __forceinline__ f32x16 mma16<float>(const uint4& a, const uint4& b, f32x16 c) {
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
@@ -87,6 +132,19 @@ template <typename T> struct MmaK { static constexpr int value = 2 * TT<T>::VEC;
 
 // C/D layout of the 32x32 MFMA: lane l, reg r -> col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
 __device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// dtype dispatch: binds the element type to `T` and runs the statement(s); unknown dtype -> EMO_ERR_BAD_DTYPE
+#define EMO_DISPATCH(dtype, who, ...)                                                              \
+  do {                                                                                             \
+    switch (dtype) {                                                                               \
+      case EMO_F32: { using T = float; __VA_ARGS__; } break;                                      \
+      case EMO_BF16: { using T = bf16_t; __VA_ARGS__; } break;                                    \
+      case EMO_F16: { using T = f16_t; __VA_ARGS__; } break;                                      \
+      default: return emo_fail(EMO_ERR_BAD_DTYPE, "%s: dtype %d", who, (int)(dtype));             \
+    }                                                                                              \
+  } while (0)
+static inline bool emo_dtype_ok(int dtype) { return dtype == EMO_F32 || dtype == EMO_BF16 || dtype == EMO_F16; }
+static inline int emo_dtype_vec(int dtype) { return dtype == EMO_F32 ? 4 : 8; }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

@@ -16,9 +16,7 @@ __global__ void act_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n
 extern "C" int emo_act(const void* x, void* y, int64_t n, int kind, int dtype, void* stream) {
   EMO_CHECK(x && y, EMO_ERR_NULL, "emo_act: null pointer");
   EMO_CHECK(n > 0 && kind >= 0 && kind <= 2, EMO_ERR_BAD_SHAPE, "emo_act: n=%lld kind=%d", (long long)n, kind);
-  if (dtype == EMO_F32) act_kernel<float><<<cgrid(n), 256, 0, as_stream(stream)>>>((const float*)x, (float*)y, n, kind);
-  else if (dtype == EMO_BF16) act_kernel<bf16_t><<<cgrid(n), 256, 0, as_stream(stream)>>>((const bf16_t*)x, (bf16_t*)y, n, kind);
-  else return emo_fail(EMO_ERR_BAD_DTYPE, "emo_act: dtype %d", dtype);
+  EMO_DISPATCH(dtype, "emo_act", (act_kernel<T><<<cgrid(n), 256, 0, as_stream(stream)>>>((const T*)x, (T*)y, n, kind)));
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
@@ -36,9 +34,7 @@ extern "C" int emo_speed_encode(const float* v, const float* centers, const floa
                                 void* stream) {
   EMO_CHECK(v && centers && radii && out, EMO_ERR_NULL, "emo_speed_encode: null pointer");
   EMO_CHECK(B > 0 && nb > 0, EMO_ERR_BAD_SHAPE, "emo_speed_encode: bad shape");
-  if (dtype == EMO_F32) speed_encode_kernel<float><<<cgrid((int64_t)B * nb), 256, 0, as_stream(stream)>>>(v, centers, radii, (float*)out, B, nb);
-  else if (dtype == EMO_BF16) speed_encode_kernel<bf16_t><<<cgrid((int64_t)B * nb), 256, 0, as_stream(stream)>>>(v, centers, radii, (bf16_t*)out, B, nb);
-  else return emo_fail(EMO_ERR_BAD_DTYPE, "emo_speed_encode: dtype %d", dtype);
+  EMO_DISPATCH(dtype, "emo_speed_encode", (speed_encode_kernel<T><<<cgrid((int64_t)B * nb), 256, 0, as_stream(stream)>>>(v, centers, radii, (T*)out, B, nb)));
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
@@ -77,9 +73,7 @@ __global__ void gather_rows_kernel(const T* __restrict__ table, const int32_t* _
 extern "C" int emo_gather_rows(const void* table, const int32_t* idx, void* out, int B, int D, int rows, int dtype, void* stream) {
   EMO_CHECK(table && idx && out, EMO_ERR_NULL, "emo_gather_rows: null pointer");
   EMO_CHECK(B > 0 && D > 0 && rows > 0, EMO_ERR_BAD_SHAPE, "emo_gather_rows: bad shape");
-  if (dtype == EMO_F32) gather_rows_kernel<float><<<cgrid((int64_t)B * D), 256, 0, as_stream(stream)>>>((const float*)table, idx, (float*)out, B, D, rows);
-  else if (dtype == EMO_BF16) gather_rows_kernel<bf16_t><<<cgrid((int64_t)B * D), 256, 0, as_stream(stream)>>>((const bf16_t*)table, idx, (bf16_t*)out, B, D, rows);
-  else return emo_fail(EMO_ERR_BAD_DTYPE, "emo_gather_rows: dtype %d", dtype);
+  EMO_DISPATCH(dtype, "emo_gather_rows", (gather_rows_kernel<T><<<cgrid((int64_t)B * D), 256, 0, as_stream(stream)>>>((const T*)table, idx, (T*)out, B, D, rows)));
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
@@ -98,9 +92,7 @@ extern "C" int emo_add_rowbias(const void* x, int ldx, const void* rb, int ldr, 
                                int dtype, void* stream) {
   EMO_CHECK(x && rb && y, EMO_ERR_NULL, "emo_add_rowbias: null pointer");
   EMO_CHECK(M > 0 && C > 0 && rows_per_batch > 0, EMO_ERR_BAD_SHAPE, "emo_add_rowbias: bad shape");
-  if (dtype == EMO_F32) add_rowbias_kernel<float><<<cgrid(M * C), 256, 0, as_stream(stream)>>>((const float*)x, ldx, (const float*)rb, ldr, (float*)y, ldy, M, C, rows_per_batch);
-  else if (dtype == EMO_BF16) add_rowbias_kernel<bf16_t><<<cgrid(M * C), 256, 0, as_stream(stream)>>>((const bf16_t*)x, ldx, (const bf16_t*)rb, ldr, (bf16_t*)y, ldy, M, C, rows_per_batch);
-  else return emo_fail(EMO_ERR_BAD_DTYPE, "emo_add_rowbias: dtype %d", dtype);
+  EMO_DISPATCH(dtype, "emo_add_rowbias", (add_rowbias_kernel<T><<<cgrid(M * C), 256, 0, as_stream(stream)>>>((const T*)x, ldx, (const T*)rb, ldr, (T*)y, ldy, M, C, rows_per_batch)));
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }

@@ -82,9 +82,7 @@ extern "C" int emo_ncfhw_to_rows(const float* x, void* y, int B, int C, int F, i
   int HW = H * W;
   int64_t ntiles = (int64_t)B * F * ((HW + 63) / 64) * ((Cpad + 31) / 32);
   int grid = (int)(ntiles < 4096 ? ntiles : 4096);
-  if (dtype == EMO_F32) ncfhw_to_rows_kernel<float><<<grid, 256, 0, as_stream(stream)>>>(x, (float*)y, B, C, F, HW, Cpad, ldo);
-  else if (dtype == EMO_BF16) ncfhw_to_rows_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>(x, (bf16_t*)y, B, C, F, HW, Cpad, ldo);
-  else return emo_fail(EMO_ERR_BAD_DTYPE, "emo_ncfhw_to_rows: dtype %d", dtype);
+  EMO_DISPATCH(dtype, "emo_ncfhw_to_rows", (ncfhw_to_rows_kernel<T><<<grid, 256, 0, as_stream(stream)>>>(x, (T*)y, B, C, F, HW, Cpad, ldo)));
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
@@ -96,9 +94,7 @@ extern "C" int emo_rows_to_ncfhw(const void* x, float* y, int B, int C, int F, i
   int HW = H * W;
   int64_t ntiles = (int64_t)B * F * ((HW + 63) / 64) * ((C + 31) / 32);
   int grid = (int)(ntiles < 4096 ? ntiles : 4096);
-  if (dtype == EMO_F32) rows_to_ncfhw_kernel<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)x, y, B, C, F, HW, ldi);
-  else if (dtype == EMO_BF16) rows_to_ncfhw_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)x, y, B, C, F, HW, ldi);
-  else return emo_fail(EMO_ERR_BAD_DTYPE, "emo_rows_to_ncfhw: dtype %d", dtype);
+  EMO_DISPATCH(dtype, "emo_rows_to_ncfhw", (rows_to_ncfhw_kernel<T><<<grid, 256, 0, as_stream(stream)>>>((const T*)x, y, B, C, F, HW, ldi)));
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
@@ -117,13 +113,12 @@ __global__ __launch_bounds__(256) void copy_cols_kernel(const T* __restrict__ x,
 }
 extern "C" int emo_copy_cols(const void* x, int ldx, void* y, int ldy, int coff, int64_t M, int C, int dtype, void* stream) {
   EMO_CHECK(x && y, EMO_ERR_NULL, "emo_copy_cols: null pointer");
-  int V = dtype == EMO_F32 ? 4 : 8;
-  EMO_CHECK(dtype == EMO_F32 || dtype == EMO_BF16, EMO_ERR_BAD_DTYPE, "emo_copy_cols: dtype %d", dtype);
+  int V = emo_dtype_vec(dtype);
+  EMO_CHECK(emo_dtype_ok(dtype), EMO_ERR_BAD_DTYPE, "emo_copy_cols: dtype %d", dtype);
   EMO_CHECK(M > 0 && C > 0 && C % V == 0 && coff % V == 0 && ldx % V == 0 && ldy % V == 0 && coff + C <= ldy && C <= ldx,
             EMO_ERR_BAD_SHAPE, "emo_copy_cols: C=%d coff=%d ldx=%d ldy=%d must be multiples of %d", C, coff, ldx, ldy, V);
   int grid = grid_for(M * (C / V), 256);
-  if (dtype == EMO_F32) copy_cols_kernel<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)x, ldx, (float*)y, ldy, coff, M, C);
-  else copy_cols_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)x, ldx, (bf16_t*)y, ldy, coff, M, C);
+  EMO_DISPATCH(dtype, "emo_copy_cols", (copy_cols_kernel<T><<<grid, 256, 0, as_stream(stream)>>>((const T*)x, ldx, (T*)y, ldy, coff, M, C)));
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
@@ -147,12 +142,11 @@ __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, int l
 extern "C" int emo_add(const void* a, int lda, const void* b, int ldb, float alpha, void* y, int ldy, int64_t M, int C,
                        int dtype, void* stream) {
   EMO_CHECK(a && b && y, EMO_ERR_NULL, "emo_add: null pointer");
-  EMO_CHECK(dtype == EMO_F32 || dtype == EMO_BF16, EMO_ERR_BAD_DTYPE, "emo_add: dtype %d", dtype);
-  int V = dtype == EMO_F32 ? 4 : 8;
+  EMO_CHECK(emo_dtype_ok(dtype), EMO_ERR_BAD_DTYPE, "emo_add: dtype %d", dtype);
+  int V = emo_dtype_vec(dtype);
   EMO_CHECK(M > 0 && C > 0 && C % V == 0 && lda % V == 0 && ldb % V == 0 && ldy % V == 0, EMO_ERR_BAD_SHAPE, "emo_add: bad shape");
   int grid = grid_for(M * (C / V), 256);
-  if (dtype == EMO_F32) add_kernel<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)a, lda, (const float*)b, ldb, alpha, (float*)y, ldy, M, C);
-  else add_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)a, lda, (const bf16_t*)b, ldb, alpha, (bf16_t*)y, ldy, M, C);
+  EMO_DISPATCH(dtype, "emo_add", (add_kernel<T><<<grid, 256, 0, as_stream(stream)>>>((const T*)a, lda, (const T*)b, ldb, alpha, (T*)y, ldy, M, C)));
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
@@ -173,11 +167,14 @@ extern "C" int emo_convert(const void* src, int sdt, void* dst, int ddt, int64_t
   EMO_CHECK(n > 0, EMO_ERR_BAD_SHAPE, "emo_convert: n=%lld", (long long)n);
   int grid = grid_for(n, 256);
   hipStream_t st = as_stream(stream);
-  if (sdt == EMO_F32 && ddt == EMO_F32) convert_kernel<float, float><<<grid, 256, 0, st>>>((const float*)src, (float*)dst, n, fp16_round);
-  else if (sdt == EMO_F32 && ddt == EMO_BF16) convert_kernel<float, bf16_t><<<grid, 256, 0, st>>>((const float*)src, (bf16_t*)dst, n, fp16_round);
-  else if (sdt == EMO_BF16 && ddt == EMO_F32) convert_kernel<bf16_t, float><<<grid, 256, 0, st>>>((const bf16_t*)src, (float*)dst, n, fp16_round);
-  else if (sdt == EMO_BF16 && ddt == EMO_BF16) convert_kernel<bf16_t, bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)src, (bf16_t*)dst, n, fp16_round);
-  else return emo_fail(EMO_ERR_BAD_DTYPE, "emo_convert: dtypes %d -> %d", sdt, ddt);
+  EMO_CHECK(emo_dtype_ok(sdt) && emo_dtype_ok(ddt), EMO_ERR_BAD_DTYPE, "emo_convert: dtypes %d -> %d", sdt, ddt);
+  EMO_DISPATCH(sdt, "emo_convert", {
+    using S = T;
+    const S* sp = (const S*)src;
+    if (ddt == EMO_F32) convert_kernel<S, float><<<grid, 256, 0, st>>>(sp, (float*)dst, n, fp16_round);
+    else if (ddt == EMO_BF16) convert_kernel<S, bf16_t><<<grid, 256, 0, st>>>(sp, (bf16_t*)dst, n, fp16_round);
+    else convert_kernel<S, f16_t><<<grid, 256, 0, st>>>(sp, (f16_t*)dst, n, fp16_round);
+  });
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
@@ -191,9 +188,7 @@ extern "C" int emo_silu(const void* x, void* y, int64_t n, int dtype, void* stre
   EMO_CHECK(x && y, EMO_ERR_NULL, "emo_silu: null pointer");
   EMO_CHECK(n > 0, EMO_ERR_BAD_SHAPE, "emo_silu: n");
   int grid = grid_for(n, 256);
-  if (dtype == EMO_F32) silu_kernel<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)x, (float*)y, n);
-  else if (dtype == EMO_BF16) silu_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)x, (bf16_t*)y, n);
-  else return emo_fail(EMO_ERR_BAD_DTYPE, "emo_silu: dtype %d", dtype);
+  EMO_DISPATCH(dtype, "emo_silu", (silu_kernel<T><<<grid, 256, 0, as_stream(stream)>>>((const T*)x, (T*)y, n)));
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
@@ -225,9 +220,7 @@ extern "C" int emo_timestep_embedding(const int64_t* ts, const float* freqs, voi
   EMO_CHECK(ts && out && freqs, EMO_ERR_NULL, "emo_timestep_embedding: null pointer");
   EMO_CHECK(B > 0 && dim > 1, EMO_ERR_BAD_SHAPE, "emo_timestep_embedding: B=%d dim=%d", B, dim);
   int grid = grid_for((int64_t)B * dim, 256);
-  if (dtype == EMO_F32) timestep_kernel<float><<<grid, 256, 0, as_stream(stream)>>>(ts, freqs, (float*)out, B, dim, flip);
-  else if (dtype == EMO_BF16) timestep_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>(ts, freqs, (bf16_t*)out, B, dim, flip);
-  else return emo_fail(EMO_ERR_BAD_DTYPE, "emo_timestep_embedding: dtype %d", dtype);
+  EMO_DISPATCH(dtype, "emo_timestep_embedding", (timestep_kernel<T><<<grid, 256, 0, as_stream(stream)>>>(ts, freqs, (T*)out, B, dim, flip)));
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
@@ -288,9 +281,7 @@ extern "C" int emo_accumulate_window(const void* pred, int ld, float* np, float*
   EMO_CHECK(pred && np && counter && frames, EMO_ERR_NULL, "emo_accumulate_window: null pointer");
   EMO_CHECK(nf > 0 && nf <= 256 && C > 0 && ld >= C, EMO_ERR_BAD_SHAPE, "emo_accumulate_window: bad shape");
   int grid = grid_for((int64_t)nf * HW * C, 256);
-  if (dtype == EMO_F32) accumulate_window_kernel<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)pred, ld, np, counter, frames, nf, C, F, HW, add_counter);
-  else if (dtype == EMO_BF16) accumulate_window_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)pred, ld, np, counter, frames, nf, C, F, HW, add_counter);
-  else return emo_fail(EMO_ERR_BAD_DTYPE, "emo_accumulate_window: dtype %d", dtype);
+  EMO_DISPATCH(dtype, "emo_accumulate_window", (accumulate_window_kernel<T><<<grid, 256, 0, as_stream(stream)>>>((const T*)pred, ld, np, counter, frames, nf, C, F, HW, add_counter)));
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }

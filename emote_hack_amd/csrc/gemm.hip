@@ -126,9 +126,9 @@ __device__ __forceinline__ void epilogue_row(const f32x16 (&acc)[WTN], const emo
         if (!m_ok) continue;
         if (R) {
           if constexpr (sizeof(T) == 2) {
-            const uint2 rv = *(const uint2*)(R + m * p.ldr + no0);
-            o[0] += __uint_as_float(rv.x << 16); o[1] += __uint_as_float(rv.x & 0xffff0000u);
-            o[2] += __uint_as_float(rv.y << 16); o[3] += __uint_as_float(rv.y & 0xffff0000u);
+            float r4[4];
+            unpack4<T>(*(const uint2*)(R + m * p.ldr + no0), r4);
+            o[0] += r4[0]; o[1] += r4[1]; o[2] += r4[2]; o[3] += r4[3];
           } else {
             const float4 rv = *(const float4*)(R + m * p.ldr + no0);
             o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
@@ -140,7 +140,7 @@ __device__ __forceinline__ void epilogue_row(const f32x16 (&acc)[WTN], const emo
         if (o[0] == 123.456f)
 #endif
         {
-        if constexpr (sizeof(T) == 2) *(uint2*)(C + m * p.ldc + no0) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+        if constexpr (sizeof(T) == 2) *(uint2*)(C + m * p.ldc + no0) = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
         else *(float4*)(C + m * p.ldc + no0) = make_float4(o[0], o[1], o[2], o[3]);
         }
       } else {   // ragged N / unaligned leading dims: scalar path
@@ -178,9 +178,10 @@ __device__ __forceinline__ void lds_write8(unsigned addr, unsigned lo, unsigned 
   asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 // m_of(i, row) -> global output row of row `row` (0..31) of this wave's MFMA tile row i, or -1 if it does not exist
-template <int WTM, int WTN, int NW, int XBYTES, bool GEGLU, typename MF>
+template <typename T, int WTM, int WTN, int NW, int XBYTES, bool GEGLU, typename MF>
 __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], const emo_gemm_params& p, MF m_of, int wn0, int wave, int lane,
-                                             unsigned xbase, bf16_t* __restrict__ C, const bf16_t* __restrict__ R) {
+                                             unsigned xbase, T* __restrict__ C, const T* __restrict__ R) {
+  static_assert(sizeof(T) == 2, "the staged epilogue is for the 2-byte element types");
   constexpr int OTW = GEGLU ? WTN / 2 : WTN;                  // 32-column output tiles per wave row
   constexpr int JMAX = (XBYTES / (NW * 32) - 16) / 64;        // tiles per pass that fit this wave's share of the slot
   constexpr int JG = JMAX < OTW ? JMAX : OTW;
@@ -234,7 +235,7 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], cons
               o[0] *= g0; o[1] *= g1; o[2] *= g2; o[3] *= g3;
             }
           }
-          lds_write8(xw + l31 * PITCH + t * 64 + (8 * g + 4 * half) * 2, pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+          lds_write8(xw + l31 * PITCH + t * 64 + (8 * g + 4 * half) * 2, pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
         }
       }
       wait_lgkmcnt<0>();
@@ -260,11 +261,11 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], cons
             *(uint4*)(C + m * p.ldc + col) = xv[it];
           } else {
             float x[8], r[8];
-            unpack16<bf16_t>(xv[it], x);
-            unpack16<bf16_t>(rv[it], r);
+            unpack16<T>(xv[it], x);
+            unpack16<T>(rv[it], r);
 #pragma unroll
             for (int e = 0; e < 8; e++) x[e] = (x[e] + r[e]) * p.out_scale;
-            *(uint4*)(C + m * p.ldc + col) = pack16<bf16_t>(x);
+            *(uint4*)(C + m * p.ldc + col) = pack16<T>(x);
           }
         }
       }
@@ -566,9 +567,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
       const unsigned xbase = lds_base + ((gs + NS - 1) % NS) * Tile::STAGE_BYTES;
       auto m_of = [&](int i, int row) -> int64_t { const int64_t m = wm0 + i * 32 + row; return m < p.M ? m : -1; };
       if (p.geglu) {
-        if constexpr (WTN % 2 == 0) epilogue_lds<WTM, WTN, NW, Tile::STAGE_BYTES, true>(acc, pe, m_of, wn0, wave, lane, xbase, (bf16_t*)C, (const bf16_t*)R);
+        if constexpr (WTN % 2 == 0) epilogue_lds<T, WTM, WTN, NW, Tile::STAGE_BYTES, true>(acc, pe, m_of, wn0, wave, lane, xbase, C, R);
       } else {
-        epilogue_lds<WTM, WTN, NW, Tile::STAGE_BYTES, false>(acc, pe, m_of, wn0, wave, lane, xbase, (bf16_t*)C, (const bf16_t*)R);
+        epilogue_lds<T, WTM, WTN, NW, Tile::STAGE_BYTES, false>(acc, pe, m_of, wn0, wave, lane, xbase, C, R);
       }
     }
   }
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
           const int64_t b = m0 / p.t_rows, ml = m0 % p.t_rows;
           T* dst = C + b * p.t_batch_stride + (int64_t)n * p.t_ld + ml;
           if (quad_ok && m0 + 3 < p.M) {   // t_rows % 4 == 0 => the quad never straddles a batch
-            if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+            if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
             else *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
           } else {
 #pragma unroll
@@ -889,8 +890,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const emo_gemm_par
         auto m_of = [&](int i, int row) -> int64_t {
           return ((int64_t)img * p.H + y0 + (wvm * WTM + i) * 2 + (row >> 4)) * p.W_ + x0 + (row & 15);
         };
-        epilogue_lds<WTM, WTN, NW, Halo::HALO_BYTES, false>(acc, pe, m_of, wn0, wave, lane, lds_base + ((gc + 1) & 1) * Halo::HALO_BYTES,
-                                                            (bf16_t*)C, (const bf16_t*)R);
+        epilogue_lds<T, WTM, WTN, NW, Halo::HALO_BYTES, false>(acc, pe, m_of, wn0, wave, lane, lds_base + ((gc + 1) & 1) * Halo::HALO_BYTES, C, R);
         staged = true;
       }
     }
@@ -940,9 +940,9 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(const emo_gem
       if (vec_io) {
         if (R) {
           if constexpr (sizeof(T) == 2) {
-            const uint2 rv = *(const uint2*)(R + m * p.ldr + no);
-            v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-            v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+            float r4[4];
+            unpack4<T>(*(const uint2*)(R + m * p.ldr + no), r4);
+            v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
           } else {
             const float4 rv = *(const float4*)(R + m * p.ldr + no);
             v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(const emo_gem
         }
 #pragma unroll
         for (int e = 0; e < 4; e++) v[e] *= p.out_scale;
-        if constexpr (sizeof(T) == 2) *(uint2*)(C + m * p.ldc + no) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        if constexpr (sizeof(T) == 2) *(uint2*)(C + m * p.ldc + no) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
         else *(float4*)(C + m * p.ldc + no) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
 #pragma unroll
@@ -981,7 +981,7 @@ static GemmPlan plan_gemm(int64_t M, int N, int K, int dtype, int geglu, int tra
   const int bk = KBYTES / (dtype == EMO_F32 ? 4 : 2);
   const int nk = (K + bk - 1) / bk;
   static const int big_min_nk = env_int("EMO_GEMM_BIG_MINNK", 0);
-  pl.big = (dtype == EMO_BF16 && tiles256 >= 224 && (N % 256 == 0 || N >= 1792) && nk >= big_min_nk) ? 1 : 0;
+  pl.big = (dtype != EMO_F32 && tiles256 >= 224 && (N % 256 == 0 || N >= 1792) && nk >= big_min_nk) ? 1 : 0;
   pl.nt5 = (!pl.big && !geglu && N % 160 == 0) ? 1 : 0;
   pl.small = 0;
   if (pl.nt5 && N % 128 == 0) {
@@ -1104,8 +1104,8 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
   EMO_CHECK(pp, EMO_ERR_NULL, "emo_gemm: null params");
   const emo_gemm_params& p = *pp;
   EMO_CHECK(p.A && p.W && p.C, EMO_ERR_NULL, "emo_gemm: null pointer");
-  EMO_CHECK(p.dtype == EMO_F32 || p.dtype == EMO_BF16, EMO_ERR_BAD_DTYPE, "emo_gemm: dtype %d", p.dtype);
-  const int V = p.dtype == EMO_F32 ? 4 : 8;
+  EMO_CHECK(emo_dtype_ok(p.dtype), EMO_ERR_BAD_DTYPE, "emo_gemm: dtype %d", p.dtype);
+  const int V = emo_dtype_vec(p.dtype);
   EMO_CHECK(p.M > 0 && p.N > 0 && p.K > 0, EMO_ERR_BAD_SHAPE, "emo_gemm: M=%lld N=%d K=%d", (long long)p.M, p.N, p.K);
   EMO_CHECK(p.K % V == 0 && p.lda % V == 0, EMO_ERR_BAD_SHAPE, "emo_gemm: K=%d lda=%lld must be multiples of %d", p.K,
             (long long)p.lda, V);
@@ -1135,6 +1135,8 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
         (!p.rowbias || (p.rows_per_batch % (p.H * p.W_) == 0 && (p.ld_rowbias & 3) == 0))) {
       static bool once = false;
       if (!once) {
+        hipError_t e0 = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo::LDS_BYTES);
+        if (e0 != hipSuccess) return emo_fail(EMO_ERR_HIP, "emo_gemm: hipFuncSetAttribute(halo conv f16)");
         hipError_t e1 = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo::LDS_BYTES);
         hipError_t e2 = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo::LDS_BYTES);
         if (e1 != hipSuccess || e2 != hipSuccess) return emo_fail(EMO_ERR_HIP, "emo_gemm: hipFuncSetAttribute(halo conv)");
@@ -1143,8 +1145,7 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
       const int64_t tiles = (p.M / 128) * ((p.N + Halo::BN - 1) / Halo::BN);
       const int64_t gx = tiles > 512 ? 512 : tiles;
       hipStream_t st = as_stream(stream);
-      if (p.dtype == EMO_F32) conv3x3_halo_kernel<float><<<(unsigned)gx, 256, Halo::LDS_BYTES, st>>>(p);
-      else conv3x3_halo_kernel<bf16_t><<<(unsigned)gx, 256, Halo::LDS_BYTES, st>>>(p);
+      EMO_DISPATCH(p.dtype, "emo_gemm", (conv3x3_halo_kernel<T><<<(unsigned)gx, 256, Halo::LDS_BYTES, st>>>(p)));
       EMO_LAUNCH_CHECK();
       return EMO_OK;
     }
@@ -1155,13 +1156,13 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
     EMO_CHECK(p.N % 4 == 0, EMO_ERR_BAD_SHAPE, "emo_gemm: split-K needs N %% 4 == 0");
   }
   hipStream_t st = as_stream(stream);
-  int rc = p.dtype == EMO_F32 ? dispatch_gemm<float>(p, pl, S, st) : dispatch_gemm<bf16_t>(p, pl, S, st);
+  int rc = EMO_OK;
+  EMO_DISPATCH(p.dtype, "emo_gemm", rc = dispatch_gemm<T>(p, pl, S, st));
   if (rc) return rc;
   if (S > 1) {
     const int64_t total = p.M * (p.geglu ? p.N / 2 : p.N) / 4;
     int64_t g = (total + 255) / 256; if (g > 4096) g = 4096;
-    if (p.dtype == EMO_F32) gemm_splitk_epilogue_kernel<float><<<(int)g, 256, 0, st>>>(p);
-    else gemm_splitk_epilogue_kernel<bf16_t><<<(int)g, 256, 0, st>>>(p);
+    EMO_DISPATCH(p.dtype, "emo_gemm", (gemm_splitk_epilogue_kernel<T><<<(int)g, 256, 0, st>>>(p)));
     EMO_LAUNCH_CHECK();
   }
   return EMO_OK;

@@ -275,8 +275,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
 }
 
 static int gn_check(const char* who, int N, int64_t S, int C, int G, int ld, int dtype) {
-  EMO_CHECK(dtype == EMO_F32 || dtype == EMO_BF16, EMO_ERR_BAD_DTYPE, "%s: dtype %d", who, dtype);
-  int V = dtype == EMO_F32 ? 4 : 8;
+  EMO_CHECK(emo_dtype_ok(dtype), EMO_ERR_BAD_DTYPE, "%s: dtype %d", who, dtype);
+  int V = emo_dtype_vec(dtype);
   EMO_CHECK(N > 0 && S > 0 && C > 0 && G > 0 && C % G == 0, EMO_ERR_BAD_SHAPE, "%s: N=%d S=%lld C=%d G=%d", who, N, (long long)S, C, G);
   EMO_CHECK(C % V == 0 && ld % V == 0 && ld >= C, EMO_ERR_BAD_SHAPE, "%s: C=%d ld=%d must be multiples of %d", who, C, ld, V);
   EMO_CHECK(C / V <= GN_THREADS * GN_MAXJ, EMO_ERR_UNSUPPORTED, "%s: C=%d too wide", who, C);
@@ -288,13 +288,12 @@ extern "C" int emo_groupnorm_stats(const void* x, int ldx, void* partials, int N
   EMO_CHECK(x && partials, EMO_ERR_NULL, "emo_groupnorm_stats: null pointer");
   int rc = gn_check("emo_groupnorm_stats", N, S, C, G, ldx, dtype);
   if (rc) return rc;
-  const GnGeom gg = gn_geom(N, S, C, G, dtype == EMO_F32 ? 4 : 8);
+  const GnGeom gg = gn_geom(N, S, C, G, emo_dtype_vec(dtype));
   const size_t lds = (size_t)gg.RP * gg.Cp * 2 * sizeof(float);
   EMO_CHECK(lds <= 64 * 1024, EMO_ERR_UNSUPPORTED, "emo_groupnorm_stats: LDS %zu", lds);
   hipStream_t st = as_stream(stream);
   const dim3 grid((unsigned)(N * gg.nsplit_stats), (unsigned)gg.NC);
-  if (dtype == EMO_F32) gn_stats_kernel<float><<<grid, GN_THREADS, lds, st>>>((const float*)x, ldx, (float*)partials, S, gg.Cp, gg.Gp, G, gg.nsplit_stats);
-  else gn_stats_kernel<bf16_t><<<grid, GN_THREADS, lds, st>>>((const bf16_t*)x, ldx, (float*)partials, S, gg.Cp, gg.Gp, G, gg.nsplit_stats);
+  EMO_DISPATCH(dtype, "emo_groupnorm_stats", (gn_stats_kernel<T><<<grid, GN_THREADS, lds, st>>>((const T*)x, ldx, (float*)partials, S, gg.Cp, gg.Gp, G, gg.nsplit_stats)));
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
@@ -307,16 +306,13 @@ extern "C" int emo_groupnorm_apply(const void* x, int ldx, const void* partials,
   rc = gn_check("emo_groupnorm_apply", N, S, C, G, ldy, dtype);
   if (rc) return rc;
   EMO_CHECK(((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0, EMO_ERR_BAD_SHAPE, "emo_groupnorm_apply: gamma/beta alignment");
-  const GnGeom gg = gn_geom(N, S, C, G, dtype == EMO_F32 ? 4 : 8);
+  const GnGeom gg = gn_geom(N, S, C, G, emo_dtype_vec(dtype));
   const double count = (double)S * (C / G);
   hipStream_t st = as_stream(stream);
   const dim3 grid((unsigned)(N * gg.nsplit_apply), (unsigned)gg.NC);
-  if (dtype == EMO_F32)
-    gn_apply_kernel<float><<<grid, GN_THREADS, 0, st>>>((const float*)x, ldx, (const float*)partials, gamma, beta, (float*)y, ldy, S, gg.Cp, gg.Gp, G,
-                                                         gg.nsplit_stats, gg.nsplit_apply, count, eps, silu);
-  else
-    gn_apply_kernel<bf16_t><<<grid, GN_THREADS, 0, st>>>((const bf16_t*)x, ldx, (const float*)partials, gamma, beta, (bf16_t*)y, ldy, S, gg.Cp,
-                                                          gg.Gp, G, gg.nsplit_stats, gg.nsplit_apply, count, eps, silu);
+  EMO_DISPATCH(dtype, "emo_groupnorm_apply",
+               (gn_apply_kernel<T><<<grid, GN_THREADS, 0, st>>>((const T*)x, ldx, (const float*)partials, gamma, beta, (T*)y, ldy, S, gg.Cp, gg.Gp, G,
+                                                                gg.nsplit_stats, gg.nsplit_apply, count, eps, silu)));
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
@@ -384,7 +380,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
           float v = (f[j][e] - mean) * rstd * g[e] + b[e];
           if (pe_row) {
             // the reference adds pe to the LN output tensor (in compute dtype) => round first in bf16 mode
-            if constexpr (sizeof(T) == 2) v = bf2f(f2bf(v));
+            v = round_through<T>(v);
             v += pe_row[cv * V + e];
           }
           o[e] = v;
@@ -419,16 +415,15 @@ static void launch_layernorm(const T* x, int ldx, const float* gamma, const floa
 extern "C" int emo_layernorm(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, int64_t M, int C,
                              float eps, const float* pe, int rows_per_frame, int frames, int dtype, void* stream) {
   EMO_CHECK(x && gamma && beta && y, EMO_ERR_NULL, "emo_layernorm: null pointer");
-  EMO_CHECK(dtype == EMO_F32 || dtype == EMO_BF16, EMO_ERR_BAD_DTYPE, "emo_layernorm: dtype %d", dtype);
-  const int V = dtype == EMO_F32 ? 4 : 8;
+  EMO_CHECK(emo_dtype_ok(dtype), EMO_ERR_BAD_DTYPE, "emo_layernorm: dtype %d", dtype);
+  const int V = emo_dtype_vec(dtype);
   EMO_CHECK(M > 0 && C > 0 && C % V == 0 && ldx % V == 0 && ldy % V == 0 && ldx >= C && ldy >= C, EMO_ERR_BAD_SHAPE,
             "emo_layernorm: M=%lld C=%d ldx=%d ldy=%d", (long long)M, C, ldx, ldy);
   EMO_CHECK(C / V <= 64 * LN_MAXV, EMO_ERR_UNSUPPORTED, "emo_layernorm: C=%d too wide", C);
   EMO_CHECK(!pe || (rows_per_frame > 0 && frames > 0), EMO_ERR_BAD_SHAPE, "emo_layernorm: pe needs rows_per_frame/frames");
   EMO_CHECK(((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0, EMO_ERR_BAD_SHAPE, "emo_layernorm: gamma/beta alignment");
   hipStream_t st = as_stream(stream);
-  if (dtype == EMO_F32) launch_layernorm<float>((const float*)x, ldx, gamma, beta, (float*)y, ldy, M, C, eps, pe, rows_per_frame, frames, st);
-  else launch_layernorm<bf16_t>((const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, M, C, eps, pe, rows_per_frame, frames, st);
+  EMO_DISPATCH(dtype, "emo_layernorm", (launch_layernorm<T>((const T*)x, ldx, gamma, beta, (T*)y, ldy, M, C, eps, pe, rows_per_frame, frames, st)));
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }

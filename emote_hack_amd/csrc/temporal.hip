@@ -23,6 +23,14 @@ template <> __device__ __forceinline__ float dot16<float>(const uint4& a, const 
   acc += __uint_as_float(a.w) * __uint_as_float(b.w);
   return acc;
 }
+template <> __device__ __forceinline__ float dot16<f16_t>(const uint4& a, const uint4& b, float acc) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a.x), __builtin_bit_cast(h2, b.x), acc, false);   // v_dot2_f32_f16
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a.y), __builtin_bit_cast(h2, b.y), acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a.z), __builtin_bit_cast(h2, b.z), acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a.w), __builtin_bit_cast(h2, b.w), acc, false);
+  return acc;
+}
 template <> __device__ __forceinline__ float dot16<bf16_t>(const uint4& a, const uint4& b, float acc) {
   typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
   acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.x), __builtin_bit_cast(bf2, b.x), acc, false);   // v_dot2_f32_bf16
@@ -106,7 +114,7 @@ __global__ __launch_bounds__(TA_THREADS) void temporal_attention_kernel(const T*
     const float inv = 1.0f / sum;
     for (int k = 0; k < F; k++) {
       float w = row[k] * inv;
-      if constexpr (sizeof(T) == 2) w = bf2f(f2bf(w));
+      w = round_through<T>(w);
       row[k] = w;
     }
   }
@@ -141,8 +149,8 @@ __global__ __launch_bounds__(TA_THREADS) void temporal_attention_kernel(const T*
 extern "C" int emo_temporal_attention(const void* qkv, int64_t ldqkv, void* out, int64_t ldo, int B, int F, int HW, int heads, int d,
                                       float scale, int dtype, void* stream) {
   EMO_CHECK(qkv && out, EMO_ERR_NULL, "emo_temporal_attention: null pointer");
-  EMO_CHECK(dtype == EMO_F32 || dtype == EMO_BF16, EMO_ERR_BAD_DTYPE, "emo_temporal_attention: dtype %d", dtype);
-  const int V = dtype == EMO_F32 ? 4 : 8, esz = dtype == EMO_F32 ? 4 : 2;
+  EMO_CHECK(emo_dtype_ok(dtype), EMO_ERR_BAD_DTYPE, "emo_temporal_attention: dtype %d", dtype);
+  const int V = emo_dtype_vec(dtype), esz = dtype == EMO_F32 ? 4 : 2;
   EMO_CHECK(B > 0 && F > 0 && F <= 32 && HW > 0 && heads > 0 && d > 0, EMO_ERR_BAD_SHAPE, "emo_temporal_attention: B=%d F=%d HW=%d", B, F, HW);
   EMO_CHECK(d % V == 0 && ldqkv % V == 0 && ldo % V == 0, EMO_ERR_BAD_SHAPE, "emo_temporal_attention: d=%d must be a multiple of %d", d, V);
   const int C = heads * d;
@@ -150,7 +158,7 @@ extern "C" int emo_temporal_attention(const void* qkv, int64_t ldqkv, void* out,
   // choose heads-per-block / pixels-per-block so the Q,K,V stage stays under ~48 KB
   const int budget = 48 * 1024;
   int hpb = heads;
-  while (hpb > 1 && (hpb % 2 == 0) && 3 * F * (hpb * d * esz + 16) > budget) hpb /= 2;
+  while (hpb > 1 && (hpb % 2 == 0) && 3 * F * (hpb * d * esz + 16) + hpb * F * F * 4 > budget) hpb /= 2;   // stage + score matrix
   int P = 1;
   while (P < 8 && P * 2 <= HW && 3 * F * (2 * P * hpb * d * esz + 16) + 2 * P * hpb * F * F * 4 <= budget) P *= 2;
   const size_t lds = (size_t)3 * F * (P * hpb * d * esz + 16) + (size_t)P * hpb * F * F * 4;
@@ -160,10 +168,8 @@ extern "C" int emo_temporal_attention(const void* qkv, int64_t ldqkv, void* out,
   const int JW = P * hpb * d / V < TA_THREADS ? P * hpb * d / V : TA_THREADS;
   const int FP = F <= 16 ? 16 : 32;
   hipStream_t st = as_stream(stream);
-  if (dtype == EMO_F32)
-    temporal_attention_kernel<float><<<grid, TA_THREADS, lds, st>>>((const float*)qkv, ldqkv, (float*)out, ldo, F, HW, C, d, hpb, P, scale, JW, FP);
-  else
-    temporal_attention_kernel<bf16_t><<<grid, TA_THREADS, lds, st>>>((const bf16_t*)qkv, ldqkv, (bf16_t*)out, ldo, F, HW, C, d, hpb, P, scale, JW, FP);
+  EMO_DISPATCH(dtype, "emo_temporal_attention",
+               (temporal_attention_kernel<T><<<grid, TA_THREADS, lds, st>>>((const T*)qkv, ldqkv, (T*)out, ldo, F, HW, C, d, hpb, P, scale, JW, FP)));
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }

@@ -12,9 +12,9 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import EMO_BF16, EMO_F32, AttentionParams, GemmParams, check
+from ._lib import EMO_BF16, EMO_F16, EMO_F32, AttentionParams, GemmParams, check
 
-_DT = {torch.float32: EMO_F32, torch.bfloat16: EMO_BF16}
+_DT = {torch.float32: EMO_F32, torch.bfloat16: EMO_BF16, torch.float16: EMO_F16}
 
 
 def dt(t_or_dtype) -> int:
@@ -22,7 +22,7 @@ def dt(t_or_dtype) -> int:
     try:
         return _DT[d]
     except KeyError:
-        raise _lib.EmoHipError(f"unsupported compute dtype {d} (float32 | bfloat16)")
+        raise _lib.EmoHipError(f"unsupported compute dtype {d} (float32 | bfloat16 | float16)")
 
 
 def vec(dtype) -> int:

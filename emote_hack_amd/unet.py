@@ -114,8 +114,8 @@ class UNet3DConditionModel:
             else:
                 device = torch.device(a)
         if dtype is not None:
-            if dtype not in (torch.float32, torch.bfloat16):
-                raise EmoHipError(f"compute dtype {dtype} not supported (float32 | bfloat16)")
+            if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+                raise EmoHipError(f"compute dtype {dtype} not supported (float32 | bfloat16 | float16)")
             self.dtype = dtype
         if device is not None:
             self.device = torch.device(device)

@@ -13,7 +13,8 @@
  *   - activations are "rows x channels" row-major (NHWC: row = ((b*F+f)*H + y)*W + x); `ld*`
  *     are leading dimensions in ELEMENTS.  Weights are [N][K] row-major (torch Linear layout;
  *     conv weights re-laid once at load to [Cout][ky][kx][Cin]).
- *   - dtype: EMO_F32 (validation mode: f32 MFMA, exact-f32 accumulate) or EMO_BF16
+ *   - dtype: EMO_F32 (validation mode: f32 MFMA, exact-f32 accumulate), EMO_BF16 or EMO_F16 (IEEE half: the reference's
+ *     `weight_dtype=torch.float16` configurations; same kernels, v_mfma_f32_32x32x16_f16)
  *     (production: bf16 MFMA, f32 accumulate).  Statistics / softmax / latents are always f32.
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), never allocates,
  *     never synchronises, keeps no global mutable state (re-entrant per stream).
@@ -30,7 +31,7 @@
 extern "C" {
 #endif
 
-typedef enum { EMO_F32 = 0, EMO_BF16 = 1 } emo_dtype;
+typedef enum { EMO_F32 = 0, EMO_BF16 = 1, EMO_F16 = 2 } emo_dtype;
 
 typedef enum {
   EMO_OK = 0,

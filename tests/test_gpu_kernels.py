@@ -14,8 +14,8 @@ from emote_hack_amd.synth import seeded_randn
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda"
-TOL = {torch.float32: dict(rtol=1e-3, atol=1e-4), torch.bfloat16: dict(rtol=3e-2, atol=3e-2)}
-DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: dict(rtol=1e-3, atol=1e-4), torch.bfloat16: dict(rtol=3e-2, atol=3e-2), torch.float16: dict(rtol=5e-3, atol=5e-3)}
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 
 
 def ops():

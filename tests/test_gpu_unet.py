@@ -33,10 +33,11 @@ def check(got, ref, dtype):
         torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-4)
     else:
         # bf16 yard-stick relative to the tensor's own scale (UNet output mean-abs ~0.3, LN banks ~0.8):
-        # mean error < 3 % of mean |ref|, max error < 10 % of max |ref|
+        # mean error < 3 % of mean |ref|, max error < 10 % of max |ref|; fp16 (11 significand bits) 8x tighter
+        k = 1.0 if dtype == torch.bfloat16 else 0.125
         err = (got - ref).abs()
-        assert float(err.mean()) < 0.03 * float(ref.abs().mean()) + 1e-3, (float(err.mean()), float(ref.abs().mean()))
-        assert float(err.max()) < 0.10 * float(ref.abs().max()) + 1e-2, (float(err.max()), float(ref.abs().max()))
+        assert float(err.mean()) < k * 0.03 * float(ref.abs().mean()) + 1e-3, (float(err.mean()), float(ref.abs().mean()))
+        assert float(err.max()) < k * 0.10 * float(ref.abs().max()) + 1e-2, (float(err.max()), float(ref.abs().max()))
 
 
 @pytest.fixture(scope="module")
@@ -44,14 +45,14 @@ def tiny():
     return load_file(os.path.join(G, "unet_tiny.safetensors"))
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_unet_tiny_plain(tiny, dtype):
     x, ctx = cases.tiny_inputs(2, 4)
     m = build(cases.TINY, dtype)
     check(m(x[:, :, :2].to(DEV), 981, ctx.to(DEV)).sample, tiny["plain/out"], dtype)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_unet_tiny_motion(tiny, dtype):
     x, ctx = cases.tiny_inputs(2, 4)
     m = build(cases.TINY_MOTION, dtype)
@@ -74,7 +75,7 @@ def test_unet_tiny_controlnet_residuals(tiny):
     check(y, tiny["motion/out_ctrl"], torch.float32)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_reference_write_read(tiny, dtype):
     """ReferenceNet write -> fp16-rounded banks -> Backbone read with CFG batch 2."""
     from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
@@ -168,6 +169,26 @@ def test_cfg1_baseline_config1():
     m = build(cfg, torch.float32)
     y = m(seeded_randn((1, 4, 1, 32, 32), 1).to(DEV), 981, seeded_randn((1, 77, 768), 2).to(DEV)).sample
     check(y, load_file(path)["cfg1/out"], torch.float32)
+
+
+def test_config4_geometry_fp16():
+    """BASELINE.json configs[4] geometry: 768x768 (96x96 latents), a 24-frame window, speed-layer embeddings, fp16 - on a
+    two-level SD-1.5-width UNet with motion modules.  fp16 HIP vs f32 HIP (the f32 path is pinned to the oracle at the
+    small sizes above) within the fp16 yard-stick, and CFG batch rows independent of each other."""
+    cfg = dict(cases.SD15_MOTION, block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock3D", "DownBlock3D"),
+               up_block_types=("UpBlock3D", "CrossAttnUpBlock3D"), attention_head_dim=8, layers_per_block=1)
+    x, ctx = seeded_randn((2, 4, 24, 96, 96), 1), seeded_randn((2, 77, 768), 2)
+    speed = 0.1 * seeded_randn((2, 4 * 320), 3)
+    m32 = build(cfg, torch.float32)
+    y32 = m32(x.to(DEV), 500, ctx.to(DEV), speed_embeddings=speed.to(DEV)).sample.float().cpu()
+    del m32
+    torch.cuda.empty_cache()
+    m16 = build(cfg, torch.float16)
+    y16 = m16(x.to(DEV), 500, ctx.to(DEV), speed_embeddings=speed.to(DEV)).sample
+    assert y16.shape == (2, 4, 24, 96, 96) and bool(torch.isfinite(y16).all())
+    check(y16, y32, torch.float16)
+    y1 = m16(x[1:].to(DEV), 500, ctx[1:].to(DEV), speed_embeddings=speed[1:].to(DEV)).sample
+    torch.testing.assert_close(y1.float().cpu(), y16[1:].float().cpu(), rtol=2e-2, atol=2e-2)
 
 
 def test_unet_vs_oracle_medium_size_properties():
