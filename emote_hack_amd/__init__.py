@@ -19,6 +19,9 @@ def __getattr__(name):  # heavy modules on demand
     if name in ("EMOAnimationPipeline", "AnimationPipelineOutput"):
         from . import pipeline
         return getattr(pipeline, name)
+    if name in ("ControlNetModel", "ControlNetOutput"):
+        from . import controlnet
+        return getattr(controlnet, name)
     if name == "AppearanceEncoderModel":
         from .appearance_encoder import AppearanceEncoderModel
         return AppearanceEncoderModel

@@ -62,9 +62,10 @@ class UNetSpec:
     mid: BlockSpec
     up: List[BlockSpec]
     has_out: bool = True
+    controlnet: Optional[tuple] = None   # ControlNet: conditioning-embedding channels (16, 32, 96, 256); no up path
 
 
-def build_spec(cfg_kwargs, *, has_out=True) -> UNetSpec:
+def build_spec(cfg_kwargs, *, has_out=True, controlnet=None) -> UNetSpec:
     cfg = normalize_unet_config(dict(cfg_kwargs), strict=False)
     boc = cfg["block_out_channels"]
     temb = boc[0] * 4
@@ -111,6 +112,8 @@ def build_spec(cfg_kwargs, *, has_out=True) -> UNetSpec:
     mid.attentions = [tfm("mid_block.attentions.0", c, hd[-1])]
     mid.motions = [motion("mid_block.motion_modules.0", c, cfg["use_motion_module"] and cfg["motion_module_mid_block"])]
 
+    if controlnet is not None:   # magicanimate/models/controlnet.py:155-262: down blocks + mid block only
+        return UNetSpec(cfg, down, mid, [], False, tuple(controlnet))
     up = []
     rboc = list(reversed(boc))
     rhd = list(reversed(hd))
@@ -206,6 +209,16 @@ def _motion_shapes(m: MotionSpec, d):
     d[f"{p}.proj_out.bias"] = (c,)
 
 
+def skip_channels(spec: UNetSpec):
+    """Channel counts of the skip tensors in push order: conv_in, every resnet sub-block, every downsampler."""
+    out = [spec.cfg["block_out_channels"][0]]
+    for b in spec.down:
+        out += [b.channels] * len(b.resnets)
+        if b.sampler:
+            out.append(b.channels)
+    return out
+
+
 def param_shapes(spec: UNetSpec) -> "OrderedDict[str, tuple]":
     cfg = spec.cfg
     boc = cfg["block_out_channels"]
@@ -216,7 +229,18 @@ def param_shapes(spec: UNetSpec) -> "OrderedDict[str, tuple]":
     d["time_embedding.linear_1.bias"] = (boc[0] * 4,)
     d["time_embedding.linear_2.weight"] = (boc[0] * 4, boc[0] * 4)
     d["time_embedding.linear_2.bias"] = (boc[0] * 4,)
-    for b in spec.down + [spec.mid] + spec.up:
+    if spec.controlnet is not None:   # ControlNetConditioningEmbedding (controlnet.py:49-91), module registration order
+        cc = spec.controlnet
+        d["controlnet_cond_embedding.conv_in.weight"] = (cc[0], cfg.get("conditioning_channels", 3), 3, 3)
+        d["controlnet_cond_embedding.conv_in.bias"] = (cc[0],)
+        for i in range(len(cc) - 1):
+            d[f"controlnet_cond_embedding.blocks.{2 * i}.weight"] = (cc[i], cc[i], 3, 3)
+            d[f"controlnet_cond_embedding.blocks.{2 * i}.bias"] = (cc[i],)
+            d[f"controlnet_cond_embedding.blocks.{2 * i + 1}.weight"] = (cc[i + 1], cc[i], 3, 3)
+            d[f"controlnet_cond_embedding.blocks.{2 * i + 1}.bias"] = (cc[i + 1],)
+        d["controlnet_cond_embedding.conv_out.weight"] = (boc[0], cc[-1], 3, 3)
+        d["controlnet_cond_embedding.conv_out.bias"] = (boc[0],)
+    for b in spec.down + ([] if spec.controlnet is not None else [spec.mid]) + spec.up:
         for r in b.resnets:
             _resnet_shapes(r, d)
         for a in b.attentions:
@@ -228,6 +252,16 @@ def param_shapes(spec: UNetSpec) -> "OrderedDict[str, tuple]":
         if b.sampler:
             d[f"{b.sampler}.conv.weight"] = (b.channels, b.channels, 3, 3)
             d[f"{b.sampler}.conv.bias"] = (b.channels,)
+    if spec.controlnet is not None:   # zero convs (controlnet.py:209-243), then the mid block (registered last, :245-257)
+        for k, c in enumerate(skip_channels(spec)):
+            d[f"controlnet_down_blocks.{k}.weight"] = (c, c, 1, 1)
+            d[f"controlnet_down_blocks.{k}.bias"] = (c,)
+        d["controlnet_mid_block.weight"] = (boc[-1], boc[-1], 1, 1)
+        d["controlnet_mid_block.bias"] = (boc[-1],)
+        for r in spec.mid.resnets:
+            _resnet_shapes(r, d)
+        for a in spec.mid.attentions:
+            _transformer_shapes(a, d)
     if spec.has_out:
         d["conv_norm_out.weight"] = (boc[0],)
         d["conv_norm_out.bias"] = (boc[0],)

@@ -62,8 +62,9 @@ class _State:
 class UNet3DConditionModel:
     def __init__(self, **kwargs):
         self._has_out = kwargs.pop("_has_out", True)
+        self._controlnet = kwargs.pop("_controlnet", None)   # ControlNetModel: conditioning-embedding channels
         self.config: FrozenConfig = normalize_unet_config(kwargs)
-        self.spec: UNetSpec = build_spec(self.config, has_out=self._has_out)
+        self.spec: UNetSpec = build_spec(self.config, has_out=self._has_out, controlnet=self._controlnet)
         self.sample_size = self.config["sample_size"]
         self.in_channels = self.config["in_channels"]
         self.num_upsamplers = len(self.config["block_out_channels"]) - 1
@@ -257,6 +258,15 @@ class UNet3DConditionModel:
         if spec.has_out:
             w["conv_norm_out.g"], w["conv_norm_out.b"] = f32("conv_norm_out.weight"), f32("conv_norm_out.bias")
             w["conv_out.w"], w["conv_out.b"] = conv3("conv_out.weight"), f32("conv_out.bias")
+        if spec.controlnet is not None:
+            ce = "controlnet_cond_embedding"
+            names = ["conv_in"] + [f"blocks.{i}" for i in range(2 * (len(spec.controlnet) - 1))] + ["conv_out"]
+            for n_ in names:
+                w[f"{ce}.{n_}.w"], w[f"{ce}.{n_}.b"] = conv3(f"{ce}.{n_}.weight"), f32(f"{ce}.{n_}.bias")
+            from .spec import skip_channels
+            for k in range(len(skip_channels(spec))):
+                w[f"controlnet_down_blocks.{k}.w"], w[f"controlnet_down_blocks.{k}.b"] = lin(f"controlnet_down_blocks.{k}.weight"), f32(f"controlnet_down_blocks.{k}.bias")
+            w["controlnet_mid_block.w"], w["controlnet_mid_block.b"] = lin("controlnet_mid_block.weight"), f32("controlnet_mid_block.bias")
         self._w = w
 
     # ------------------------------------------------------------------ blocks (all HIP launches)
@@ -342,7 +352,7 @@ class UNet3DConditionModel:
     # ------------------------------------------------------------------ forward (three stages so that the sampler can
     # overlap the ReferenceNet pass with the bank-independent down path on a second HIP stream)
     def _begin(self, sample, timestep, encoder_hidden_states, audio_features=None, speed_embeddings=None,
-               down_block_additional_residuals=None, mid_block_additional_residual=None):
+               down_block_additional_residuals=None, mid_block_additional_residual=None, add_after_conv_in=None):
         if self._w is None:
             raise EmoHipError("UNet3DConditionModel: weights not loaded / model not on a HIP device "
                               "(load_state_dict + .to('cuda')); there is no CPU execution path")
@@ -391,9 +401,11 @@ class UNet3DConditionModel:
         # Zero-copy skip connections: every skip tensor is produced straight into the RIGHT columns of the buffer the up
         # path will read as cat([hidden, skip]) (unet_3d_blocks.py:627-629), and the up path's producers write `hidden`
         # into its LEFT columns - the concatenation never runs.  (ControlNet residuals re-materialise the skips: old path.)
-        s.zero_copy = down_block_additional_residuals is None
+        s.zero_copy = down_block_additional_residuals is None and len(self.spec.up) > 0
         s.skips, s.n_pushed = [], 0
         s.x, _, _ = ops.conv3x3(x, w["conv_in.w"], w["conv_in.b"], B * F, H, W, out=self._skip_slot(s, B * F * H * W, self.spec.down[0].resnets[0].cin))
+        if add_after_conv_in is not None:   # ControlNet: sample += controlnet_cond_embedding(cond) (controlnet.py:523-525)
+            s.x = ops.add(s.x, add_after_conv_in)
         self._push_skip(s, s.x)
         s.h, s.w = H, W
         return s
@@ -445,18 +457,23 @@ class UNet3DConditionModel:
             s.skips = [ops.add(sk, ops.ncfhw_to_rows(r.to(dev), dtp)) for sk, r in zip(s.skips, down_res)]  # unet_controlnet.py:430-439
         s.x, s.h, s.w = x, h_, w_
 
+    def _run_mid(self, s, x, out=None):
+        """mid block (unet_3d_blocks.py UNetMidBlock3DCrossAttn): resnet, transformer, [motion], resnet"""
+        spec, c, h_, w_ = self.spec, s.c, s.h, s.w
+        sc = self.config["mid_block_scale_factor"]
+        x = self._resnet(spec.mid.resnets[0], x, s.temb_all, c, h_, w_, sc)
+        x = self._transformer(spec.mid.attentions[0], x, s.ctx_rows, s.ctx_len, s.ctx_div, c, h_, w_)
+        if spec.mid.motions[0] is not None:
+            x = self._motion(spec.mid.motions[0], x, c, h_, w_)
+        return self._resnet(spec.mid.resnets[1], x, s.temb_all, c, h_, w_, sc, out=out)
+
     def _run_rest(self, s, return_rows=False):
         cfg, w, spec, dtp, dev = self.config, self._w, self.spec, self.dtype, self.device
         x, c, h_, w_ = s.x, s.c, s.h, s.w
         B, F = s.B, s.F
         down_res, mid_res = s.ctrl
-        sc = cfg["mid_block_scale_factor"]
-        x = self._resnet(spec.mid.resnets[0], x, s.temb_all, c, h_, w_, sc)
-        x = self._transformer(spec.mid.attentions[0], x, s.ctx_rows, s.ctx_len, s.ctx_div, c, h_, w_)
-        if spec.mid.motions[0] is not None:
-            x = self._motion(spec.mid.motions[0], x, c, h_, w_)
         skips = s.skips
-        x = self._resnet(spec.mid.resnets[1], x, s.temb_all, c, h_, w_, sc, out=self._hidden_slot(s, skips, spec.mid.resnets[1].cout))
+        x = self._run_mid(s, x, out=self._hidden_slot(s, skips, spec.mid.resnets[1].cout))
         if down_res is not None and mid_res is not None:
             x = ops.add(x, ops.ncfhw_to_rows(mid_res.to(dev), dtp))
         for blk in spec.up:

@@ -296,3 +296,40 @@ def test_cfg1_unet_config_yaml_shape():
     sd = synth_state_dict(param_shapes(build_spec(cfg)))
     y = U.unet_forward(sd, cfg, seeded_randn((1, 4, 1, 32, 32), 1), 981, seeded_randn((1, 77, 768), 2))
     close(y, load_file(path)["cfg1/out"])
+
+
+def test_controlnet_cond_embedding_vs_reference():
+    """oracle/controlnet_ref.cond_embedding vs the reference's ControlNetConditioningEmbedding (controlnet.py:49-91) run
+    through tools/oracle/gen_golden.py (same synthesised weights by key name)."""
+    from oracle.controlnet_ref import cond_embedding
+    from emote_hack_amd.synth import synth_state_dict
+    shapes = {"controlnet_cond_embedding.conv_in.weight": (16, 3, 3, 3), "controlnet_cond_embedding.conv_in.bias": (16,)}
+    cc = (16, 32, 96, 256)
+    for i in range(3):
+        shapes[f"controlnet_cond_embedding.blocks.{2 * i}.weight"] = (cc[i], cc[i], 3, 3)
+        shapes[f"controlnet_cond_embedding.blocks.{2 * i}.bias"] = (cc[i],)
+        shapes[f"controlnet_cond_embedding.blocks.{2 * i + 1}.weight"] = (cc[i + 1], cc[i], 3, 3)
+        shapes[f"controlnet_cond_embedding.blocks.{2 * i + 1}.bias"] = (cc[i + 1],)
+    shapes["controlnet_cond_embedding.conv_out.weight"] = (32, 256, 3, 3)
+    shapes["controlnet_cond_embedding.conv_out.bias"] = (32,)
+    # gen_golden synthesises under the module-local names with the prefix as salt: same (prefix + local key) strings
+    sd = synth_state_dict({k[len("controlnet_cond_embedding."):]: v for k, v in shapes.items()}, prefix="controlnet_cond_embedding.")
+    sd = {"controlnet_cond_embedding." + k: v for k, v in sd.items()}
+    g = load_file(os.path.join(G, "controlnet.safetensors"))
+    y = cond_embedding(sd, seeded_randn((2, 3, 64, 64), 70))
+    torch.testing.assert_close(y, g["cond_embedding/out"], rtol=1e-4, atol=1e-5)
+
+
+def test_controlnet_state_dict_keys_follow_the_reference_module_tree():
+    """Key names / shapes of ControlNetModel (controlnet.py:94-262): cond embedding, down blocks, 12 + 1 zero convs, mid."""
+    from emote_hack_amd.spec import build_spec, param_shapes, skip_channels
+    sp = build_spec(dict(cases.SD15, down_block_types=("CrossAttnDownBlock3D",) * 3 + ("DownBlock3D",)), controlnet=(16, 32, 96, 256))
+    d = param_shapes(sp)
+    assert skip_channels(sp) == [320, 320, 320, 320, 640, 640, 640, 1280, 1280, 1280, 1280, 1280]
+    assert d["controlnet_cond_embedding.conv_in.weight"] == (16, 3, 3, 3)
+    assert d["controlnet_cond_embedding.blocks.5.weight"] == (256, 96, 3, 3)
+    assert d["controlnet_cond_embedding.conv_out.weight"] == (320, 256, 3, 3)
+    assert d["controlnet_down_blocks.11.weight"] == (1280, 1280, 1, 1) and "controlnet_down_blocks.12.weight" not in d
+    assert d["controlnet_mid_block.weight"] == (1280, 1280, 1, 1)
+    assert not any(k.startswith(("up_blocks.", "conv_out.", "conv_norm_out.")) for k in d)
+    assert "mid_block.attentions.0.transformer_blocks.0.attn1.to_q.weight" in d

@@ -291,6 +291,27 @@ def gen_conditioning():
     print("conditioning.safetensors", list(T))
 
 
+# =============================================================================== ControlNet
+def gen_controlnet():
+    """The in-tree arithmetic of magicanimate/models/controlnet.py that does not need diffusers: the
+    ControlNetConditioningEmbedding class (AST-extracted, :49-91) with synthesised weights under the module's own key names
+    (prefix controlnet_cond_embedding.) on a 3x64x64 conditioning image."""
+    import torch.nn as nn
+
+    def zero_module(module):   # controlnet.py:570-573 (the weights are overwritten by load_synth anyway)
+        for p_ in module.parameters():
+            nn.init.zeros_(p_)
+        return module
+
+    C = shim.extract_classes("/root/reference/magicanimate/models/controlnet.py", ["ControlNetConditioningEmbedding"],
+                             extra_ns={"zero_module": zero_module})
+    ce = load_synth(C["ControlNetConditioningEmbedding"](conditioning_embedding_channels=32, block_out_channels=(16, 32, 96, 256)),
+                    "controlnet_cond_embedding.")
+    y = ce(seeded_randn((2, 3, 64, 64), 70))
+    save_file({"cond_embedding/out": y.contiguous()}, os.path.join(GOLD, "controlnet.safetensors"))
+    print("controlnet.safetensors", tuple(y.shape), float(y.abs().mean()))
+
+
 # =============================================================================== cfg1 (BASELINE config 1)
 def gen_cfg1():
     """BASELINE.json configs[0]: UNet built literally from configs/unet-config.yaml:default
@@ -311,7 +332,7 @@ if __name__ == "__main__":
     ap.add_argument("--skip-cfg1", action="store_true")
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    todo = a.only.split(",") if a.only else ["ints", "modules", "unet", "cond", "cfg1"]
+    todo = a.only.split(",") if a.only else ["ints", "modules", "unet", "cond", "controlnet", "cfg1"]
     if "ints" in todo:
         gen_ints()
     if "modules" in todo:
@@ -321,5 +342,7 @@ if __name__ == "__main__":
         gen_loop(u1, ref)
     if "cond" in todo:
         gen_conditioning()
+    if "controlnet" in todo:
+        gen_controlnet()
     if "cfg1" in todo and not a.skip_cfg1:
         gen_cfg1()
