@@ -94,7 +94,8 @@ class EMOAnimationPipeline:
     def prepare_denoise(self, latents, ref_image_latents, text_embeddings, *, appearance_encoder, num_inference_steps=50,
                         guidance_scale=7.5, eta=0.0, context_frames=16, context_stride=1, context_overlap=4,
                         context_batch_size=1, context_schedule="uniform", audio_features=None, speed_embeddings=None, seed=0,
-                        fusion_blocks="midup", dist=False, rank=0, world_size=1, return_eps=False, use_graphs=False):
+                        fusion_blocks="midup", dist=False, rank=0, world_size=1, return_eps=False, use_graphs=False,
+                        controlnet=None, controlnet_cond=None, controlnet_conditioning_scale=1.0):
         """Set up the loop state (EMOAnimationPipeline.py:628-696).  latents f32 (1,4,F_tot,h,w);
         ref_image_latents (1,4,h,w); text_embeddings (2,L,D) = [uncond, cond]."""
         unet, sch = self.unet, self.scheduler
@@ -147,6 +148,23 @@ class EMOAnimationPipeline:
         st.t_ref = torch.zeros(1, dtype=torch.int64, device=dev)   # timestep of the ReferenceNet pass this rank computes
         st.return_eps, st.eps_trace = return_eps, []
         st.bank_group, st.bank_shapes, st.bank_group_start, st.bank_now = None, None, -1, None
+        # ControlNet branch (EMOAnimationPipeline.py:643-650,678-679,718-746): (F_tot,3,H,W) conditioning images in [0,1]
+        st.controlnet = controlnet
+        if controlnet is not None:
+            if controlnet_cond is None or controlnet_cond.shape[0] != st.f_tot:
+                raise ValueError("controlnet_cond must hold one (3,H,W) conditioning image per frame")
+            st.cn_scale = float(controlnet_conditioning_scale)
+            st.cn_cond = controlnet_cond.to(dev).float()
+            # the frames this rank's windows touch; residuals are computed once per frame and step, in chunks of
+            # context_frames (the reference caches them per frame from overlap-0 windows: the network is per-frame, so
+            # the chunking does not enter the result)
+            need = sorted({k for ctx in st.my_contexts for c in ctx for k in c})
+            st.cn_frames = need
+            st.cn_pos = {k: i for i, k in enumerate(need)}
+            st.cn_chunks = [torch.tensor(need[i:i + context_frames], dtype=torch.int64, device=dev) for i in range(0, len(need), context_frames)]
+            st.cn_text = st.text[st.text.shape[0] // 2:][:1]        # cond text embedding (:678-679)
+            st.cn_sel = [[torch.tensor([st.cn_pos[k] for c in ctx for k in c], dtype=torch.int64, device=dev)] for ctx in st.my_contexts]
+            st.cn_down, st.cn_mid = None, None
         return st
 
     def _exchange_banks(self, st, si):
@@ -177,6 +195,30 @@ class EMOAnimationPipeline:
     #      can be captured once into HIP graphs and replayed for the other 49 steps
     def _part_writer(self, st):
         self._write_banks(st.appearance_encoder, st.writer, st.ref_rep, st.t_buf, st.text)    # :711-716
+
+    def _part_controlnet(self, st):
+        """Per-frame ControlNet residuals of this step (:718-746)."""
+        downs, mids = [], []
+        for idx in st.cn_chunks:
+            x = self.scheduler.scale_model_input(st.latents.index_select(2, idx), None)[0].permute(1, 0, 2, 3).contiguous()
+            d, m = st.controlnet(x, st.t_buf, encoder_hidden_states=st.cn_text.repeat(idx.numel(), 1, 1),
+                                 controlnet_cond=st.cn_cond.index_select(0, idx), conditioning_scale=st.cn_scale, return_dict=False)
+            downs.append(d)
+            mids.append(m)
+        st.cn_down = [torch.cat([d[i] for d in downs]) for i in range(len(downs[0]))]
+        st.cn_mid = torch.cat(mids)
+
+    def _controlnet_residuals(self, st, ci):
+        """select_controlnet_res_samples (:514-540): frames of the window batch, '(b f) c h w -> b c f h w', CFG repeat."""
+        if st.controlnet is None:
+            return {}
+        sel = st.cn_sel[ci][0]
+        nb, nf = len(st.my_contexts[ci]), len(st.my_contexts[ci][0])
+
+        def to5(t):
+            y = t.index_select(0, sel)
+            return y.reshape(nb, nf, *y.shape[1:]).permute(0, 2, 1, 3, 4).repeat(2, 1, 1, 1, 1)
+        return dict(down_block_additional_residuals=tuple(to5(t) for t in st.cn_down), mid_block_additional_residual=to5(st.cn_mid))
 
     def _unet_inputs(self, st, ci):
         dev = self.unet.device
@@ -209,7 +251,8 @@ class EMOAnimationPipeline:
         x, af = self._unet_inputs(st, ci)
         self._update_reader(st)
         rows = self.unet(x, st.t_buf, encoder_hidden_states=st.text[:x.shape[0]], audio_features=af,
-                         speed_embeddings=st.speed_embeddings, return_dict=False, _return_rows=True)   # :777-786
+                         speed_embeddings=st.speed_embeddings, return_dict=False, _return_rows=True,
+                         **self._controlnet_residuals(st, ci))                                # :777-786
         st.reader.clear()                                                                     # :788
         self._accumulate(st, ci, rows)
 
@@ -217,7 +260,7 @@ class EMOAnimationPipeline:
     # depend on the ReferenceNet, so it overlaps the write pass running on a second HIP stream
     def _part_unet_down(self, st, ci):
         x, af = self._unet_inputs(st, ci)
-        s = self.unet._begin(x, st.t_buf, st.text[:x.shape[0]], af, st.speed_embeddings)
+        s = self.unet._begin(x, st.t_buf, st.text[:x.shape[0]], af, st.speed_embeddings, **self._controlnet_residuals(st, ci))
         self.unet._run_down(s)
         st.unet_state[ci] = s
 
@@ -258,6 +301,8 @@ class EMOAnimationPipeline:
         st.t_buf.copy_(st.t_table[si:si + 1], non_blocking=True)     # device-to-device: the INT timestep of this step
         st.noise_pred.zero_()
         st.counter.zero_()
+        if st.controlnet is not None:   # per-frame residual cache of this step (:718-746), before any UNet part needs it
+            self._run(st, "controlnet", lambda: self._part_controlnet(st))
         overlap = st.overlap
         if overlap:
             # ReferenceNet write pass  ||  bank-independent Backbone down path.  All three parts go through the same
@@ -335,8 +380,17 @@ class EMOAnimationPipeline:
         assert num_videos_per_prompt == 1   # :641
         if isinstance(prompt, list) and len(prompt) != 1:
             raise AssertionError("batch_size == 1")  # :642
-        if self.controlnet is not None or controlnet_condition is not None:
-            raise NotImplementedError("ControlNet branch is SURVEY.md section 8(f) 'next' - not built yet")
+        cn_cond = None
+        if self.controlnet is not None:
+            if controlnet_condition is None:
+                raise ValueError("controlnet_condition (F,H,W,3 uint8 frames or a (F,3,H,W) float tensor) is required with a ControlNet")
+            # prepare_condition (:369-376): uint8 HWC frames / 255 -> (f, c, h, w)
+            cn_cond = controlnet_condition if torch.is_tensor(controlnet_condition) else torch.as_tensor(controlnet_condition)
+            if cn_cond.dim() == 4 and cn_cond.shape[-1] == 3 and cn_cond.shape[1] != 3:
+                cn_cond = cn_cond.permute(0, 3, 1, 2).float() / 255.0
+            cn_cond = cn_cond.float()
+        elif controlnet_condition is not None:
+            raise ValueError("controlnet_condition given but the pipeline has no controlnet")
         if appearance_encoder is None:
             raise ValueError("appearance_encoder (ReferenceNet) is required")
         text_embeddings = kwargs.get("text_embeddings")
@@ -372,7 +426,8 @@ class EMOAnimationPipeline:
                            audio_features=kwargs.get("audio_features"), speed_embeddings=kwargs.get("speed_embeddings"),
                            seed=kwargs.get("seed", 0), dist=kwargs.get("dist", False), rank=kwargs.get("rank", 0),
                            world_size=kwargs.get("world_size", 1), num_actual_inference_steps=num_actual_inference_steps,
-                           callback=callback, callback_steps=callback_steps)
+                           callback=callback, callback_steps=callback_steps, controlnet=self.controlnet, controlnet_cond=cn_cond,
+                           controlnet_conditioning_scale=controlnet_conditioning_scale)
         if self.vae is not None and output_type != "latent":
             video = self.vae.decode_video(lat)   # caller-supplied (:291-307)
         else:

@@ -19,7 +19,7 @@ def denoise_loop(unet_sd, unet_cfg, ref_sd, ref_cfg, latents, ref_latents, text_
                  scheduler: SchedulerRef, num_inference_steps=50, guidance_scale=7.5,
                  context_frames=16, context_stride=1, context_overlap=4, context_batch_size=1,
                  fusion_blocks="midup", seed=0, audio_features=None, speed_embeddings=None,
-                 rank=0, world_size=1, return_eps=False):
+                 rank=0, world_size=1, return_eps=False, controlnet=None):
     """latents (1,4,F_tot,h,w); ref_latents (1,4,h,w); text_embeddings (2,L,D) = [uncond, cond].
 
     Per step (EMOAnimationPipeline.py:698-823):
@@ -30,7 +30,10 @@ def denoise_loop(unet_sd, unet_cfg, ref_sd, ref_cfg, latents, ref_latents, text_
       eps = uc + s*(c - uc) on noise_pred/counter                                (:812-814)
       latents = scheduler.step(eps, t, latents)                                  (:817)
     rank/world_size shard windows exactly as `global_context[rank::world_size]` (:757); with
-    world_size>1 this function processes ALL ranks' windows in rank order (it is an oracle)."""
+    world_size>1 this function processes ALL ranks' windows in rank order (it is an oracle).
+    controlnet = dict(sd=, cfg=, cond=(F_tot,3,H,W), scale=): per step the ControlNet runs per frame on the (scaled) latents
+    with the cond text embedding, residuals are cached per frame (:718-746), then selected per window, reshaped
+    '(b f) c h w -> b c f h w' and repeated for CFG (:514-540) and added inside the UNet (unet_controlnet.py:430-447)."""
     timesteps = scheduler.set_timesteps(num_inference_steps)
     cbs = context_batch_size
     text = torch.cat([text_embeddings] * cbs) if cbs > 1 else text_embeddings  # (:631) [uc.., c..] per cat
@@ -45,6 +48,16 @@ def denoise_loop(unet_sd, unet_cfg, ref_sd, ref_cfg, latents, ref_latents, text_
         windows = uniform_windows(0, num_inference_steps, f_tot, context_frames, context_stride, context_overlap)
         nb = math.ceil(len(windows) / cbs)
         batches = [windows[i * cbs:(i + 1) * cbs] for i in range(nb)]
+        cn_cache = None
+        if controlnet is not None:
+            from .controlnet_ref import controlnet_forward
+            cn_cache = {}
+            for c in uniform_windows(0, num_inference_steps, f_tot, context_frames, context_stride, 0):   # overlap 0 (:723-725)
+                xin = scheduler.scale_model_input(latents[:, :, c], t)[0].permute(1, 0, 2, 3)              # (f, c, h, w)
+                dn, md = controlnet_forward(controlnet["sd"], controlnet["cfg"], xin, t, text_embeddings[1:].repeat(len(c), 1, 1),
+                                            controlnet["cond"][c], controlnet.get("scale", 1.0))
+                for j, k in enumerate(c):
+                    cn_cache[k] = ([d[j:j + 1] for d in dn], md[j:j + 1])
         for r in range(world_size):
             for context in batches[r::world_size]:
                 x = torch.cat([latents[:, :, c] for c in context]).repeat(2, 1, 1, 1, 1)
@@ -56,9 +69,20 @@ def denoise_loop(unet_sd, unet_cfg, ref_sd, ref_cfg, latents, ref_latents, text_
                 if audio_features is not None:  # (F_tot, L_a, D) per-frame ctx; uc rows get zeros
                     cond = torch.cat([audio_features[c] for c in context])
                     af = torch.cat([torch.zeros_like(cond), cond])
+                ckw = {}
+                if cn_cache is not None:   # select_controlnet_res_samples (:514-540)
+                    frames = [k for c in context for k in c]
+                    n_res = len(cn_cache[frames[0]][0])
+
+                    def to5(ts):
+                        y = torch.cat(ts)                                                     # ((b f), C, h, w), b = len(context)
+                        y = y.reshape(len(context), f, *y.shape[1:]).permute(0, 2, 1, 3, 4)    # b c f h w
+                        return y.repeat(2, 1, 1, 1, 1)
+                    ckw = dict(down_block_additional_residuals=[to5([cn_cache[k][0][i] for k in frames]) for i in range(n_res)],
+                               mid_block_additional_residual=to5([cn_cache[k][1] for k in frames]))
                 pred = unet_forward(unet_sd, unet_cfg, x, t, text[:b], bank_mode="read", banks=banks,
                                     uc_rows=uc_rows, fusion_blocks=fusion_blocks, audio_features=af,
-                                    speed_embeddings=speed_embeddings)
+                                    speed_embeddings=speed_embeddings, **ckw)
                 pred_uc, pred_c = pred.chunk(2)
                 pred = torch.stack([pred_uc, pred_c])
                 for j, c in enumerate(context):

@@ -16,6 +16,7 @@ DEV = "cuda"
 G = cases.GOLDEN_DIR
 CN_CFG = dict(cases.TINY, down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"))
 CN_PREFIX = "controlnet."   # seed salt
+_LOOP_CACHE = {}
 
 
 def build_controlnet(dtype):
@@ -98,3 +99,41 @@ def test_backbone_consumes_controlnet_residuals():
     y = unet(x2.to(DEV), 961, ctx.to(DEV), down_block_additional_residuals=tuple(to5(t) for t in out.down_block_res_samples),
              mid_block_additional_residual=to5(out.mid_block_res_sample)).sample
     torch.testing.assert_close(y.float().cpu(), ref, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_denoise_loop_with_controlnet_vs_oracle(graphs):
+    """The sampling loop with the ControlNet branch on (per-frame residual cache -> per-window selection -> Backbone,
+    EMOAnimationPipeline.py:514-540,718-746): HIP f32 (eager and HIP-graph replay) vs the oracle loop, 3 DDPM steps,
+    8 frames in overlapping windows of 4."""
+    from oracle.pipeline_ref import denoise_loop
+    from oracle.scheduler_ref import SchedulerRef
+    from emote_hack_amd import DDPMScheduler, UNet3DConditionModel
+    from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
+    from emote_hack_amd.pipeline import EMOAnimationPipeline
+    cn, cn_sd = build_controlnet(torch.float32)
+    usd = synth_state_dict(param_shapes(build_spec(cases.TINY_MOTION)))
+    rsd = synth_state_dict(param_shapes(build_spec(cases.TINY, has_out=False)), prefix=cases.REF_PREFIX)
+    unet = UNet3DConditionModel(**cases.TINY_MOTION)
+    unet.load_state_dict(usd)
+    unet.to(DEV, torch.float32)
+    ref = AppearanceEncoderModel(**cases.TINY)
+    ref.load_state_dict(rsd)
+    ref.to(DEV, torch.float32)
+    lat, refl, text = seeded_randn((1, 4, 8, 16, 16), 5), seeded_randn((1, 4, 16, 16), 3), seeded_randn((2, 5, 32), 2)
+    cond = seeded_randn((8, 3, 128, 128), 77).clamp(-1, 1) * 0.5 + 0.5
+    if "want" not in _LOOP_CACHE:   # the CPU oracle loop is the slow part: once for both parametrisations
+        _LOOP_CACHE["want"] = denoise_loop(usd, cases.TINY_MOTION, rsd, cases.TINY, lat, refl, text, scheduler=SchedulerRef("ddpm"),
+                                           num_inference_steps=3, guidance_scale=7.5, context_frames=4, context_stride=1,
+                                           context_overlap=2, seed=0, controlnet=dict(sd=cn_sd, cfg=CN_CFG, cond=cond, scale=0.9))
+        _LOOP_CACHE["base"] = denoise_loop(usd, cases.TINY_MOTION, rsd, cases.TINY, lat, refl, text, scheduler=SchedulerRef("ddpm"),
+                                           num_inference_steps=3, guidance_scale=7.5, context_frames=4, context_stride=1,
+                                           context_overlap=2, seed=0)
+    want = _LOOP_CACHE["want"]
+    pipe = EMOAnimationPipeline(unet=unet, controlnet=cn, scheduler=DDPMScheduler())
+    got = pipe.denoise(lat.to(DEV), refl, text, appearance_encoder=ref, num_inference_steps=3, guidance_scale=7.5, context_frames=4,
+                       context_stride=1, context_overlap=2, seed=0, use_graphs=graphs, controlnet=cn, controlnet_cond=cond,
+                       controlnet_conditioning_scale=0.9)
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-3, atol=2e-4)
+    # and the branch matters: without it the latents differ
+    assert float((_LOOP_CACHE["base"] - want).abs().max()) > 1e-2
