@@ -1,1103 +1,19 @@
-// gemm.hip - MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950 (wave64, 32x32 MFMA tiles).
-//
-//   C[M,N] = epilogue( A[M,K] . W[N,K]^T )        A: NHWC activation rows, W: torch Linear layout
-//
-// One kernel template serves every GEMM-shaped op on the hot path: Linear q/k/v/out/FF
-// (orig_attention.py:566-575,776,817), 1x1 conv proj_in/out + shortcuts (attention.py:82,110;
-// resnet.py:175) and - with the conv A-loader - the per-frame 3x3 convs (resnet.py:30-38), stride 2
-// (resnet.py:98) and nearest-x2-upsample-folded (resnet.py:74-82: the interpolate is folded into the
-// load indexing, the upsampled tensor never exists).
-//
-// Structure (v6):
-//   * PERSISTENT blocks: a launch has as many blocks as the chip holds at once (by LDS, <= 4 per CU; a multiple of 8),
-//     block b walks tiles b, b+G, ... of an XCD-aware order (block b runs on XCD b%8; each XCD owns a contiguous run of
-//     tiles, n fastest, so the A rows it re-reads stay in that XCD's L2).
-//   * a wave owns WTM x WTN MFMA 32x32 tiles: 2x4 = 8 waves of 128x64 (256x256, the big compute-bound shapes), 2x2 waves
-//     of 64x64 (128x128), 4x1 waves of 32x160 (128x160: every channel count of the SD-1.5 UNet is a multiple of 160),
-//     2x2 waves of 32x32 (64x64: few-block short-K shapes and V^T outputs, 4 co-resident blocks per CU).
-//   * K is streamed in 128-BYTE stages (bf16: 64, f32: 32 k-values; one full L2 line per row per stage) through a
-//     2-deep LDS ring filled by ASYNCHRONOUS direct-to-LDS loads (global_load_lds_dwordx4, no VGPR round trip).  The
-//     loader state is a stream of (tile, stage) pairs that runs one stage AHEAD of the MFMA loop and does not stop at tile
-//     boundaries: a tile's epilogue runs with the next tile's first stage in flight.  The whole next stage is requested
-//     right behind the per-stage s_barrier (it then has the full MFMA time of this stage to land).
-//   * software-pipelined stage: after the barrier only the first k-step's fragment read is exposed; the reads of
-//     step kk+1 are issued one at a time BETWEEN the MFMAs of step kk (compile-time `static_for` so every register-array
-//     index is a constant: a runtime index sends the arrays to scratch and breaks the asm-read/wait protocol).
-//   * the LDS image of a stage is lane-linear (a glds writes wave-base + lane*16), so the 16-byte chunk position is
-//     XOR-swizzled with (row / rows-per-bank-row) on the SOURCE address and on the fragment read: the ds_read_b128 of
-//     a 16-lane group then hits 16 distinct 16-byte slots (conflict-free, SQ_LDS_BANK_CONFLICT = 0 measured).  One
-//     swizzle key per lane serves every glds; the k-step fragment addresses are the step-0 address XOR (kk << 5).
-//   * fragment reads are inline-asm ds_read_b128 with hand-counted lgkmcnt: hipcc drains vmcnt(0) in front of
-//     every C++-level LDS read while a glds is in flight, which would serialise the ring.
-//   * dense operands: rows past M / N are clamped to the last valid row (never stored), so every source pointer steps
-//     by one constant per stage; K tails and the conv loader's zero padding source a 16-byte zero page.
-//   * the MFMA is issued with the operands SWAPPED (acc = W_frag x A_frag), so a lane ends up with 4 consecutive
-//     output COLUMNS of one row per register quad.  V^T store (TRANS): operands unswapped, a lane holds 4 consecutive
-//     ROWS of one column.
-//   * EPILOGUE (what bounds the short-K shapes): accumulators start at the bias; bf16 row-major outputs are staged
-//     through the ring slot the main loop has just released and written back as full 128-byte lines, 16 bytes per lane,
-//     with equally coalesced residual loads issued ahead of the staging phase (epilogue_lds); everything else (f32,
-//     ragged N, split-K partials, V^T) uses the row-per-lane / column-per-lane paths.
-//   bf16: v_mfma_f32_32x32x16_bf16, f32 accumulate.   f32: v_mfma_f32_32x32x2_f32 (exact f32 fma chain).
-// Epilogue fused: bias, per-batch row bias (temb), GEGLU, residual, scale, row-major or V^T store.
-// Split-K (small M): f32 partial slabs + a fixed-order reduce/epilogue kernel (deterministic).
-// conv3x3_halo_kernel (below): the stride-1 3x3 convs with input-halo reuse instead of the im2col loader.
-// EMO_ABL_* / EMO_FORCE_* / EMO_LATE_ISSUE macros and the EMO_GEMM_* environment knobs are measurement hooks (ablations and
-// tile-choice overrides quoted in DESIGN.md 7), not product configuration.
-#include <stdlib.h>
-#include "common.h"
+// gemm.hip - C ABI entry points of the GEMM / 3x3 conv family: argument checks, tile / split-K planning, dtype dispatch.
+// The kernels live in gemm_impl.h and are instantiated per element type in gemm_f32.hip / gemm_bf16.hip / gemm_f16.hip.
+#include "gemm_api.h"
 
-#ifndef EMO_GEMM_KBYTES
-#define EMO_GEMM_KBYTES 128
-#endif
-static constexpr int KBYTES = EMO_GEMM_KBYTES;   // bytes of K per ring stage and per LDS row (128 = one full L2 line per row)
-static constexpr int CPR = KBYTES / 16;          // 16-byte chunks per LDS row
-static constexpr int KSTEPS = KBYTES / 32;       // mma16 steps per stage (a step consumes 2 chunks: one per lane half)
-static constexpr int RPB = 256 / KBYTES;         // LDS rows per 256-byte bank row
-// XOR swizzle of the chunk position: rows that share a 256-B bank row get the same key, consecutive bank rows
-// different keys -> the 16 lanes of a ds_read_b128 group (rows {0-3,12-15,20-27} / {4-11,16-19,28-31}) hit 16
-// distinct 16-byte slots
-__device__ __forceinline__ int swz(int row) { return (row / RPB) & (CPR - 1); }
-
-__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0, 0, 0, 0};
-__device__ int g_gemm_lds_epi = 1;   // experiment switch (EMO_GEMM_LDS_EPI=0): 0 = row-per-lane epilogue everywhere
-
-template <int WTM, int WTN, int WVM, int WVN, int NS_> struct GemmTile {
-  static constexpr int NS = NS_;   // LDS ring depth
-  static constexpr int NW = WVM * WVN, THREADS = 64 * NW;
-  static constexpr int BM = 32 * WTM * WVM, BN = 32 * WTN * WVN;
-  static constexpr int RPI = 64 * NW / CPR;   // LDS rows filled by one glds "round" of the whole block
-  static constexpr int A_ROWS = (BM + RPI - 1) / RPI * RPI, B_ROWS = (BN + RPI - 1) / RPI * RPI;
-  static constexpr int A_BYTES = A_ROWS * KBYTES, B_BYTES = B_ROWS * KBYTES;
-  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-  static constexpr int LDS_BYTES = NS * STAGE_BYTES;
-  static constexpr int LA = A_ROWS / RPI, LB = B_ROWS / RPI, LPS = LA + LB;   // glds per wave per stage
-  // co-resident blocks per CU the launch is sized for (by LDS, <= 4) and the waves per SIMD that needs: the register
-  // budget handed to the compiler (the persistent loop keeps the loader state live across the epilogue)
-  static constexpr int BPC = (160 * 1024 / LDS_BYTES) > 4 ? 4 : ((160 * 1024 / LDS_BYTES) < 1 ? 1 : (160 * 1024 / LDS_BYTES));
-  static constexpr int WPE = (BPC * NW + 3) / 4;
-};
-
-#define EMO_GLDS16(gptr, lptr) \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ uint4 lds_read16(unsigned addr) {
-  uint4 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
-  return v;
-}
-
-// Row-major fused epilogue of one 32-row MFMA tile row (lane <-> output row m; register quad g of tile j <-> columns
-// j*32 + 8*g + 4*half + {0..3}): bias, per-batch row bias, GEGLU, residual, scale, 8-byte (bf16) / 16-byte (f32) stores.
-template <typename T, int WTN>
-__device__ __forceinline__ void epilogue_row(const f32x16 (&acc)[WTN], const emo_gemm_params& p, int64_t m, bool m_ok, int wn0, int half,
-                                             T* __restrict__ C, const T* __restrict__ R) {
-  const float* rbias = (p.rowbias && m_ok) ? p.rowbias + (m / p.rows_per_batch) * p.ld_rowbias : nullptr;
-  const int n_out = p.geglu ? p.N / 2 : p.N;
-  const bool vec_ok = (p.N & 3) == 0 && ((p.ldc | (R ? p.ldr : 0)) & 3) == 0 && (!p.rowbias || (p.ld_rowbias & 3) == 0);
-#pragma unroll
-  for (int j = 0; j < WTN; j++) {
-    if (p.geglu && (j & 1)) continue;   // gate tile is consumed with its value tile
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const int nw0 = wn0 + j * 32 + 8 * g + 4 * half;              // column in W-row space
-      const int no0 = p.geglu ? ((wn0 + j * 32) >> 1) + 8 * g + 4 * half : nw0;   // output column
-      if (nw0 >= p.N) continue;
-      float o[4] = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
-      if (vec_ok) {   // the whole quad is in range (N % 4 == 0)
-        if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
-        if (rbias) { const float4 b4 = *(const float4*)(rbias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
-        if (p.geglu) {
-          float gt[4] = {acc[(j + 1) % WTN][4 * g], acc[(j + 1) % WTN][4 * g + 1], acc[(j + 1) % WTN][4 * g + 2],
-                         acc[(j + 1) % WTN][4 * g + 3]};
-          if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0 + 32); gt[0] += b4.x; gt[1] += b4.y; gt[2] += b4.z; gt[3] += b4.w; }
-          if constexpr (sizeof(T) == 2) {
-            float g0, g1, g2, g3;
-            gelu_erf_poly2(gt[0], gt[1], g0, g1);
-            gelu_erf_poly2(gt[2], gt[3], g2, g3);
-            o[0] *= g0; o[1] *= g1; o[2] *= g2; o[3] *= g3;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; e++) o[e] *= gelu_for<T>(gt[e]);
-          }
-        }
-        if (!m_ok) continue;
-        if (R) {
-          if constexpr (sizeof(T) == 2) {
-            float r4[4];
-            unpack4<T>(*(const uint2*)(R + m * p.ldr + no0), r4);
-            o[0] += r4[0]; o[1] += r4[1]; o[2] += r4[2]; o[3] += r4[3];
-          } else {
-            const float4 rv = *(const float4*)(R + m * p.ldr + no0);
-            o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; e++) o[e] *= p.out_scale;
-#ifdef EMO_ABL_NOSTORE
-        if (o[0] == 123.456f)
-#endif
-        {
-        if constexpr (sizeof(T) == 2) *(uint2*)(C + m * p.ldc + no0) = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
-        else *(float4*)(C + m * p.ldc + no0) = make_float4(o[0], o[1], o[2], o[3]);
-        }
-      } else {   // ragged N / unaligned leading dims: scalar path
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const int nw = nw0 + e;
-          if (nw >= p.N || !m_ok) continue;
-          float v = o[e];
-          if (p.bias) v += p.bias[nw];
-          if (rbias) v += rbias[nw];
-          if (p.geglu) {
-            float gt = acc[(j + 1) % WTN][4 * g + e];
-            if (p.bias) gt += p.bias[nw + 32];
-            v *= gelu_for<T>(gt);
-          }
-          if (no0 + e < n_out) {
-            if (R) v += TT<T>::ld(R + m * p.ldr + no0 + e);
-            TT<T>::st(C + m * p.ldc + no0 + e, v * p.out_scale);
-          }
-        }
-      }
-    }
-  }
-}
-
-// bf16 epilogue through LDS: the row-per-lane stores of epilogue_row touch 64 different 128-byte lines with 8 bytes each per
-// wave instruction (and so do its residual loads) - on the memory-bound short-K shapes the epilogue then runs at the L2
-// REQUEST rate, ~3 TB/s.  Here a wave stages its 32-row tile rows (bias / temb / GEGLU applied, rounded to bf16 like the
-// reference's Linear output) in a private region of the ring slot the main loop has just released, reads them back
-// row-major - 16 bytes per lane, consecutive lanes along the row - adds the residual from an equally coalesced 16-byte
-// load and stores full lines.  LDS ops are inline asm with counted lgkmcnt (a C++ LDS access would make hipcc drain the
-// next tile's prefetched stage first).
-__device__ __forceinline__ void lds_write8(unsigned addr, unsigned lo, unsigned hi) {
-  const unsigned long long v = ((unsigned long long)hi << 32) | lo;
-  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-// m_of(i, row) -> global output row of row `row` (0..31) of this wave's MFMA tile row i, or -1 if it does not exist
-template <typename T, int WTM, int WTN, int NW, int XBYTES, bool GEGLU, typename MF>
-__device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], const emo_gemm_params& p, MF m_of, int wn0, int wave, int lane,
-                                             unsigned xbase, T* __restrict__ C, const T* __restrict__ R) {
-  static_assert(sizeof(T) == 2, "the staged epilogue is for the 2-byte element types");
-  constexpr int OTW = GEGLU ? WTN / 2 : WTN;                  // 32-column output tiles per wave row
-  constexpr int JMAX = (XBYTES / (NW * 32) - 16) / 64;        // tiles per pass that fit this wave's share of the slot
-  constexpr int JG = JMAX < OTW ? JMAX : OTW;
-  static_assert(JG >= 1, "transpose slot too small");
-  constexpr int PITCH = JG * 64 + 16;                          // bytes per staged row (+16: rows on different banks)
-  const int half = lane >> 5, l31 = lane & 31;
-  const unsigned xw = xbase + wave * (32 * PITCH);
-  const int n_out = GEGLU ? p.N / 2 : p.N;
-  const int oc0 = GEGLU ? (wn0 >> 1) : wn0;                    // first output column of this wave
-  const bool plain = R == nullptr && p.out_scale == 1.0f;
-#pragma unroll
-  for (int i = 0; i < WTM; i++) {
-    const int64_t m_lane = m_of(i, l31);
-    const float* rbias = (p.rowbias && m_lane >= 0) ? p.rowbias + (m_lane / p.rows_per_batch) * p.ld_rowbias : nullptr;
-#pragma unroll
-    for (int ot0 = 0; ot0 < OTW; ot0 += JG) {
-      constexpr int dummy = 0; (void)dummy;
-      constexpr int NIT = 2 * JG;                              // 16-byte chunks per lane per pass: 32 rows * 4*nt chunks / 64 lanes
-      const int nt = (OTW - ot0) < JG ? (OTW - ot0) : JG;     // tiles in this pass (compile-time after unrolling)
-      const int cw = nt * 4;                                   // 16-byte chunks per staged row
-      // ---- residual loads of the whole pass first (coalesced 16-byte chunks; chunk idx -> (row, c)): their latency hides
-      // under phase 1
-      uint4 rv[NIT];
-#pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        rv[it] = make_uint4(0, 0, 0, 0);
-        const int idx = it * 64 + lane;
-        const int row = idx / cw, c = idx - row * cw;
-        const int64_t m = it < 2 * nt ? m_of(i, row) : -1;
-        const int col = oc0 + ot0 * 32 + c * 8;
-        if (R && m >= 0 && col < n_out) rv[it] = *(const uint4*)(R + m * p.ldr + col);
-      }
-      // ---- phase 1: lane <-> row, quads of 4 columns -> LDS
-#pragma unroll
-      for (int t = 0; t < JG; t++) {
-        if (ot0 + t >= OTW) break;
-        const int jv = GEGLU ? 2 * (ot0 + t) : (ot0 + t);
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const int nw0 = wn0 + jv * 32 + 8 * g + 4 * half;    // column in W-row space
-          float o[4] = {acc[i][jv][4 * g], acc[i][jv][4 * g + 1], acc[i][jv][4 * g + 2], acc[i][jv][4 * g + 3]};
-          if (nw0 < p.N) {
-            if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
-            if (rbias) { const float4 b4 = *(const float4*)(rbias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
-            if constexpr (GEGLU) {
-              float gt[4] = {acc[i][jv + 1][4 * g], acc[i][jv + 1][4 * g + 1], acc[i][jv + 1][4 * g + 2], acc[i][jv + 1][4 * g + 3]};
-              if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0 + 32); gt[0] += b4.x; gt[1] += b4.y; gt[2] += b4.z; gt[3] += b4.w; }
-              float g0, g1, g2, g3;
-              gelu_erf_poly2(gt[0], gt[1], g0, g1);
-              gelu_erf_poly2(gt[2], gt[3], g2, g3);
-              o[0] *= g0; o[1] *= g1; o[2] *= g2; o[3] *= g3;
-            }
-          }
-          lds_write8(xw + l31 * PITCH + t * 64 + (8 * g + 4 * half) * 2, pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
-        }
-      }
-      wait_lgkmcnt<0>();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- phase 2: read back row-major, add the residual, store full lines
-      uint4 xv[NIT];
-#pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        const int idx = it * 64 + lane;
-        const int row = idx / cw, c = idx - row * cw;
-        if (it < 2 * nt) xv[it] = lds_read16(xw + row * PITCH + c * 16);
-      }
-      wait_lgkmcnt<0>();
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        const int idx = it * 64 + lane;
-        const int row = idx / cw, c = idx - row * cw;
-        const int64_t m = it < 2 * nt ? m_of(i, row) : -1;
-        const int col = oc0 + ot0 * 32 + c * 8;
-        if (m >= 0 && col < n_out) {
-          if (plain) {   // no residual, no scale: the staged bf16 chunk is the result
-            *(uint4*)(C + m * p.ldc + col) = xv[it];
-          } else {
-            float x[8], r[8];
-            unpack16<T>(xv[it], x);
-            unpack16<T>(rv[it], r);
-#pragma unroll
-            for (int e = 0; e < 8; e++) x[e] = (x[e] + r[e]) * p.out_scale;
-            *(uint4*)(C + m * p.ldc + col) = pack16<T>(x);
-          }
-        }
-      }
-      wait_lgkmcnt<0>();   // (all reads retired before the next pass overwrites the region)
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-}
-
-// Accumulators start at the bias (row-major layout: register quad g of tile j <-> columns j*32 + 8*g + 4*half + {0..3}):
-// the epilogue then has no bias loads (an L2 round trip per pass with only 2-4 waves per SIMD to hide it) or adds.
-template <int WTM, int WTN>
-__device__ __forceinline__ void init_acc_bias(f32x16 (&acc)[WTM][WTN], const float* __restrict__ bias, int wn0, int half, int N) {
-#pragma unroll
-  for (int j = 0; j < WTN; j++)
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const int n0 = wn0 + j * 32 + 8 * g + 4 * half;
-      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (bias && n0 < N) b4 = *(const float4*)(bias + n0);   // N % 4 == 0 checked by the caller
-#pragma unroll
-      for (int i = 0; i < WTM; i++) { acc[i][j][4 * g] = b4.x; acc[i][j][4 * g + 1] = b4.y; acc[i][j][4 * g + 2] = b4.z; acc[i][j][4 * g + 3] = b4.w; }
-    }
-}
-
-struct ConvRow { int img, iy0, ix0; };
-
-template <typename T, bool CONV, bool TRANS, int WTM, int WTN, int WVM, int WVN, int NS>
-__global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::WPE)) void gemm_kernel(const emo_gemm_params p) {
-  using Tile = GemmTile<WTM, WTN, WVM, WVN, NS>;
-  constexpr int NW = Tile::NW;
-  constexpr int V = TT<T>::VEC;          // elements per 16 B
-  constexpr int BK = KBYTES / (int)sizeof(T);
-  constexpr int BM = Tile::BM, BN = Tile::BN, LA = Tile::LA, LB = Tile::LB, LPS = Tile::LPS;
-  extern __shared__ __attribute__((aligned(128))) unsigned char lds[];   // 128: the XOR k-step addressing below
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wvm = wave / WVN, wvn = wave % WVN;
-  const int half = lane >> 5, l31 = lane & 31;
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int tiles_m = (int)((p.M + BM - 1) / BM);
-  const int tiles_all = tiles_m * tiles_n;
-  const int G = gridDim.x;                     // persistent: block b works tiles b, b+G, b+2G, ... of the XCD-aware order
-  // XCD-aware tile order (bijective): stream index i runs on XCD i % 8 (G is a multiple of 8 whenever a block has more
-  // than one tile); XCD x owns a contiguous run of tiles (n fastest), so the A rows it re-reads stay in that XCD's L2
-  auto tile_of = [&](int i) {
-    const int qn = tiles_all >> 3, rn = tiles_all & 7, x = i & 7, idx = i >> 3;
-    return (x < rn ? x * (qn + 1) : rn * (qn + 1) + (x - rn) * qn) + idx;
-  };
-  const int nsplit = p.split_k > 1 ? p.split_k : 1;
-
-  const T* __restrict__ A = (const T*)p.A;
-  const T* __restrict__ W = (const T*)p.W;
-  const T* zero = (const T*)g_zero_page;
-
-  const int nk_all = (p.K + BK - 1) / BK;
-  const int nk_per = (nk_all + nsplit - 1) / nsplit;
-  const int kt0 = blockIdx.y * nk_per;
-  const int nk = (kt0 + nk_per <= nk_all ? nk_per : nk_all - kt0);   // may be <= 0 for a trailing empty slice
-
-  // ---- loader state.  The loader streams (tile, k-stage) pairs NS-1 stages AHEAD of the MFMA loop and does not stop at
-  // tile boundaries: while a tile's epilogue runs, the first stages of the block's next tile are already in flight.
-  // glds #i of this wave fills LDS rows (i*NW + wave)*(64/CPR) .. of the operand; lane l writes physical chunk l%CPR of
-  // row l/CPR, which holds LOGICAL chunk (l%CPR) ^ swz(row)
-  const int lrow = lane / CPR, lchunk = lane % CPR;
-  // the swizzle key of row (i*NW + wave)*(64/CPR) + lrow does not depend on the round i (NW*(64/CPR)/RPB is a multiple of
-  // CPR): one logical chunk index per lane serves every glds of A and B
-  static_assert((NW * (64 / CPR) / RPB) % CPR == 0, "swizzle key must be round-independent");
-  const int klog = lchunk ^ swz(wave * (64 / CPR) + lrow);
-  ConvRow a_cr[LA];
-  bool a_ok[LA];          // conv loader only
-  // Dense operands: rows past M / N are CLAMPED to the last valid row (their products land in accumulator rows / columns
-  // that are never stored), so every pointer advances by the same BK per stage - no per-row increments or validity flags.
-  const T* a_ptr[LA];
-  const T* b_ptr[LB];
-  int l_iter = blockIdx.x, l_kt = 0;   // the loader's tile (stream index) and next stage within the slice
-  auto setup_loader = [&](int iter) {
-    const int tile = tile_of(iter);
-    const int64_t lbm = (int64_t)(tile / tiles_n) * BM;
-    const int lbn = (tile % tiles_n) * BN;
-#pragma unroll
-    for (int i = 0; i < LA; i++) {
-      const int row = (i * NW + wave) * (64 / CPR) + lrow;
-      const int64_t m = lbm + row;
-      a_ok[i] = row < BM && m < p.M;
-      if (CONV) {
-        const int hw = p.Ho * p.Wo;
-        const int64_t mm = a_ok[i] ? m : 0;
-        const int img = (int)(mm / hw), rem = (int)(mm % hw);
-        const int oy = rem / p.Wo, ox = rem % p.Wo;
-        a_cr[i].img = img; a_cr[i].iy0 = oy * p.stride - 1; a_cr[i].ix0 = ox * p.stride - 1;
-      } else {
-        const int64_t mc = m < p.M ? m : p.M - 1;
-        a_ptr[i] = A + mc * p.lda + klog * V + (int64_t)kt0 * BK;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < LB; i++) {
-      const int row = (i * NW + wave) * (64 / CPR) + lrow;
-      const int n = lbn + row < p.N ? lbn + row : p.N - 1;
-      b_ptr[i] = W + (int64_t)n * p.K + klog * V + (int64_t)kt0 * BK;
-    }
-  };
-  const bool k_ragged = (p.K % BK) != 0;            // only the very last stage can run past K
-  const bool cin_aligned = CONV && (p.Cin % BK) == 0; // a stage then lies inside one 3x3 tap (tap is wave-uniform)
-
-  // one glds of operand A (index i < LA) / B (i < LB) of k-stage kt (absolute) into ring slot `slot`
-  auto issue_a = [&](int kt, int slot, auto I) {
-    constexpr int i = decltype(I)::value;
-    unsigned char* sa = lds + slot * Tile::STAGE_BYTES;
-    const bool tail = k_ragged && (kt + 1) * BK > p.K;
-    if constexpr (!CONV) {
-      const T* src = a_ptr[i];
-      if (tail && kt * BK + klog * V >= p.K) src = zero;
-      EMO_GLDS16(src, sa + (i * NW + wave) * 1024);
-      a_ptr[i] += BK;
-    } else {
-      const int Hin = p.upsample2x ? 2 * p.H : p.H, Win = p.upsample2x ? 2 * p.W_ : p.W_;
-      const int k0 = kt * BK + klog * V;
-      int tap, ci;
-      if (cin_aligned) { tap = (kt * BK) / p.Cin; ci = kt * BK - tap * p.Cin + klog * V; }   // tap is wave-uniform (SALU)
-      else { tap = k0 / p.Cin; ci = k0 - tap * p.Cin; }
-      const int ky = tap / 3, kx = tap - ky * 3;
-      int iy = a_cr[i].iy0 + ky, ix = a_cr[i].ix0 + kx;
-      const T* src = zero;
-      if (a_ok[i] && k0 < p.K && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
-        if (p.upsample2x) { iy >>= 1; ix >>= 1; }
-        src = A + (((int64_t)a_cr[i].img * p.H + iy) * p.W_ + ix) * p.lda + ci;
-      }
-      EMO_GLDS16(src, sa + (i * NW + wave) * 1024);
-    }
-  };
-  auto issue_b = [&](int kt, int slot, auto I) {
-    constexpr int i = decltype(I)::value;
-    unsigned char* sb = lds + slot * Tile::STAGE_BYTES + Tile::A_BYTES;
-    const bool tail = k_ragged && (kt + 1) * BK > p.K;
-    const T* src = b_ptr[i];
-    if (tail && kt * BK + klog * V >= p.K) src = zero;
-    EMO_GLDS16(src, sb + (i * NW + wave) * 1024);
-    b_ptr[i] += BK;
-  };
-  // after the last glds of a stage: step the loader to the next stage of the stream (next tile when this one is done)
-  auto advance_loader = [&]() {
-    if (++l_kt >= nk) {
-      l_kt = 0;
-      l_iter += G;
-      if (l_iter < tiles_all) setup_loader(l_iter);
-    }
-  };
-
-  // fragment read addresses (LDS byte offsets, stage-relative), swizzled
-  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-  // k-step kk reads chunk (kk*2 + half) ^ swz(r) = ((half ^ swz(r)) ^ (kk << 1)): with 128-byte aligned stages the address
-  // of step kk is the step-0 address XOR (kk << 5) - one register per fragment row instead of KSTEPS
-  static_assert(KSTEPS * 32 <= KBYTES && (Tile::STAGE_BYTES % 128) == 0 && (Tile::A_BYTES % 128) == 0, "XOR k-step addressing");
-  unsigned fa0[WTM], fb0[WTN];
-#pragma unroll
-  for (int i = 0; i < WTM; i++) {
-    const int r = wvm * 32 * WTM + i * 32 + l31;
-    fa0[i] = lds_base + r * KBYTES + ((half ^ swz(r)) * 16);
-  }
-#pragma unroll
-  for (int j = 0; j < WTN; j++) {
-    const int r = wvn * 32 * WTN + j * 32 + l31;
-    fb0[j] = lds_base + Tile::A_BYTES + r * KBYTES + ((half ^ swz(r)) * 16);
-  }
-
-  T* __restrict__ C = (T*)p.C;
-  const T* __restrict__ R = (const T*)p.residual;
-  // row-major single-pass outputs start their accumulators at the bias; the epilogues then see bias == nullptr
-  const bool bias_in_acc = !TRANS && nsplit == 1 && p.bias != nullptr && (p.N & 3) == 0;
-  emo_gemm_params pe = p;
-  if (bias_in_acc) pe.bias = nullptr;
-  // coalesced LDS-staged epilogue (bf16, row-major, single pass): needs whole 16-byte chunks everywhere
-  const int n_out_all = p.geglu ? p.N / 2 : p.N;
-  const bool use_lds_epi = !TRANS && sizeof(T) == 2 && nsplit == 1 && nk > 0 && g_gemm_lds_epi && (n_out_all & 7) == 0 && (p.N & 3) == 0 &&
-                           (p.ldc & 7) == 0 && (!R || (p.ldr & 7) == 0) && (!p.rowbias || (p.ld_rowbias & 3) == 0) &&
-                           (!p.geglu || (WTN % 2 == 0));
-
-  // stream prologue: NS-1 stages in flight
-  int gs = 0;   // stream stage counter of the MFMA loop (ring slot = gs % NS)
-  if (nk > 0) {
-    setup_loader(l_iter);
-#pragma unroll
-    for (int s = 0; s < NS - 1; s++)
-      if (l_iter < tiles_all) {
-        static_for<LA>([&](auto I) { issue_a(kt0 + l_kt, s, I); });
-        static_for<LB>([&](auto I) { issue_b(kt0 + l_kt, s, I); });
-        advance_loader();
-      }
-  }
-
-  for (int c_iter = blockIdx.x; c_iter < tiles_all; c_iter += G) {
-  const int c_tile = tile_of(c_iter);
-  const int64_t bm = (int64_t)(c_tile / tiles_n) * BM;
-  const int bn = (c_tile % tiles_n) * BN;
-  const int tiles_left = (tiles_all - 1 - c_iter) / G;   // tiles of this block after this one
-
-  f32x16 acc[WTM][WTN];
-  if (bias_in_acc) {
-    init_acc_bias<WTM, WTN>(acc, p.bias, bn + wvn * 32 * WTN, half, p.N);
-  } else {
-#pragma unroll
-    for (int i = 0; i < WTM; i++)
-#pragma unroll
-      for (int j = 0; j < WTN; j++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-  }
-
-  for (int kt = 0; kt < nk; kt++, gs++) {
-    // stage gs must have landed; up to NS-2 younger stages may still be in flight - fewer at the end of the stream, and none
-    // are counted on at a tile's first stage: the previous tile's epilogue stores sit in the same counter
-    const int rem = nk - 1 - kt + tiles_left * nk;   // younger stages of this block's stream still to come
-    if (rem >= NS - 2 && (kt > 0 || c_iter == (int)blockIdx.x)) wait_vmcnt<(NS - 2) * LPS>();
-    else if (NS > 3 && rem >= 1 && kt > 0) {   // draining: rem younger stages in flight
-      if (rem == 1) wait_vmcnt<LPS>();
-      else if (NS > 4 && rem == 2) wait_vmcnt<2 * LPS>();
-      else if (NS > 5 && rem == 3) wait_vmcnt<3 * LPS>();
-      else if (NS > 6 && rem == 4) wait_vmcnt<4 * LPS>();
-      else if (NS > 7 && rem == 5) wait_vmcnt<5 * LPS>();
-      else wait_vmcnt<0>();
-    }
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();   // everyone's part of stage gs landed; everyone finished reading slot (gs-1)%NS
-    const unsigned st = (gs % NS) * Tile::STAGE_BYTES;   // stage offset (fa0 / fb0 carry the LDS base)
-    const bool more = l_iter < tiles_all;
-    const int kt_next = kt0 + l_kt, slot_next = (gs + NS - 1) % NS;
-    // Software-pipelined stage: the only exposed latency is the first k-step's fragment read.  The fragment reads
-    // of step kk+1 and the next ring stage's glds (with their address arithmetic) are issued one at a time BETWEEN the
-    // MFMAs of step kk, so their issue cost and latency hide under the matrix pipe.
-    uint4 fa[2][WTM], fb[2][WTN];
-#pragma unroll
-    for (int i = 0; i < WTM; i++) fa[0][i] = lds_read16(st + fa0[i]);
-#pragma unroll
-    for (int j = 0; j < WTN; j++) fb[0][j] = lds_read16(st + fb0[j]);
-    constexpr int NMMA = WTM * WTN, NRD = WTM + WTN;
-#ifndef EMO_LATE_ISSUE
-    // the whole next ring stage is requested right behind the barrier: it then has this stage's full MFMA time to land
-    // (spreading the glds between the MFMAs left the last ones ~no time: +10-20 % on the K >= 2560 shapes, 8192^3 980 -> 1130 TF/s)
-    if (more) {
-      static_for<LA>([&](auto I) { issue_a(kt_next, slot_next, I); });
-      static_for<LB>([&](auto I) { issue_b(kt_next, slot_next, I); });
-    }
-#endif
-    static_for<KSTEPS>([&](auto KK) {
-      constexpr int kk = decltype(KK)::value, cur = kk & 1, nxt = cur ^ 1;
-      wait_lgkmcnt<0>();                       // fragments of step kk
-      __builtin_amdgcn_sched_barrier(0);
-      // side ops of this cluster: the next step's fragment reads, then this cluster's share of the glds
-      constexpr int n_rd = (kk + 1 < KSTEPS) ? NRD : 0;
-      constexpr int g_begin = kk * LPS / KSTEPS, g_end = (kk + 1) * LPS / KSTEPS;
-      constexpr int n_side = n_rd + (g_end - g_begin);
-      static_for<NMMA>([&](auto Q) {
-        constexpr int q = decltype(Q)::value, i = q / WTN, j = q % WTN;
-#ifndef EMO_ABL_NOMMA
-        if constexpr (TRANS) acc[i][j] = mma16<T>(fa[cur][i], fb[cur][j], acc[i][j]);   // rows = m, lane = n
-        else acc[i][j] = mma16<T>(fb[cur][j], fa[cur][i], acc[i][j]);                   // rows = n, lane = m
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<n_side>([&](auto O) {
-          constexpr int o = decltype(O)::value;
-          if constexpr ((o * NMMA) / n_side == q) {
-            if constexpr (o < n_rd) {
-#ifndef EMO_ABL_NOREAD
-              if constexpr (o < WTM) fa[nxt][o] = lds_read16((st + fa0[o]) ^ (((kk + 1) % KSTEPS) << 5));
-              else fb[nxt][o - WTM] = lds_read16((st + fb0[o - WTM]) ^ (((kk + 1) % KSTEPS) << 5));
-#endif
-            } else {
-              constexpr int g = g_begin + (o - n_rd);
-#if defined(EMO_ABL_NOLOAD) || !defined(EMO_LATE_ISSUE)
-              if (false) {
-#else
-              if (more) {
-#endif
-                if constexpr (g < LA) issue_a(kt_next, slot_next, std::integral_constant<int, g>{});
-                else issue_b(kt_next, slot_next, std::integral_constant<int, g - LA>{});
-              }
-            }
-          }
-        });
-        __builtin_amdgcn_sched_barrier(0);
-      });
-    });
-    if (more) advance_loader();
-  }
-
-  const int64_t wm0 = bm + wvm * 32 * WTM;
-  const int wn0 = bn + wvn * 32 * WTN;
-
-  bool lds_epilogue = false;
-  if constexpr (!TRANS && sizeof(T) == 2) {
-    lds_epilogue = use_lds_epi;
-    if (lds_epilogue) {
-      // the slot the last stage was read from is free once every wave has finished that stage (the other slot holds the
-      // next tile's prefetched first stage); it is rewritten by the loader only behind the next stage's barrier
-      __builtin_amdgcn_s_barrier();
-      const unsigned xbase = lds_base + ((gs + NS - 1) % NS) * Tile::STAGE_BYTES;
-      auto m_of = [&](int i, int row) -> int64_t { const int64_t m = wm0 + i * 32 + row; return m < p.M ? m : -1; };
-      if (p.geglu) {
-        if constexpr (WTN % 2 == 0) epilogue_lds<T, WTM, WTN, NW, Tile::STAGE_BYTES, true>(acc, pe, m_of, wn0, wave, lane, xbase, C, R);
-      } else {
-        epilogue_lds<T, WTM, WTN, NW, Tile::STAGE_BYTES, false>(acc, pe, m_of, wn0, wave, lane, xbase, C, R);
-      }
-    }
-  }
-  if (lds_epilogue) {
-  } else if constexpr (!TRANS) {
-    // lane <-> output row m; register quad g of tile j <-> columns j*32 + 8*g + 4*half + {0..3}
-#pragma unroll
-    for (int i = 0; i < WTM; i++) {
-      const int64_t m = wm0 + i * 32 + l31;
-      const bool m_ok = m < p.M;
-      if (nsplit > 1) {
-        float* __restrict__ ws = (float*)p.workspace + ((int64_t)blockIdx.y * p.M + (m_ok ? m : 0)) * p.N;
-#pragma unroll
-        for (int j = 0; j < WTN; j++)
-#pragma unroll
-          for (int g = 0; g < 4; g++) {
-            const int n0 = wn0 + j * 32 + 8 * g + 4 * half;
-            if (m_ok && n0 < p.N)   // N % 4 == 0 is enforced for split-K
-              *(float4*)(ws + n0) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-          }
-        continue;
-      }
-#ifndef EMO_ABL_NOEPI
-      epilogue_row<T, WTN>(acc[i], pe, m, m_ok, wn0, half, C, R);
-#else
-      if (acc[i][0][0] == 123.456f) epilogue_row<T, WTN>(acc[i], pe, m, m_ok, wn0, half, C, R);
-#endif
-    }
-  } else {
-    // TRANS: lane <-> column n; register quad g <-> rows 8*g + 4*half + {0..3} (4 CONSECUTIVE rows), which are 4
-    // contiguous elements of V^T: Ct[m / t_rows][n][m % t_rows] -> one 8-byte (bf16) / 16-byte (f32) store per quad
-    const bool quad_ok = (p.t_rows & 3) == 0 && (p.t_ld & 3) == 0 && (p.t_batch_stride & 3) == 0;
-#pragma unroll
-    for (int i = 0; i < WTM; i++)
-#pragma unroll
-      for (int j = 0; j < WTN; j++) {
-        const int n = wn0 + j * 32 + l31;
-        if (n >= p.N) continue;
-        const float bias_v = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const int64_t m0 = wm0 + i * 32 + 8 * g + 4 * half;
-          if (m0 >= p.M) continue;
-          if (nsplit > 1) {
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-              if (m0 + e < p.M) ((float*)p.workspace)[((int64_t)blockIdx.y * p.M + m0 + e) * p.N + n] = acc[i][j][4 * g + e];
-            continue;
-          }
-          float o[4];
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            float v = acc[i][j][4 * g + e] + bias_v;
-            if (p.rowbias && m0 + e < p.M) v += p.rowbias[((m0 + e) / p.rows_per_batch) * p.ld_rowbias + n];
-            o[e] = v * p.out_scale;
-          }
-          const int64_t b = m0 / p.t_rows, ml = m0 % p.t_rows;
-          T* dst = C + b * p.t_batch_stride + (int64_t)n * p.t_ld + ml;
-          if (quad_ok && m0 + 3 < p.M) {   // t_rows % 4 == 0 => the quad never straddles a batch
-            if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
-            else *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-              const int64_t m = m0 + e;
-              if (m < p.M) TT<T>::st(C + (m / p.t_rows) * p.t_batch_stride + (int64_t)n * p.t_ld + (m % p.t_rows), o[e]);
-            }
-          }
-        }
-      }
-  }
-  }   // tiles of this block
-}
-
-// ------------------------------------------------------------------------------------------ 3x3 conv, halo reuse
-// Stride-1 3x3 convolution (resnet.py:30-38 - 44 of the 54 convs of a UNet pass) without the 9x re-read of the im2col
-// loader.  A block owns an 8x16 patch of output pixels of one frame (= 128 GEMM rows) x 128 output channels.  K runs
-// channel-chunk major: for every 128-byte channel chunk the (8+2)x(16+2) input HALO of the patch is brought into LDS ONCE
-// (23 KB instead of 9 x 16 KB of im2col rows) and the 9 taps read their A fragments from it at shifted pixel positions;
-// only the weight tile (128 x 128 B per tap) streams per stage.  LDS-DMA traffic per MFMA drops by ~40 % - the
-// direct-to-LDS path (~9 TB/s chip-wide measured) is what bounds the im2col kernel.
-//   * LDS: 2 halo buffers (chunk c+1 arrives in 6 pieces during the first 6 taps of chunk c) + a 2-deep weight ring
-//     = 78 KB -> 2 blocks per CU.  LDS "rows" of the halo are halo pixels; same XOR chunk swizzle as the GEMM.
-//   * persistent blocks, continuous loader stream across tiles, weights one stage ahead (requested right behind the
-//     barrier), vmcnt(0) + one s_barrier per tap-stage.
-//   * epilogue = the GEMM's row-major fused epilogue (bias, temb row bias, residual), rows mapped through the patch.
-// Needs Cin % (128 B of channels) == 0, H % 8 == 0, W % 16 == 0; everything else stays on the im2col loader.
-struct Halo {
-  static constexpr int PH = 8, PW = 16, HW_ = PW + 2, HPIX = (PH + 2) * (PW + 2);   // 180 halo pixels
-  static constexpr int PIECES = (HPIX + 7) / 8;                 // 1 KB glds pieces of 8 pixels: 23
-  static constexpr int LH = (PIECES + 3) / 4;                   // pieces per wave: 6 (the last round is partial)
-  static constexpr int HALO_BYTES = PIECES * 1024;              // 23 KB
-  static constexpr int BN = 128, LB = BN / 32;                  // weight tile rows, glds per wave per stage
-  static constexpr int B_BYTES = BN * KBYTES;                   // 16 KB
-  static constexpr int B_OFF = 2 * HALO_BYTES;
-  static constexpr int LDS_BYTES = 2 * HALO_BYTES + 2 * B_BYTES;   // 79872
-};
-
-template <typename T>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const emo_gemm_params p) {
-  constexpr int V = TT<T>::VEC, BK = KBYTES / (int)sizeof(T);
-  constexpr int WTM = 2, WTN = 2, NW = 4, LH = Halo::LH, LB = Halo::LB, BN = Halo::BN;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wvm = wave >> 1, wvn = wave & 1;
-  const int half = lane >> 5, l31 = lane & 31;
-
-  const int tpx = p.W_ / Halo::PW, tpy = p.H / Halo::PH, tpi = tpx * tpy;   // patches per frame
-  const int tiles_m = (int)(p.M / ((int64_t)p.H * p.W_)) * tpi;
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int tiles_all = tiles_m * tiles_n;
-  const int G = gridDim.x;
-  auto tile_of = [&](int i) {
-    const int qn = tiles_all >> 3, rn = tiles_all & 7, x = i & 7, idx = i >> 3;
-    return (x < rn ? x * (qn + 1) : rn * (qn + 1) + (x - rn) * qn) + idx;
-  };
-  const int nchunks = p.Cin / BK;
-  const int nk = nchunks * 9;            // tap-stages per tile
-
-  const T* __restrict__ A = (const T*)p.A;
-  const T* __restrict__ W = (const T*)p.W;
-  const T* zero = (const T*)g_zero_page;
-  const int lrow = lane / CPR, lchunk = lane % CPR;
-
-  // ---- halo loader: piece pi = i*4 + wave covers halo pixels pi*8 .. +8 (lane -> pixel pi*8 + lane/8, chunk lane%8)
-  int h_y[LH], h_x[LH], h_klog[LH];
-  bool h_piece[LH];
-#pragma unroll
-  for (int i = 0; i < LH; i++) {
-    const int pi = i * NW + wave, hp = pi * 8 + lrow;
-    h_piece[i] = pi < Halo::PIECES;
-    h_klog[i] = lchunk ^ swz(hp);
-    h_y[i] = hp < Halo::HPIX ? hp / Halo::HW_ : -100000;   // pad pixels of the last piece read the zero page
-    h_x[i] = hp % Halo::HW_;
-  }
-  const T* h_ptr[LH];
-  int h_inc[LH];
-  int h_iter = blockIdx.x, h_c = 0, h_count = 0;   // halo loader: tile, chunk, running chunk counter (buffer = count % 2)
-  auto setup_halo = [&](int iter) {
-    const int tile = tile_of(iter);
-    const int tm = tile / tiles_n;
-    const int img = tm / tpi, rem = tm % tpi;
-    const int y0 = (rem / tpx) * Halo::PH - 1, x0 = (rem % tpx) * Halo::PW - 1;
-#pragma unroll
-    for (int i = 0; i < LH; i++) {
-      const int iy = y0 + h_y[i], ix = x0 + h_x[i];
-      const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W_;
-      h_ptr[i] = ok ? A + (((int64_t)img * p.H + iy) * p.W_ + ix) * p.lda + h_klog[i] * V : zero;
-      h_inc[i] = ok ? BK : 0;
-    }
-  };
-  auto issue_halo = [&](auto I) {
-    constexpr int i = decltype(I)::value;
-    if (h_piece[i]) {
-      EMO_GLDS16(h_ptr[i], lds + (h_count & 1) * Halo::HALO_BYTES + (i * NW + wave) * 1024);
-      h_ptr[i] += h_inc[i];
-    }
-  };
-  auto advance_halo = [&]() {   // after the last piece of a chunk
-    h_count++;
-    if (++h_c >= nchunks) {
-      h_c = 0;
-      h_iter += G;
-      if (h_iter < tiles_all) setup_halo(h_iter);
-    }
-  };
-
-  // ---- weight loader: stage (c, t) of a tile reads W[n][t*Cin + c*BK ..+BK)
-  int b_klog[LB];
-  const T* b_base[LB];
-  bool b_ok[LB];
-#pragma unroll
-  for (int i = 0; i < LB; i++) b_klog[i] = lchunk ^ swz((i * NW + wave) * (64 / CPR) + lrow);
-  int l_iter = blockIdx.x, l_c = 0, l_t = 0;
-  auto setup_b = [&](int iter) {
-    const int tile = tile_of(iter);
-    const int lbn = (tile % tiles_n) * BN;
-#pragma unroll
-    for (int i = 0; i < LB; i++) {
-      const int n = lbn + (i * NW + wave) * (64 / CPR) + lrow;
-      b_ok[i] = n < p.N;
-      b_base[i] = b_ok[i] ? W + (int64_t)n * p.K + b_klog[i] * V : zero;
-    }
-  };
-  auto issue_b = [&](int slot) {
-    const int koff = l_t * p.Cin + l_c * BK;
-#pragma unroll
-    for (int i = 0; i < LB; i++)
-      EMO_GLDS16(b_ok[i] ? b_base[i] + koff : zero, lds + Halo::B_OFF + slot * Halo::B_BYTES + (i * NW + wave) * 1024);
-  };
-  auto advance_b = [&]() {
-    if (++l_t >= 9) {
-      l_t = 0;
-      if (++l_c >= nchunks) {
-        l_c = 0;
-        l_iter += G;
-        if (l_iter < tiles_all) setup_b(l_iter);
-      }
-    }
-  };
-
-  // ---- fragment addressing
-  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-  int hp0[WTM];   // halo pixel of tap (0,0) for this lane's output pixel of MFMA tile row i
-#pragma unroll
-  for (int i = 0; i < WTM; i++) hp0[i] = ((wvm * WTM + i) * 2 + (l31 >> 4)) * Halo::HW_ + (l31 & 15);
-  unsigned fb_off[WTN][KSTEPS];
-#pragma unroll
-  for (int j = 0; j < WTN; j++) {
-    const int r = wvn * 32 * WTN + j * 32 + l31;
-#pragma unroll
-    for (int kk = 0; kk < KSTEPS; kk++) fb_off[j][kk] = Halo::B_OFF + r * KBYTES + (((kk * 2 + half) ^ swz(r)) * 16);
-  }
-
-  T* __restrict__ C = (T*)p.C;
-  const T* __restrict__ R = (const T*)p.residual;
-  emo_gemm_params pe = p;     // the accumulators start at bias + temb row bias: the epilogue sees neither
-  pe.bias = nullptr;
-  pe.rowbias = nullptr;
-  const bool lds_epi = sizeof(T) == 2 && g_gemm_lds_epi && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!R || (p.ldr & 7) == 0);
-
-  // ---- stream prologue: halo of the first chunk, weights of the first stage
-  setup_halo(h_iter);
-  static_for<LH>([&](auto I) { issue_halo(I); });
-  advance_halo();
-  setup_b(l_iter);
-  issue_b(0);
-  advance_b();
-
-  int gs = 0, gc = 0;   // running tap-stage / chunk counters of the MFMA loop (weight slot = gs % 2, halo buffer = gc % 2)
-  for (int c_iter = blockIdx.x; c_iter < tiles_all; c_iter += G) {
-    const int c_tile = tile_of(c_iter);
-    f32x16 acc[WTM][WTN];
-    init_acc_bias<WTM, WTN>(acc, p.bias, (c_tile % tiles_n) * BN + wvn * 32 * WTN, half, p.N);   // zeros without a bias
-    if (p.rowbias) {   // temb row bias (resnet.py:188): one row per frame, a patch lies inside one frame
-      const int tm0 = c_tile / tiles_n;
-      const int64_t m0 = (int64_t)(tm0 / tpi) * p.H * p.W_;
-      const float* rb = p.rowbias + (m0 / p.rows_per_batch) * p.ld_rowbias;
-      const int wnb = (c_tile % tiles_n) * BN + wvn * 32 * WTN;
-#pragma unroll
-      for (int j = 0; j < WTN; j++)
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const int n0 = wnb + j * 32 + 8 * g + 4 * half;
-          if (n0 < p.N) {
-            const float4 b4 = *(const float4*)(rb + n0);
-#pragma unroll
-            for (int i = 0; i < WTM; i++) { acc[i][j][4 * g] += b4.x; acc[i][j][4 * g + 1] += b4.y; acc[i][j][4 * g + 2] += b4.z; acc[i][j][4 * g + 3] += b4.w; }
-          }
-        }
-    }
-
-    for (int c = 0; c < nchunks; c++, gc++) {
-      const unsigned stH = lds_base + (gc & 1) * Halo::HALO_BYTES;
-      for (int t = 0; t < 9; t++, gs++) {
-        wait_vmcnt<0>();                  // this stage's weights (and, at t == 0, the whole halo) have landed
-        __builtin_amdgcn_s_barrier();     // ... for every wave; everyone is done with the previous stage's slot
-        // next stage's weights, then one piece of the next chunk's halo (pieces 0..5 ride on taps 0..5)
-        if (l_iter < tiles_all) { issue_b((gs + 1) & 1); advance_b(); }
-        if (t < LH && h_iter < tiles_all) {
-          switch (t) {
-            case 0: issue_halo(std::integral_constant<int, 0>{}); break;
-            case 1: issue_halo(std::integral_constant<int, 1>{}); break;
-            case 2: issue_halo(std::integral_constant<int, 2>{}); break;
-            case 3: issue_halo(std::integral_constant<int, 3>{}); break;
-            case 4: issue_halo(std::integral_constant<int, 4>{}); break;
-            default: issue_halo(std::integral_constant<int, 5>{}); break;
-          }
-          if (t == LH - 1) advance_halo();
-        }
-        const unsigned stB = lds_base + (gs & 1) * Halo::B_BYTES;
-        // A fragment addresses of this tap: halo pixel (y + ky, x + kx)
-        const int toff = (t / 3) * Halo::HW_ + (t % 3);
-        unsigned fa_base[WTM], fa_key[WTM];
-#pragma unroll
-        for (int i = 0; i < WTM; i++) {
-          const int hp = hp0[i] + toff;
-          fa_base[i] = stH + hp * KBYTES;
-          fa_key[i] = swz(hp);
-        }
-        uint4 fa[2][WTM], fb[2][WTN];
-#pragma unroll
-        for (int i = 0; i < WTM; i++) fa[0][i] = lds_read16(fa_base[i] + ((half ^ fa_key[i]) << 4));
-#pragma unroll
-        for (int j = 0; j < WTN; j++) fb[0][j] = lds_read16(stB + fb_off[j][0]);
-        constexpr int NMMA = WTM * WTN, NRD = WTM + WTN;
-        static_for<KSTEPS>([&](auto KK) {
-          constexpr int kk = decltype(KK)::value, cur = kk & 1, nxt = cur ^ 1;
-          wait_lgkmcnt<0>();
-          __builtin_amdgcn_sched_barrier(0);
-          constexpr int n_rd = (kk + 1 < KSTEPS) ? NRD : 0;
-          static_for<NMMA>([&](auto Q) {
-            constexpr int q = decltype(Q)::value, i = q / WTN, j = q % WTN;
-            acc[i][j] = mma16<T>(fb[cur][j], fa[cur][i], acc[i][j]);   // rows = n, lane = m
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (q < n_rd) {
-              if constexpr (q < WTM) fa[nxt][q] = lds_read16(fa_base[q] + ((((kk + 1) * 2 + half) ^ fa_key[q]) << 4));
-              else fb[nxt][q - WTM] = lds_read16(stB + fb_off[q - WTM][kk + 1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          });
-        });
-      }
-    }
-
-    // ---- epilogue: MFMA tile row i of this wave = patch rows 2*(wvm*2+i), +1 (16 pixels each)
-    const int tm = c_tile / tiles_n;
-    const int img = tm / tpi, rem = tm % tpi;
-    const int y0 = (rem / tpx) * Halo::PH, x0 = (rem % tpx) * Halo::PW;
-    const int wn0 = (c_tile % tiles_n) * BN + wvn * 32 * WTN;
-    bool staged = false;
-    if constexpr (sizeof(T) == 2) {
-      if (lds_epi) {
-        // the halo buffer of the chunk just finished is free once every wave is past its last tap; the halo loader
-        // rewrites it only behind the next stage's barrier
-        __builtin_amdgcn_s_barrier();
-        auto m_of = [&](int i, int row) -> int64_t {
-          return ((int64_t)img * p.H + y0 + (wvm * WTM + i) * 2 + (row >> 4)) * p.W_ + x0 + (row & 15);
-        };
-        epilogue_lds<T, WTM, WTN, NW, Halo::HALO_BYTES, false>(acc, pe, m_of, wn0, wave, lane, lds_base + ((gc + 1) & 1) * Halo::HALO_BYTES, C, R);
-        staged = true;
-      }
-    }
-    if (!staged) {
-#pragma unroll
-      for (int i = 0; i < WTM; i++) {
-        const int y = y0 + (wvm * WTM + i) * 2 + (l31 >> 4), x = x0 + (l31 & 15);
-        const int64_t m = ((int64_t)img * p.H + y) * p.W_ + x;
-        epilogue_row<T, WTN>(acc[i], pe, m, true, wn0, half, C, R);
-      }
-    }
-  }
-}
-
-// split-K second pass: fixed-order reduction of the f32 partials + the same fused epilogue; a thread owns 4 consecutive
-// output columns (N % 4 == 0 is enforced for split-K): 16-byte partial loads, 8/16-byte stores
-template <typename T>
-__global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(const emo_gemm_params p) {
-  const int n_out = p.geglu ? p.N / 2 : p.N;
-  const int nq = n_out >> 2;
-  const int64_t total = p.M * nq;
-  const float* __restrict__ ws = (const float*)p.workspace;
-  const int64_t slab = p.M * (int64_t)p.N;
-  T* __restrict__ C = (T*)p.C;
-  const T* __restrict__ R = (const T*)p.residual;
-  const bool vec_io = ((p.ldc | (R ? p.ldr : 0)) & 3) == 0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = i / nq;
-    const int no = (int)(i % nq) * 4;
-    const int nw = p.geglu ? (no / 32) * 64 + (no % 32) : no;   // column in W-row space
-    float v[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < p.split_k; s++) {
-      const float4 a = *(const float4*)(ws + s * slab + m * p.N + nw);
-      v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
-      if (p.geglu) {
-        const float4 b = *(const float4*)(ws + s * slab + m * p.N + nw + 32);
-        g[0] += b.x; g[1] += b.y; g[2] += b.z; g[3] += b.w;
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      if (p.bias) { v[e] += p.bias[nw + e]; if (p.geglu) g[e] += p.bias[nw + 32 + e]; }
-      if (p.rowbias) v[e] += p.rowbias[(m / p.rows_per_batch) * p.ld_rowbias + nw + e];
-      if (p.geglu) v[e] = v[e] * gelu_erf_f(g[e]);
-    }
-    if (!p.transpose_out) {
-      if (vec_io) {
-        if (R) {
-          if constexpr (sizeof(T) == 2) {
-            float r4[4];
-            unpack4<T>(*(const uint2*)(R + m * p.ldr + no), r4);
-            v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
-          } else {
-            const float4 rv = *(const float4*)(R + m * p.ldr + no);
-            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; e++) v[e] *= p.out_scale;
-        if constexpr (sizeof(T) == 2) *(uint2*)(C + m * p.ldc + no) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
-        else *(float4*)(C + m * p.ldc + no) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          float o = v[e];
-          if (R) o += TT<T>::ld(R + m * p.ldr + no + e);
-          TT<T>::st(C + m * p.ldc + no + e, o * p.out_scale);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; e++)
-        TT<T>::st(C + (m / p.t_rows) * p.t_batch_stride + (int64_t)(no + e) * p.t_ld + (m % p.t_rows), v[e] * p.out_scale);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------ host side
-struct GemmPlan { int nt5, big, small, split_k; };
-
-static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
-
-static GemmPlan plan_gemm(int64_t M, int N, int K, int dtype, int geglu, int transpose_out) {
-  GemmPlan pl;
-  // 256x256 / 8 waves for the big compute-bound shapes (N a multiple of 256, or wide enough that the ragged last
-  // tile is small), else 128x160 when N is a multiple of 160 (every SD-1.5 width), else 128x128
-  const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
-  const int bk = KBYTES / (dtype == EMO_F32 ? 4 : 2);
-  const int nk = (K + bk - 1) / bk;
-  static const int big_min_nk = env_int("EMO_GEMM_BIG_MINNK", 0);
-  pl.big = (dtype != EMO_F32 && tiles256 >= 224 && (N % 256 == 0 || N >= 1792) && nk >= big_min_nk) ? 1 : 0;
-  pl.nt5 = (!pl.big && !geglu && N % 160 == 0) ? 1 : 0;
-  pl.small = 0;
-  if (pl.nt5 && N % 128 == 0) {
-    // both 128x160 and 128x128 tile N exactly: take the one that fills the 2-blocks-per-CU slots better (the 2x2 wave
-    // layout also reads 1.0 instead of 1.2 LDS fragments per MFMA, so it wins ties)
-    const int64_t mt = (M + 127) / 128, slots = 512;
-    const int64_t b5 = mt * (N / 160), b4 = mt * (N / 128);
-    const double f5 = (double)b5 / (double)(((b5 + slots - 1) / slots) * slots);
-    const double f4 = (double)b4 / (double)(((b4 + slots - 1) / slots) * slots);
-    static const int force = env_int("EMO_GEMM_TILE", 0);
-    if (force == 4 || (force == 0 && f4 * 1.05 >= f5)) pl.nt5 = 0;
-  }
-  // fewer 128-row blocks than CUs and a short K (the 8x8 / 16x16 levels, the ReferenceNet pass): splitting K pays an f32
-  // round trip + a second launch and a block is mostly prologue + epilogue -> 64x64 tiles (4 waves of 32x32, 32 KB of
-  // LDS: ~4 co-resident blocks per CU overlap each other's prologue/epilogue).  They read 2 LDS fragments per MFMA, so
-  // long-K shapes (every conv) stay on 128-row tiles + split-K.  V^T outputs also take them: the column-per-lane
-  // store of the transposed epilogue is cheaper from 32x32 wave tiles (measured 91 -> 59 us at M=98304 N=K=320).
-  static const int small_mode = env_int("EMO_GEMM_SMALL", 1), small_slots = env_int("EMO_GEMM_SMALL_SLOTS", 512);
-  static const int small_below = env_int("EMO_GEMM_SMALL_BELOW", 256), small_nk = env_int("EMO_GEMM_SMALL_NK", 24);
-  const int64_t blocks128 = ((M + 127) / 128) * ((N + (pl.nt5 ? 159 : 127)) / (pl.nt5 ? 160 : 128));
-  if (small_mode && !pl.big && !geglu && nk <= small_nk && (blocks128 < small_below || transpose_out)) { pl.small = 1; pl.nt5 = 0; }
-  const int bm = pl.small ? 64 : 128, bn = pl.small ? 64 : (pl.nt5 ? 160 : 128);
-  const int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-  const int64_t slots = pl.small ? small_slots : 512;     // co-resident blocks to aim at
-  int s = 1;
-  if (!pl.big && tiles * 2 <= slots && nk >= 8 && N % 4 == 0) {
-    s = (int)(slots / tiles);                     // whole blocks only: one block more than the slots costs a second round
-    const int max_by_k = nk / 4;                  // keep >= 4 stages per slice
-    if (s > max_by_k) s = max_by_k;
-    if (s > 32) s = 32;
-    if (s < 2) s = 1;
-  }
-  pl.split_k = s;
-  return pl;
-}
+extern template int gemm_run<float>(const emo_gemm_params&, const GemmPlan&, int, hipStream_t);
+extern template int gemm_run<bf16_t>(const emo_gemm_params&, const GemmPlan&, int, hipStream_t);
+extern template int gemm_run<f16_t>(const emo_gemm_params&, const GemmPlan&, int, hipStream_t);
+extern template int gemm_run_halo<float>(const emo_gemm_params&, int64_t, hipStream_t);
+extern template int gemm_run_halo<bf16_t>(const emo_gemm_params&, int64_t, hipStream_t);
+extern template int gemm_run_halo<f16_t>(const emo_gemm_params&, int64_t, hipStream_t);
 
 extern "C" int emo_gemm_suggest_split_k(int64_t M, int N, int K, int dtype, int geglu, int transpose_out) {
   return plan_gemm(M, N, K, dtype, geglu, transpose_out).split_k;
 }
 extern "C" size_t emo_gemm_workspace_bytes(int64_t M, int N, int split_k) {
   return split_k > 1 ? (size_t)split_k * (size_t)M * (size_t)N * sizeof(float) : 0;
-}
-
-template <typename T, bool CONV, bool TRANS, int WTM, int WTN, int WVM, int WVN, int NS>
-static int launch_gemm(const emo_gemm_params& p, int S, hipStream_t st) {
-  using Tile = GemmTile<WTM, WTN, WVM, WVN, NS>;
-  auto kern = gemm_kernel<T, CONV, TRANS, WTM, WTN, WVM, WVN, NS>;
-  if (Tile::LDS_BYTES > 64 * 1024) {
-    static bool once = false;
-    if (!once) {
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES);
-      if (e != hipSuccess) return emo_fail(EMO_ERR_HIP, "emo_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      once = true;
-    }
-  }
-  const int64_t tiles = ((p.M + Tile::BM - 1) / Tile::BM) * ((p.N + Tile::BN - 1) / Tile::BN);
-  if (tiles >= (1ll << 31)) return emo_fail(EMO_ERR_BAD_SHAPE, "emo_gemm: too many tiles");
-  // persistent launch: as many blocks as the chip holds at once (by LDS, <= 4 per CU), each walking its tiles; a
-  // multiple of 8 so that a block's tiles all map to its own XCD
-  static const int persist = env_int("EMO_GEMM_PERSIST", 1);
-  static const int lds_epi_set = [] {
-    const int v = env_int("EMO_GEMM_LDS_EPI", 1);
-    if (v != 1) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_lds_epi), &v, sizeof(int));
-    return v;
-  }();
-  (void)lds_epi_set;
-  int64_t slots = (256 * Tile::BPC / S) & ~7;
-  if (slots < 8) slots = 8;
-  const int64_t gx = (persist && tiles > slots) ? slots : tiles;
-  dim3 grid((unsigned)gx, (unsigned)S);
-  kern<<<grid, Tile::THREADS, Tile::LDS_BYTES, st>>>(p);
-  EMO_LAUNCH_CHECK();
-  return EMO_OK;
-}
-
-#ifndef EMO_NS11
-#define EMO_NS11 2
-#endif
-#ifndef EMO_NS15
-#define EMO_NS15 2
-#endif
-#ifndef EMO_NS22
-#define EMO_NS22 2
-#endif
-template <typename T, bool CONV, bool TRANS>
-static int dispatch_tile(const emo_gemm_params& p, const GemmPlan& pl, int S, hipStream_t st) {
-  // (4-wave 128x256 / 256x128 tiles were measured 15-35 % slower than the 8-wave 256x256 at equal LDS traffic per MFMA)
-#ifdef EMO_FORCE22
-  return launch_gemm<T, CONV, TRANS, 2, 2, 2, 2, EMO_NS22>(p, S, st);
-#endif
-#ifdef EMO_FORCE_3222   // experiment: 192x128 tile, 4 waves of 96x64, 2 blocks per CU
-  if (!CONV && !TRANS && S == 1) return launch_gemm<T, CONV, TRANS, 3, 2, 2, 2, 2>(p, S, st);
-#endif
-#ifdef EMO_FORCE_2322   // experiment: 128x192 tile, 4 waves of 64x96, 2 blocks per CU
-  if (!CONV && !TRANS && S == 1 && !p.geglu) return launch_gemm<T, CONV, TRANS, 2, 3, 2, 2, 2>(p, S, st);
-#endif
-#ifdef EMO_FORCE_2224   // experiment: 128x256 tile, 8 waves of 64x64
-  if (!CONV && !TRANS && S == 1) return launch_gemm<T, CONV, TRANS, 2, 2, 2, 4, 2>(p, S, st);
-#endif
-#ifdef EMO_FORCE_1542   // experiment: 128x320 tile, 8 waves of 32x160
-  if (!CONV && !TRANS && S == 1 && !p.geglu) return launch_gemm<T, CONV, TRANS, 1, 5, 4, 2, 2>(p, S, st);
-#endif
-  if (pl.big && S == 1) return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, 2>(p, S, st);   // 2x4 waves of 128x64, 2 x 64 KB ring
-  if (pl.small) return launch_gemm<T, CONV, TRANS, 1, 1, 2, 2, EMO_NS11>(p, S, st);   // 2x2 waves of 32x32, 2 x 16 KB ring
-  if (pl.nt5) return launch_gemm<T, CONV, TRANS, 1, 5, 4, 1, EMO_NS15>(p, S, st);   // 4x1 waves of 32x160, 2 x 36 KB ring
-#ifndef EMO_NS22
-#define EMO_NS22 2
-#endif
-  return launch_gemm<T, CONV, TRANS, 2, 2, 2, 2, EMO_NS22>(p, S, st);               // 2x2 waves of 64x64, 4 x 16 KB ring
-}
-
-template <typename T>
-static int dispatch_gemm(const emo_gemm_params& p, const GemmPlan& pl, int S, hipStream_t st) {
-  const bool conv = p.conv_taps != 0;
-  if (p.transpose_out) return conv ? dispatch_tile<T, true, true>(p, pl, S, st) : dispatch_tile<T, false, true>(p, pl, S, st);
-  return conv ? dispatch_tile<T, true, false>(p, pl, S, st) : dispatch_tile<T, false, false>(p, pl, S, st);
 }
 
 extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
@@ -1131,23 +47,13 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
     static const int halo_mode = env_int("EMO_CONV_HALO", 1);
     const int bk = KBYTES / (p.dtype == EMO_F32 ? 4 : 2);
     if (halo_mode && conv && p.stride == 1 && !p.upsample2x && !p.transpose_out && !p.geglu && S == 1 && p.Cin % bk == 0 &&
-        p.H % Halo::PH == 0 && p.W_ % Halo::PW == 0 && (p.N & 3) == 0 &&
+        p.H % HaloGeom::PH == 0 && p.W_ % HaloGeom::PW == 0 && (p.N & 3) == 0 &&
         (!p.rowbias || (p.rows_per_batch % (p.H * p.W_) == 0 && (p.ld_rowbias & 3) == 0))) {
-      static bool once = false;
-      if (!once) {
-        hipError_t e0 = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo::LDS_BYTES);
-        if (e0 != hipSuccess) return emo_fail(EMO_ERR_HIP, "emo_gemm: hipFuncSetAttribute(halo conv f16)");
-        hipError_t e1 = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo::LDS_BYTES);
-        hipError_t e2 = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo::LDS_BYTES);
-        if (e1 != hipSuccess || e2 != hipSuccess) return emo_fail(EMO_ERR_HIP, "emo_gemm: hipFuncSetAttribute(halo conv)");
-        once = true;
-      }
-      const int64_t tiles = (p.M / 128) * ((p.N + Halo::BN - 1) / Halo::BN);
+      const int64_t tiles = (p.M / 128) * ((p.N + HaloGeom::BN - 1) / HaloGeom::BN);
       const int64_t gx = tiles > 512 ? 512 : tiles;
-      hipStream_t st = as_stream(stream);
-      EMO_DISPATCH(p.dtype, "emo_gemm", (conv3x3_halo_kernel<T><<<(unsigned)gx, 256, Halo::LDS_BYTES, st>>>(p)));
-      EMO_LAUNCH_CHECK();
-      return EMO_OK;
+      int rc_h = EMO_OK;
+      EMO_DISPATCH(p.dtype, "emo_gemm", rc_h = gemm_run_halo<T>(p, gx, as_stream(stream)));
+      return rc_h;
     }
   }
   GemmPlan pl = plan_gemm(p.M, p.N, p.K, p.dtype, p.geglu, p.transpose_out);
@@ -1157,13 +63,6 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
   }
   hipStream_t st = as_stream(stream);
   int rc = EMO_OK;
-  EMO_DISPATCH(p.dtype, "emo_gemm", rc = dispatch_gemm<T>(p, pl, S, st));
-  if (rc) return rc;
-  if (S > 1) {
-    const int64_t total = p.M * (p.geglu ? p.N / 2 : p.N) / 4;
-    int64_t g = (total + 255) / 256; if (g > 4096) g = 4096;
-    EMO_DISPATCH(p.dtype, "emo_gemm", (gemm_splitk_epilogue_kernel<T><<<(int)g, 256, 0, st>>>(p)));
-    EMO_LAUNCH_CHECK();
-  }
-  return EMO_OK;
+  EMO_DISPATCH(p.dtype, "emo_gemm", rc = gemm_run<T>(p, pl, S, st));
+  return rc;
 }

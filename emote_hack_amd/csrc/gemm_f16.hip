@@ -1,0 +1,5 @@
+// gemm_f16.hip - the GEMM / conv kernels of gemm_impl.h instantiated for f16_t
+#include "gemm_impl.h"
+
+template int gemm_run<f16_t>(const emo_gemm_params&, const GemmPlan&, int, hipStream_t);
+template int gemm_run_halo<f16_t>(const emo_gemm_params&, int64_t, hipStream_t);
