@@ -191,6 +191,24 @@ def test_config4_geometry_fp16():
     torch.testing.assert_close(y1.float().cpu(), y16[1:].float().cpu(), rtol=2e-2, atol=2e-2)
 
 
+def test_cfg2_full_size_properties():
+    """BASELINE.json configs[1] at FULL size (SD-1.5 widths + motion modules, 12 frames of 64x64 latents, CFG batch of 2):
+    too large for the CPU oracle in a test, so size-independent properties - bf16 HIP vs f32 HIP (the f32 path is pinned to
+    the oracle / reference goldens at the small sizes above) within the bf16 yard-stick, finite output, and the uncond /
+    cond batch rows independent of each other."""
+    x, ctx = seeded_randn((2, 4, 12, 64, 64), 1), seeded_randn((2, 77, 768), 2)
+    m32 = build(cases.SD15_MOTION, torch.float32)
+    y32 = m32(x.to(DEV), 981, ctx.to(DEV)).sample.float().cpu()
+    y32_c = m32(x[1:].to(DEV), 981, ctx[1:].to(DEV)).sample.float().cpu()
+    torch.testing.assert_close(y32_c, y32[1:], rtol=1e-3, atol=1e-4)
+    del m32
+    torch.cuda.empty_cache()
+    m16 = build(cases.SD15_MOTION, torch.bfloat16)
+    y16 = m16(x.to(DEV), 981, ctx.to(DEV)).sample
+    assert bool(torch.isfinite(y16).all())
+    check(y16, y32, torch.bfloat16)
+
+
 def test_unet_vs_oracle_medium_size_properties():
     """A size the goldens do not hold (SD-1.5 widths at 16x16 latent, F=3, heads of 40/80/160): HIP f32
     vs the CPU oracle on the same seeded inputs; plus frame-permutation equivariance without motion
