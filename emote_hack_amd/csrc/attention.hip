@@ -20,6 +20,7 @@
 // Two KV segments: [self / context keys of the batch row] ++ [a bank shared by seg1_div consecutive
 // batch rows] = the ReferenceNet read path (mutual_self_attention.py:238-241) without materialising the
 // F-times-repeated bank or the concatenated K/V.  Head dims 40/80/160 are zero-padded to 48/80/160 (bf16).
+#include <stdlib.h>
 #include "common.h"
 
 static constexpr int ATT_THREADS = 256, BQ = 128, TK = 64;
@@ -69,7 +70,7 @@ __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1)
 
 // G = glds per wave per tile, NSR = ring depth, QT = 32-query tiles per wave (2 halves the LDS fragment traffic per MFMA)
 template <typename T, int DCH, int G, int NSR, int QT>
-__global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) void attention_kernel(const emo_attention_params p, int stage_bytes) {
+__global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) void attention_kernel(const emo_attention_params p, int stage_bytes, int order_mode) {
   using Cfg = AttCfg<T, DCH>;
   constexpr int V = Cfg::V, NT = Cfg::NT, KROW = Cfg::KROW, VROW = Cfg::VROW, STEPS = Cfg::STEPS;
   constexpr int DCHP = Cfg::DCHP, VCH = Cfg::VCH, VCHP = Cfg::VCHP, K_CHUNKS = Cfg::K_CHUNKS;
@@ -78,17 +79,30 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  // XCD-aware work order: block L of the flat launch runs on XCD L % 8.  Work items are (b, head, q-tile) with the q-tile
-  // fastest; XCD x takes a contiguous run of them, so the q-tiles that share one (b, head)'s K / V mostly share one L2
-  // instead of pulling the same 0.6 MB through all eight.
+  // XCD-aware work order: block L of the flat launch runs on XCD L % 8.  A "chunk" = the q-tiles of one (b, head): they share
+  // that (b, head)'s K / V, so a chunk stays on ONE XCD (one L2 fill instead of eight).  Chunks are dealt round-robin over
+  // the XCDs (chunk c -> XCD c % 8) - NOT as contiguous runs: under CFG the uncond batch rows have half the keys of the
+  // cond rows (no bank segment), and contiguous runs would hand whole XCDs the short rows (measured +28 % on the
+  // two-segment launch).  Needs (B * heads) % 8 == 0, else the plain order.
   int qt, head, b;
   {
     const int nqt = (p.Lq + BQ * QT - 1) / (BQ * QT);
-    const int total = gridDim.x, L = blockIdx.x;
-    const int qn = total >> 3, rn = total & 7, x = L & 7, idx = L >> 3;
-    const int wi = (x < rn ? x * (qn + 1) : rn * (qn + 1) + (x - rn) * qn) + idx;
-    qt = wi % nqt;
-    const int hb = wi / nqt;
+    const int chunks = p.B * p.heads, L = blockIdx.x;
+    int hb;
+    if ((chunks & 7) == 0 && order_mode == 2) {
+      const int x = L & 7, idx = L >> 3;
+      qt = idx % nqt;
+      hb = (idx / nqt) * 8 + x;
+    } else if (order_mode == 1) {
+      const int total = gridDim.x;
+      const int qn = total >> 3, rn = total & 7, x = L & 7, idx = L >> 3;
+      const int wi = (x < rn ? x * (qn + 1) : rn * (qn + 1) + (x - rn) * qn) + idx;
+      qt = wi % nqt;
+      hb = wi / nqt;
+    } else {
+      qt = L % nqt;
+      hb = L / nqt;
+    }
     head = hb % p.heads;
     b = hb / p.heads;
   }
@@ -437,7 +451,8 @@ static int launch_attention3(const emo_attention_params& p, hipStream_t st) {
   const int64_t nblk = (int64_t)((p.Lq + BQ * QT - 1) / (BQ * QT)) * p.heads * p.B;
   if (nblk >= (1ll << 31)) return emo_fail(EMO_ERR_BAD_SHAPE, "emo_attention: too many blocks");
   dim3 grid((unsigned)nblk);
-  kern<<<grid, ATT_THREADS, lds, st>>>(p, L::STAGE_BYTES);
+  static const int order_mode = getenv("EMO_ATT_ORDER") ? atoi(getenv("EMO_ATT_ORDER")) : 2;   // measurement hook: 0 plain, 1 contiguous runs, 2 chunk round-robin
+  kern<<<grid, ATT_THREADS, lds, st>>>(p, L::STAGE_BYTES, order_mode);
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
