@@ -89,10 +89,11 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
     const int nqt = (p.Lq + BQ * QT - 1) / (BQ * QT);
     const int chunks = p.B * p.heads, L = blockIdx.x;
     int hb;
-    if ((chunks & 7) == 0 && order_mode == 2) {
+    if ((chunks & 7) == 0 && order_mode >= 2) {
       const int x = L & 7, idx = L >> 3;
       qt = idx % nqt;
       hb = (idx / nqt) * 8 + x;
+      if (order_mode == 3) hb = chunks - 1 - hb;   // longest rows (cond: two KV segments) first, the short uncond rows fill the tail
     } else if (order_mode == 1) {
       const int total = gridDim.x;
       const int qn = total >> 3, rn = total & 7, x = L & 7, idx = L >> 3;
