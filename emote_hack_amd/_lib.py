@@ -47,6 +47,7 @@ class AttentionParams(C.Structure):
         ("B", C.c_int), ("Lq", C.c_int), ("heads", C.c_int), ("d", C.c_int),
         ("scale", C.c_float),
         ("dtype", C.c_int),
+        ("seg1_row", C.c_void_p),
     ]
 
 

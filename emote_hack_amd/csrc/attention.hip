@@ -167,7 +167,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
   const int tiles0 = (p.Lk0 + TK - 1) / TK;
   const int tiles1 = nseg == 2 ? (p.Lk1 + TK - 1) / TK : 0;
   const int ntiles = tiles0 + tiles1;
-  const int kb0 = b / p.seg0_div, kb1 = nseg == 2 ? b / p.seg1_div - p.seg1_skip : 0;
+  const int kb0 = b / p.seg0_div, kb1 = nseg == 2 ? (p.seg1_row ? p.seg1_row[0] : b / p.seg1_div - p.seg1_skip) : 0;
   const T* kbase0 = (const T*)p.k0 + (int64_t)kb0 * p.Lk0 * p.ldk0 + head * d;
   const T* vbase0 = (const T*)p.v0t + ((int64_t)kb0 * p.heads * d + (int64_t)head * d) * p.ldv0t;
   const T* kbase1 = nseg == 2 ? (const T*)p.k1 + (int64_t)kb1 * p.Lk1 * p.ldk1 + head * d : nullptr;
@@ -517,10 +517,12 @@ extern "C" int emo_attention(const emo_attention_params* pp, void* stream) {
   EMO_CHECK(p.ldv0t >= p.Lk0, EMO_ERR_BAD_SHAPE, "emo_attention: ldv0t < Lk0");
   EMO_CHECK(p.heads <= 65535 && p.B <= 65535, EMO_ERR_BAD_SHAPE, "emo_attention: grid limits");
   EMO_CHECK(p.seg0_div >= 1, EMO_ERR_BAD_SHAPE, "emo_attention: seg0_div must be >= 1");
-  if (p.k1) {
+  if (p.k1 && !p.seg1_row) {
     EMO_CHECK(p.seg1_skip >= 0 && p.seg1_first_batch / (p.seg1_div > 0 ? p.seg1_div : 1) >= p.seg1_skip, EMO_ERR_BAD_SHAPE,
               "emo_attention: seg1_skip %d exceeds the bank rows skipped by seg1_first_batch %d", p.seg1_skip, p.seg1_first_batch);
-    EMO_CHECK(p.v1t && p.Lk1 > 0 && p.seg1_div > 0 && p.ldk1 % V == 0 && p.ldv1t % V == 0 && p.ldv1t >= p.Lk1, EMO_ERR_BAD_SHAPE,
+  }
+  if (p.k1) {
+    EMO_CHECK(p.v1t && p.Lk1 > 0 && (p.seg1_div > 0 || p.seg1_row) && p.ldk1 % V == 0 && p.ldv1t % V == 0 && p.ldv1t >= p.Lk1, EMO_ERR_BAD_SHAPE,
               "emo_attention: segment-1 geometry");
   }
   hipStream_t st = as_stream(stream);

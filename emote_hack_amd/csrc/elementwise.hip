@@ -8,7 +8,7 @@ int emo_fail(int code, const char* fmt, ...) {
   va_list ap; va_start(ap, fmt); vsnprintf(emo_err_buf, sizeof(emo_err_buf), fmt, ap); va_end(ap);
   return code;
 }
-extern "C" int emo_version(void) { return 100; }
+extern "C" int emo_version(void) { return 200; }   // round 2: emo_attention_params.seg1_row, LayerNorm-folded GEMM
 extern "C" const char* emo_last_error_string(void) { return emo_err_buf; }
 
 static inline int grid_for(int64_t work, int block) {
@@ -272,9 +272,10 @@ __global__ __launch_bounds__(256) void accumulate_window_kernel(const T* __restr
     int c = (int)(i % C); int64_t r = i / C;
     int p = (int)(r % HW); int j = (int)(r / HW);
     int f = frames[j];
+    if (f < 0) continue;   // position dropped by the host: an earlier duplicate of a frame inside one window
     np[((int64_t)c * F + f) * HW + p] += TT<T>::ld(pred + r * ld + c);
   }
-  if (add_counter && blockIdx.x == 0 && threadIdx.x < nf) counter[frames[threadIdx.x]] += 1.0f;
+  if (add_counter && blockIdx.x == 0 && threadIdx.x < nf && frames[threadIdx.x] >= 0) counter[frames[threadIdx.x]] += 1.0f;
 }
 extern "C" int emo_accumulate_window(const void* pred, int ld, float* np, float* counter, const int32_t* frames, int nf, int C,
                                      int F, int HW, int add_counter, int dtype, void* stream) {

@@ -269,8 +269,9 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, H: int, W: int, 
 
 # ----------------------------------------------------------------------------- attention
 def attention(q, k0, v0t, Lk0, *, B, Lq, heads, d, scale, seg0_div=1, k1=None, v1t=None, Lk1=0, seg1_div=1,
-              seg1_first_batch=0, seg1_skip=0) -> torch.Tensor:
-    """q (B*Lq, >=heads*d) rows view; k0 rows view; v0t (Bk, heads*d, ld) V^T tensors."""
+              seg1_first_batch=0, seg1_skip=0, seg1_row=None) -> torch.Tensor:
+    """q (B*Lq, >=heads*d) rows view; k0 rows view; v0t (Bk, heads*d, ld) V^T tensors.
+    seg1_row: device int32 tensor holding the bank row every batch >= seg1_first_batch reads (see emo_hip.h)."""
     _need_cuda(q, k0, v0t)
     p = AttentionParams()
     pq, ldq = _rows(q)
@@ -283,6 +284,9 @@ def attention(q, k0, v0t, Lk0, *, B, Lq, heads, d, scale, seg0_div=1, k1=None, v
         pk1, ldk1 = _rows(k1)
         p.k1, p.ldk1, p.v1t, p.ldv1t, p.Lk1 = pk1.value, ldk1, v1t.data_ptr(), v1t.stride(1), Lk1
         p.seg1_div, p.seg1_first_batch, p.seg1_skip = seg1_div, seg1_first_batch, seg1_skip
+        if seg1_row is not None:
+            assert seg1_row.dtype == torch.int32 and seg1_row.is_cuda
+            p.seg1_row = seg1_row.data_ptr()
     else:
         p.seg1_div = 1
     p.out, p.ldo = out.data_ptr(), out.stride(0)

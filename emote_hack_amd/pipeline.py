@@ -1,21 +1,25 @@
 """EMOAnimationPipeline - the sampling loop of the reference (EMOAnimationPipeline.py:543-840) on
 MI355X.  Same `__call__` signature; the hot loop (`:698-823`) is re-designed:
 
-  * per step: ReferenceNet write pass -> per window-batch Backbone read pass -> window average + CFG +
+  * per step: Backbone read passes over this rank's work units -> (all_gather of the eps slices) -> window average + CFG +
     scheduler step fused in ONE HIP kernel (emo_cfg_step) on f32 master latents;
-  * ReferenceNet banks depend on the timestep only (never on the latents), so with world_size>1 the
-    `num_inference_steps` write passes are dealt round-robin over the ranks BEFORE the loop and exchanged
-    with one RCCL all_gather (north_star: "all-gather over xGMI to broadcast ReferenceNet features");
-    288 GB HBM holds every step's banks (50 x 28 MB at 512^2).  world_size==1 keeps the reference's
-    per-step order;
-  * windows are sharded `global_context[rank::world_size]` exactly like the reference (:757); the
-    reference's gather-to-root + broadcast (:796-821) is replaced by one all_reduce of the f32 window
-    accumulators, after which every rank runs the (deterministic, counter-based-noise) sampler step
-    redundantly - no broadcast, identical latents on all ranks.
+  * the ReferenceNet banks depend on the timestep only (never on the latents), so the write pass is hoisted out of the
+    step: T timesteps (reference_group, default 10) go through ONE batched pass (M is T times larger: the batch-1 pass of
+    the reference is a small-M, launch-bound workload), their K / V^T projections with the Backbone's attn1 weights are
+    computed once, kept resident in HBM (2 groups x 28 MB x T at 512^2) and selected per step by a device-side row index;
+    the pass of group g+1 runs on a second HIP stream while the Backbone works through group g.  With world_size > 1 the
+    ranks deal a group's timesteps among themselves and swap the banks with one RCCL all_gather (north_star: "all-gather
+    over xGMI to broadcast ReferenceNet features");
+  * work units are (context window x CFG branch): rank r owns U[r::world_size]; a UNet call batches the
+    rank's next 2*context_batch_size units, uncond first - at world_size 1 exactly the reference's batch (:759-763).  The
+    reference's gather-to-root + broadcast (:796-821) is replaced by ONE all_gather of the eps slices, after which every rank
+    accumulates all units in the same order and runs the (deterministic, counter-based-noise) sampler step redundantly -
+    no broadcast, bit-identical latents on all ranks;
+  * the attn2 K / V^T projections of the text / audio context are computed once per clip, not per step.
 
-Out of scope here: CLIP text encoder, VAE, ControlNet, wav2vec.  They are
-accepted as caller-supplied callables / precomputed tensors (`text_embeddings=`, `ref_image_latents=`,
-`audio_features=`, `speed_embeddings=` keyword arguments).
+Caller-supplied where out of scope: CLIP text encoder (`text_embeddings=`), VAE (`vae=` object with
+encode / decode_video, see emote_hack_amd/vae.py), wav2vec (`audio_features=`, windowed by
+emote_hack_amd.conditioning.audio_windows), `speed_embeddings=`.
 """
 from __future__ import annotations
 
@@ -23,8 +27,6 @@ import math
 from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import Callable, List, Optional, Union
-
-import os
 
 import torch
 
@@ -66,88 +68,125 @@ class EMOAnimationPipeline:
         if (callback_steps is None) or (not isinstance(callback_steps, int) or callback_steps <= 0):
             raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type {type(callback_steps)}.")
 
-    # ------------------------------------------------------------------ ReferenceNet banks
-    def _write_banks(self, appearance_encoder, writer, ref_lat_rep, t, text_embeddings):
-        """ReferenceNet write pass (:711-716).  The reference runs it on [uncond-text, cond-text] copies of the image, but
-        the reader never uses the uncond bank row: for the uc rows `hidden_states_c` is overwritten by the bank-free
-        uc attention (mutual_self_attention.py:243-256), and the ReferenceNet is batch-independent.  Only the cond half
-        is computed; outputs are bit-identical (tests/test_gpu_unet.py loop parity against the full oracle)."""
-        writer.clear()
-        h = ref_lat_rep.shape[0] // 2
-        appearance_encoder(ref_lat_rep[h:].unsqueeze(2), t, encoder_hidden_states=text_embeddings[h:], return_dict=False)
-        return writer
-
-    def _pack_banks(self, writer):
-        """All bank tensors of one step in one contiguous buffer (one collective instead of ten)."""
-        flat = [writer.bank[p][0].reshape(-1) for p in writer.order]
-        return torch.cat(flat)  # device copy (plumbing)
-
-    def _unpack_banks(self, buf, writer, shapes):
-        off = 0
-        for p, shp in zip(writer.order, shapes):
-            n = shp[0] * shp[1] * shp[2]
-            writer.bank[p] = [buf[off:off + n].view(shp)]
-            off += n
-
     # ------------------------------------------------------------------ the hot loop
     @torch.no_grad()
     def prepare_denoise(self, latents, ref_image_latents, text_embeddings, *, appearance_encoder, num_inference_steps=50,
                         guidance_scale=7.5, eta=0.0, context_frames=16, context_stride=1, context_overlap=4,
                         context_batch_size=1, context_schedule="uniform", audio_features=None, speed_embeddings=None, seed=0,
                         fusion_blocks="midup", dist=False, rank=0, world_size=1, return_eps=False, use_graphs=False,
-                        controlnet=None, controlnet_cond=None, controlnet_conditioning_scale=1.0):
+                        controlnet=None, controlnet_cond=None, controlnet_conditioning_scale=1.0, reference_group=10,
+                        reference_lookahead=True):
         """Set up the loop state (EMOAnimationPipeline.py:628-696).  latents f32 (1,4,F_tot,h,w);
-        ref_image_latents (1,4,h,w); text_embeddings (2,L,D) = [uncond, cond]."""
+        ref_image_latents (1,4,h,w); text_embeddings (2,L,D) = [uncond, cond].
+        reference_group = T: ReferenceNet timesteps computed per batched pass (1 = the reference's per-step order)."""
         unet, sch = self.unet, self.scheduler
         dev = unet.device
         if not guidance_scale > 1.0:
             raise NotImplementedError("guidance_scale <= 1 (no CFG) is not on the benchmarked path")
         if latents.shape[0] != 1:
             raise ValueError("batch_size must be 1 (EMOAnimationPipeline.py:641-642); run clips as separate calls")
+        if text_embeddings.shape[0] != 2:
+            raise ValueError("text_embeddings must be (2, L, D) = [uncond, cond] (:631)")
         st = SimpleNamespace()
-        st.cbs = context_batch_size
+        st.cbs = cbs = context_batch_size
         st.latents = latents.to(dev).float().contiguous()
         _, st.C4, st.f_tot, st.h, st.w = st.latents.shape
         st.HW = st.h * st.w
-        st.text = torch.cat([text_embeddings] * st.cbs).to(dev)                               # :631
+        st.text = text_embeddings.to(dev).float()
         st.appearance_encoder = appearance_encoder
         st.writer = ReferenceAttentionControl(appearance_encoder, do_classifier_free_guidance=True, mode="write",
-                                              batch_size=st.cbs, fusion_blocks=fusion_blocks)  # :633
-        st.reader = ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", batch_size=st.cbs,
-                                              fusion_blocks=fusion_blocks)                      # :634
+                                              batch_size=cbs, fusion_blocks=fusion_blocks)      # :633
+        st.reader = ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", batch_size=cbs,
+                                              fusion_blocks=fusion_blocks)                        # :634
         st.num_inference_steps = num_inference_steps
         st.timesteps = sch.set_timesteps(num_inference_steps)
-        st.ref_rep = ref_image_latents.to(dev).float().repeat(st.cbs * 2, 1, 1, 1)           # :712
+        n_steps = len(st.timesteps)
+        st.ref_lat = ref_image_latents.to(dev).float().reshape(1, st.C4, st.h, st.w)
         scheduler_fn = get_context_scheduler(context_schedule)
         # the reference recomputes the (step-independent: step arg is always 0) window list every step (:748-755)
-        queue = list(scheduler_fn(0, num_inference_steps, st.f_tot, context_frames, context_stride, context_overlap))
-        nb = math.ceil(len(queue) / st.cbs)
-        st.global_context = [queue[i * st.cbs:(i + 1) * st.cbs] for i in range(nb)]
-        st.frame_idx = {tuple(c): torch.tensor(c, dtype=torch.int32, device=dev) for ctx in st.global_context for c in ctx}
-        # EMO_FORCE_DIST=1: take the multi-GPU code path even at world_size 1 (single-GPU functional test of that path)
-        force_dist = bool(dist) and os.environ.get("EMO_FORCE_DIST") == "1"
-        st.dist_pre, st.rank_pre, st.world_pre = (bool(dist) and world_size > 1) or force_dist, rank, world_size
-        st.my_contexts = st.global_context[rank::world_size] if st.dist_pre else st.global_context          # :757
-        st.ctx_index = [[torch.tensor(c, dtype=torch.int64, device=dev) for c in ctx] for ctx in st.my_contexts]
+        st.windows = [list(map(int, c)) for c in scheduler_fn(0, num_inference_steps, st.f_tot, context_frames, context_stride, context_overlap)]
+        nf = len(st.windows[0])
+        if any(len(c) != nf for c in st.windows):
+            raise ValueError("context windows of unequal length")
+        st.nf = nf
+        nb = math.ceil(len(st.windows) / cbs)
+        st.global_context = [st.windows[i * cbs:(i + 1) * cbs] for i in range(nb)]      # the reference's window batches (:752-755)
+        # `noise_pred[:, :, c] = noise_pred[:, :, c] + pred` (:792-794) with a frame listed twice in c (wrapped windows at
+        # context_stride > 1) keeps ONE occurrence (the last write wins): positions of earlier duplicates are marked -1
+        st.frame_idx = []
+        for c in st.windows:
+            last = {k: j for j, k in enumerate(c)}
+            st.frame_idx.append(torch.tensor([k if last[k] == j else -1 for j, k in enumerate(c)], dtype=torch.int32, device=dev))
+        # ---- work units (SURVEY 8e): U = [(window, branch)], branch 0 = uncond, 1 = cond; rank r owns U[r::world].  A UNet
+        # call batches up to 2*cbs of the rank's units, uncond units first (they skip the reference banks, :243-256) - at
+        # world_size 1 that is exactly the reference's [uc x cbs, c x cbs] batch (:759-763).
+        st.dist = bool(dist)
+        st.rank, st.world_size = (int(rank), int(world_size)) if st.dist else (0, 1)
+        st.units = [(w, br) for w in range(len(st.windows)) for br in (0, 1)]
+        mine = st.units[st.rank::st.world_size]
+        st.n_slots = -(-len(st.units) // st.world_size)                    # units per rank, padded
+        st.calls = []
+        for i in range(0, len(mine), 2 * cbs):
+            chunk = mine[i:i + 2 * cbs]
+            order = [k for k, u in enumerate(chunk) if u[1] == 0] + [k for k, u in enumerate(chunk) if u[1] == 1]
+            call = SimpleNamespace(units=[chunk[k] for k in order], slots=[i + k for k in order])
+            call.n_uc = sum(1 for u in call.units if u[1] == 0)
+            call.idx = [torch.tensor(st.windows[w], dtype=torch.int64, device=dev) for w, _ in call.units]
+            st.calls.append(call)
         st.t_table = torch.tensor(st.timesteps, dtype=torch.int64, device=dev)   # INT timestep table, bit-exact
         st.t_buf = torch.zeros(1, dtype=torch.int64, device=dev)
-        st.use_graphs, st.graphs, st.graph_pool = bool(use_graphs), {}, None
-        st.overlap, st.side, st.writer_pool, st.unet_state = False, None, None, {}
+        st.use_graphs, st.graphs = bool(use_graphs), {}
+        st.graph_pool = st.writer_pool = None
         if st.use_graphs:
             st.graph_pool = torch.cuda.graph_pool_handle()
-            st.writer_pool = torch.cuda.graph_pool_handle()   # own pool: the write pass may run concurrently with the down path
-            st.overlap = (not st.dist_pre) and fusion_blocks == "midup" and os.environ.get("EMO_NO_OVERLAP") != "1"
-            st.side = torch.cuda.Stream() if st.overlap else None
+            st.writer_pool = torch.cuda.graph_pool_handle()   # own pool: the ReferenceNet pass runs concurrently with the Backbone
+        # ---- contexts of the attn2 layers: their K / V^T projections depend on the context only -> once per clip
         if audio_features is not None:
-            audio_features = audio_features.to(dev)
+            audio_features = audio_features.to(dev).float()
+        st.audio_features = audio_features
+        se = speed_embeddings
+        if se is not None:
+            se = se.to(dev).float()
+            if se.shape[0] not in (1, 2):
+                raise ValueError("speed_embeddings must have 1 row (shared) or 2 rows [uncond, cond]")
+        for call in st.calls:
+            if audio_features is None:
+                call.ctx = torch.cat([st.text[br:br + 1] for _, br in call.units])                       # (n, L, D)
+            else:   # per-frame audio context; uncond units get a zero context (design choice, SURVEY A17)
+                parts = []
+                for (w, br), ix in zip(call.units, call.idx):
+                    a = audio_features.index_select(0, ix)
+                    parts.append(a if br == 1 else torch.zeros_like(a))
+                call.ctx = torch.cat(parts)                                                              # (n*F, L_a, D)
+            call.ctx_kv = unet.context_kv(call.ctx)
+            call.speed = None if se is None else torch.cat([se[(br if se.shape[0] == 2 else 0):(br if se.shape[0] == 2 else 0) + 1]
+                                                            for _, br in call.units])
+        st.text_c = st.text[1:2]
+        st.ref_ctx_kv = appearance_encoder.context_kv(st.text_c)
+        # ---- eps hand-off: every unit's rows (nf*HW, C4); slot = position in the rank's unit list
+        st.send = torch.zeros(st.n_slots, nf * st.HW, st.C4, device=dev, dtype=unet.dtype)
+        st.recv = torch.zeros(st.world_size, st.n_slots, nf * st.HW, st.C4, device=dev, dtype=unet.dtype) if st.dist else None
         st.noise_pred = torch.empty(2, st.C4, st.f_tot, st.HW, device=dev, dtype=torch.float32)
         st.counter = torch.empty(st.f_tot, device=dev, dtype=torch.float32)
         st.guidance_scale, st.eta, st.seed = guidance_scale, eta, seed
-        st.audio_features, st.speed_embeddings = audio_features, speed_embeddings
-        st.dist, st.rank, st.world_size = (bool(dist) and world_size > 1) or force_dist, rank, world_size
-        st.t_ref = torch.zeros(1, dtype=torch.int64, device=dev)   # timestep of the ReferenceNet pass this rank computes
         st.return_eps, st.eps_trace = return_eps, []
-        st.bank_group, st.bank_shapes, st.bank_group_start, st.bank_now = None, None, -1, None
+        # ---- ReferenceNet groups: the banks depend on the timestep only (never on the latents): T timesteps per pass
+        T = max(1, min(int(reference_group), n_steps))
+        st.T = T
+        st.groups = [list(range(i, min(i + T, n_steps))) for i in range(0, n_steps, T)]
+        st.ref_t = torch.zeros(T, dtype=torch.int64, device=dev)
+        st.row_table = torch.tensor([((s_ // T) % 2) * T + s_ % T for s_ in range(n_steps)], dtype=torch.int32, device=dev)
+        st.bank_idx = torch.zeros(1, dtype=torch.int32, device=dev)
+        st.kv_all, st.group_ready, st.group_pending = None, -1, -1
+        st.ref_sel, st.ref_recv, st.ref_gath, st.bank_pg = {}, {}, {}, None
+        spec_r = appearance_encoder.spec
+        chan = {a.prefix: a.channels for blk in spec_r.down + [spec_r.mid] + spec_r.up for a in blk.attentions if a is not None}
+        st.bank_C = [chan[p] for p in st.writer.order]
+        if st.dist and st.world_size > 1:
+            import torch.distributed as td
+            st.bank_pg = td.new_group(ranks=list(range(st.world_size)))
+        st.lookahead = bool(reference_lookahead) and dev.type == "cuda"
+        st.side = torch.cuda.Stream() if st.lookahead else None
         # ControlNet branch (EMOAnimationPipeline.py:643-650,678-679,718-746): (F_tot,3,H,W) conditioning images in [0,1]
         st.controlnet = controlnet
         if controlnet is not None:
@@ -155,49 +194,110 @@ class EMOAnimationPipeline:
                 raise ValueError("controlnet_cond must hold one (3,H,W) conditioning image per frame")
             st.cn_scale = float(controlnet_conditioning_scale)
             st.cn_cond = controlnet_cond.to(dev).float()
-            # the frames this rank's windows touch; residuals are computed once per frame and step, in chunks of
+            # the frames this rank's units touch; residuals are computed once per frame and step, in chunks of
             # context_frames (the reference caches them per frame from overlap-0 windows: the network is per-frame, so
             # the chunking does not enter the result)
-            need = sorted({k for ctx in st.my_contexts for c in ctx for k in c})
-            st.cn_frames = need
+            need = sorted({k for call in st.calls for w, _ in call.units for k in st.windows[w]})
             st.cn_pos = {k: i for i, k in enumerate(need)}
             st.cn_chunks = [torch.tensor(need[i:i + context_frames], dtype=torch.int64, device=dev) for i in range(0, len(need), context_frames)]
-            st.cn_text = st.text[st.text.shape[0] // 2:][:1]        # cond text embedding (:678-679)
-            st.cn_sel = [[torch.tensor([st.cn_pos[k] for c in ctx for k in c], dtype=torch.int64, device=dev)] for ctx in st.my_contexts]
+            st.cn_text = st.text_c                                   # cond text embedding (:678-679)
+            for call in st.calls:
+                call.cn_sel = torch.tensor([st.cn_pos[k] for w, _ in call.units for k in st.windows[w]], dtype=torch.int64, device=dev)
             st.cn_down, st.cn_mid = None, None
         return st
 
-    def _exchange_banks(self, st, si):
-        """Multi-GPU ReferenceNet hand-off.  The write pass depends on the timestep only, so the ranks deal
-        the passes of the next `world_size` steps among themselves (rank r computes step si+r) and swap the
-        packed banks with ONE all_gather over xGMI - each rank runs the ReferenceNet once per world_size
-        steps instead of every step (the reference recomputes it on every rank, :711-716)."""
-        import torch.distributed as td
-        ws = st.world_size
-        mine = min(si + st.rank, len(st.timesteps) - 1)   # tail group: surplus ranks recompute the last step (unused)
-        st.t_ref.copy_(st.t_table[mine:mine + 1], non_blocking=True)
-        # the pass goes through the same warm -> capture -> replay sequence as the UNet parts (its ~450 launches cost
-        # ~20 ms of host time when enqueued from Python)
-        self._run(st, "writer_dist", lambda: self._part_writer_dist(st), pool=st.writer_pool)
-        send = st.send
-        recv = torch.empty(ws * send.numel(), device=send.device, dtype=send.dtype)   # flat: valid for RCCL and gloo
-        td.all_gather_into_tensor(recv, send)
-        st.bank_group, st.bank_group_start = recv.view(ws, send.numel()), si
-        if getattr(st, "bank_now", None) is None:
-            st.bank_now = torch.empty_like(send)
+    # ---- ReferenceNet: one batched write pass per GROUP of timesteps, one group ahead of the Backbone on a second stream
+    def _ref_sel(self, st, Tg):
+        """group-local timestep indices this rank computes (rank r: r, r+world, ...; padded by repeating the last one)"""
+        if Tg not in st.ref_sel:
+            n = -(-Tg // st.world_size)
+            mine = [min(st.rank + i * st.world_size, Tg - 1) for i in range(n)]
+            st.ref_sel[Tg] = torch.tensor(mine, dtype=torch.int64, device=st.ref_t.device)
+        return st.ref_sel[Tg]
 
-    def _part_writer_dist(self, st):
-        self._write_banks(st.appearance_encoder, st.writer, st.ref_rep, st.t_ref, st.text)
-        st.bank_shapes = [tuple(st.writer.bank[p][0].shape) for p in st.writer.order]
-        st.send = self._pack_banks(st.writer)
+    def _part_reference_write(self, st, Tg):
+        """ReferenceNet write pass (:711-716) on the cond-text copy of the reference image for this rank's share of the group's
+        timesteps, batched: (n,4,h,w) with one timestep per row.  The reference runs [uncond-text, cond-text] copies every
+        step, but the reader never uses the uncond bank row (for the uc rows `hidden_states_c` is overwritten by the bank-free
+        uc attention, mutual_self_attention.py:243-256) and the ReferenceNet is batch-independent.  Banks are rounded through
+        fp16 like reader.update() does (:588) and packed for the exchange."""
+        t = st.ref_t[:Tg] if st.world_size == 1 else st.ref_t.index_select(0, self._ref_sel(st, Tg))
+        n = t.numel()
+        st.writer.clear()
+        st.appearance_encoder(st.ref_lat.expand(n, -1, -1, -1), t, encoder_hidden_states=st.text_c, return_dict=False,
+                              _ctx_kv=st.ref_ctx_kv)
+        tgt = self.unet.dtype
+        st.bank_L = [st.writer.bank[p][0].shape[1] for p in st.writer.order]
+        banks = [ops.convert(st.writer.bank[p][0], tgt, fp16_round=True).reshape(n, -1) for p in st.writer.order]
+        st.writer.clear()                                                                      # :823
+        st.bank_pack = banks if st.world_size == 1 else torch.cat(banks, dim=1)                # (n, total) plumbing copy
 
-    # ---- the two GPU-heavy parts of a step; both read the timestep from the device buffer st.t_buf so that they
-    #      can be captured once into HIP graphs and replayed for the other 49 steps
-    def _part_writer(self, st):
-        self._write_banks(st.appearance_encoder, st.writer, st.ref_rep, st.t_buf, st.text)    # :711-716
+    def _part_reference_project(self, st, Tg):
+        """K / V^T projections of the group's banks with the BACKBONE's attn1.to_k / to_v (the read side of
+        mutual_self_attention.py:238-241), once per group instead of once per step."""
+        st.stage = {}
+        off = 0
+        for i, (pr, L, C_) in enumerate(zip(st.reader.order, st.bank_L, st.bank_C)):
+            if st.world_size == 1:
+                rows = st.bank_pack[i]
+            else:   # bank i occupies columns [off, off + L*C) of every gathered row (rows in group order)
+                rows = st.ref_gath[Tg][:Tg, off:off + L * C_].contiguous()
+                off += L * C_
+            k, vt = self.unet.bank_kv(pr, rows.reshape(-1, C_), L)
+            st.stage[pr] = (k, vt, L)
 
+    def _reference_group(self, st, g):
+        """Compute group g's projected banks on the CURRENT stream and store them in slot g % 2 of the resident cache."""
+        steps = st.groups[g]
+        Tg, T, slot = len(steps), st.T, g % 2
+        st.ref_t[:Tg].copy_(st.t_table[steps[0]:steps[0] + Tg], non_blocking=True)
+        self._run(st, ("ref_write", Tg), lambda: self._part_reference_write(st, Tg), pool=st.writer_pool)
+        if st.world_size > 1:
+            # north_star: "RCCL all-gather over xGMI to broadcast ReferenceNet features" - rank r computed timesteps
+            # r, r+world, ... of the group; ONE all_gather hands every rank every timestep's banks (own communicator: the
+            # exchange rides the side stream and must not queue in front of the per-step eps all_gather)
+            import torch.distributed as td
+            send = st.bank_pack
+            n = send.shape[0]
+            if Tg not in st.ref_gath:
+                st.ref_recv[Tg] = torch.empty(st.world_size * n, send.shape[1], device=send.device, dtype=send.dtype)
+                st.ref_gath[Tg] = torch.empty(st.world_size * n, send.shape[1], device=send.device, dtype=send.dtype)
+            td.all_gather_into_tensor(st.ref_recv[Tg].view(-1), send.contiguous().view(-1), group=st.bank_pg)
+            # row (rank r, slot i) is group-local timestep i*world + r -> group order
+            st.ref_gath[Tg].view(n, st.world_size, -1).copy_(st.ref_recv[Tg].view(st.world_size, n, -1).transpose(0, 1))
+        self._run(st, ("ref_project", Tg), lambda: self._part_reference_project(st, Tg), pool=st.writer_pool)
+        if st.kv_all is None:   # resident cache: two groups of T timesteps per block
+            st.kv_all = {}
+            for pr, (k, vt, L) in st.stage.items():
+                st.kv_all[pr] = (torch.zeros(2 * T * L, k.shape[1], device=k.device, dtype=k.dtype),
+                                 torch.zeros(2 * T, vt.shape[1], vt.shape[2], device=vt.device, dtype=vt.dtype), L)
+        dsts, srcs = [], []
+        for pr, (k, vt, L) in st.stage.items():
+            ka, va, _ = st.kv_all[pr]
+            dsts += [ka[slot * T * L:slot * T * L + Tg * L], va[slot * T:slot * T + Tg]]
+            srcs += [k[:Tg * L], vt[:Tg]]
+        torch._foreach_copy_(dsts, srcs)
+
+    def _ensure_group(self, st, si):
+        """Group of step si resident (waiting for / computing it if needed), the NEXT group launched on the side stream."""
+        g = si // st.T
+        cuda = self.unet.device.type == "cuda"
+        main = torch.cuda.current_stream() if cuda else None
+        if st.group_ready != g:
+            if st.group_pending == g:
+                main.wait_stream(st.side)
+            else:
+                self._reference_group(st, g)
+            st.group_ready, st.group_pending = g, -1
+            if g + 1 < len(st.groups) and st.lookahead:
+                # slot (g+1) % 2 held group g-1: every step of it is already enqueued on the main stream
+                st.side.wait_stream(main)
+                with torch.cuda.stream(st.side):
+                    self._reference_group(st, g + 1)
+                st.group_pending = g + 1
+
+    # ---- ControlNet (per-frame residual cache of the step, :718-746)
     def _part_controlnet(self, st):
-        """Per-frame ControlNet residuals of this step (:718-746)."""
         downs, mids = [], []
         for idx in st.cn_chunks:
             x = self.scheduler.scale_model_input(st.latents.index_select(2, idx), None)[0].permute(1, 0, 2, 3).contiguous()
@@ -208,69 +308,38 @@ class EMOAnimationPipeline:
         st.cn_down = [torch.cat([d[i] for d in downs]) for i in range(len(downs[0]))]
         st.cn_mid = torch.cat(mids)
 
-    def _controlnet_residuals(self, st, ci):
-        """select_controlnet_res_samples (:514-540): frames of the window batch, '(b f) c h w -> b c f h w', CFG repeat."""
+    def _controlnet_residuals(self, st, call):
+        """select_controlnet_res_samples (:514-540): frames of the call's units, '(b f) c h w -> b c f h w' (the CFG repeat of
+        the reference is the uncond and the cond unit of a window selecting the same frames)."""
         if st.controlnet is None:
             return {}
-        sel = st.cn_sel[ci][0]
-        nb, nf = len(st.my_contexts[ci]), len(st.my_contexts[ci][0])
+        n, nf = len(call.units), st.nf
 
         def to5(t):
-            y = t.index_select(0, sel)
-            return y.reshape(nb, nf, *y.shape[1:]).permute(0, 2, 1, 3, 4).repeat(2, 1, 1, 1, 1)
+            y = t.index_select(0, call.cn_sel)
+            return y.reshape(n, nf, *y.shape[1:]).permute(0, 2, 1, 3, 4)
         return dict(down_block_additional_residuals=tuple(to5(t) for t in st.cn_down), mid_block_additional_residual=to5(st.cn_mid))
 
-    def _unet_inputs(self, st, ci):
-        dev = self.unet.device
-        idx = st.ctx_index[ci]                                                               # device int64 frame indices
-        x = torch.cat([st.latents.index_select(2, i) for i in idx]).repeat(2, 1, 1, 1, 1)    # :759-763 (index/copy only)
-        x = self.scheduler.scale_model_input(x, None)
-        af = None
-        if st.audio_features is not None:   # per-frame audio context; uc rows get a zero context
-            cond = torch.cat([st.audio_features.index_select(0, i) for i in idx])
-            af = torch.cat([torch.zeros_like(cond), cond])
-        return x, af
-
-    def _accumulate(self, st, ci, rows):
-        context = st.my_contexts[ci]
-        nf = len(context[0])
-        for j, c in enumerate(context):                                                       # :790-794
-            fr = st.frame_idx[tuple(c)]
-            for branch in (0, 1):
-                bi = branch * len(context) + j
-                ops.accumulate_window(rows[bi * nf * st.HW:(bi + 1) * nf * st.HW], st.noise_pred[branch], st.counter, fr,
-                                      C_=st.C4, F=st.f_tot, HW=st.HW, add_counter=(branch == 0))
-
-    def _update_reader(self, st):
-        if st.writer.order and not all(st.writer.bank[p] for p in st.writer.order):
-            raise RuntimeError("ReferenceNet banks are empty at reader.update(): the write pass must run (or be captured) "
-                               "in the same step as its consumer")
-        st.reader.update(st.writer)                                                           # :774
-
+    # ---- one UNet call = the rank's next <= 2*cbs units; reads the timestep from the device buffer st.t_buf and the bank row
+    #      from st.bank_idx, so it is captured once into a HIP graph and replayed for the other steps
     def _part_unet(self, st, ci):
-        x, af = self._unet_inputs(st, ci)
-        self._update_reader(st)
-        rows = self.unet(x, st.t_buf, encoder_hidden_states=st.text[:x.shape[0]], audio_features=af,
-                         speed_embeddings=st.speed_embeddings, return_dict=False, _return_rows=True,
-                         **self._controlnet_residuals(st, ci))                                # :777-786
-        st.reader.clear()                                                                     # :788
-        self._accumulate(st, ci, rows)
+        call = st.calls[ci]
+        x = torch.cat([st.latents.index_select(2, ix) for ix in call.idx])                     # :759-763 (index/copy only)
+        x = self.scheduler.scale_model_input(x, None)
+        st.reader.set_projected_banks(st.kv_all, st.bank_idx, call.n_uc)                       # replaces reader.update (:774)
+        rows = self.unet(x, st.t_buf, encoder_hidden_states=call.ctx, speed_embeddings=call.speed, return_dict=False,
+                         _return_rows=True, _ctx_kv=call.ctx_kv, **self._controlnet_residuals(st, call))   # :777-786
+        n_rows = st.nf * st.HW
+        for k, slot in enumerate(call.slots):
+            st.send[slot].copy_(rows[k * n_rows:(k + 1) * n_rows])
 
-    # the same pass split at the first use of the reference banks (fusion 'midup': mid block): the down path does not
-    # depend on the ReferenceNet, so it overlaps the write pass running on a second HIP stream
-    def _part_unet_down(self, st, ci):
-        x, af = self._unet_inputs(st, ci)
-        s = self.unet._begin(x, st.t_buf, st.text[:x.shape[0]], af, st.speed_embeddings, **self._controlnet_residuals(st, ci))
-        self.unet._run_down(s)
-        st.unet_state[ci] = s
-
-    def _part_unet_rest(self, st, ci):
-        s = st.unet_state[ci]
-        self._update_reader(st)
-        st.reader._prepare(s.c, self.unet)
-        rows = self.unet._run_rest(s, return_rows=True)
-        st.reader.clear()                                                                     # :788
-        self._accumulate(st, ci, rows)
+    def _accumulate_all(self, st):
+        """noise_pred[:, :, c] += pred; counter[:, :, c] += 1 (:790-794) over EVERY unit in global order - each rank does this
+        redundantly on the gathered rows, so the accumulators (and the latents) are bit-identical on all ranks."""
+        for i, (w, br) in enumerate(st.units):
+            rows = st.send[i] if not st.dist else st.recv[i % st.world_size, i // st.world_size]
+            ops.accumulate_window(rows, st.noise_pred[br], st.counter, st.frame_idx[w], C_=st.C4, F=st.f_tot, HW=st.HW,
+                                  add_counter=(br == 0))
 
     def _run(self, st, key, fn, pool=None):
         """Eager on first use (warm-up: lazy kernel attributes, allocator), HIP-graph capture on the second, replay after.
@@ -298,52 +367,25 @@ class EMOAnimationPipeline:
         sch = self.scheduler
         dev = self.unet.device
         t = st.timesteps[si]
-        st.t_buf.copy_(st.t_table[si:si + 1], non_blocking=True)     # device-to-device: the INT timestep of this step
+        self._ensure_group(st, si)                                     # :711-716, hoisted: banks of T timesteps per pass
+        st.t_buf.copy_(st.t_table[si:si + 1], non_blocking=True)       # device-to-device: the INT timestep of this step
+        st.bank_idx.copy_(st.row_table[si:si + 1], non_blocking=True)  # ... and its row in the resident bank cache
         st.noise_pred.zero_()
         st.counter.zero_()
-        if st.controlnet is not None:   # per-frame residual cache of this step (:718-746), before any UNet part needs it
+        if st.controlnet is not None and st.calls:   # per-frame residual cache of this step (:718-746)
             self._run(st, "controlnet", lambda: self._part_controlnet(st))
-        overlap = st.overlap
-        if overlap:
-            # ReferenceNet write pass  ||  bank-independent Backbone down path.  All three parts go through the same
-            # warm -> capture -> replay sequence IN THE SAME STEPS, so the reader/writer bank lists are populated when the
-            # consumers are captured (a graph replay does not re-run the Python bank bookkeeping).  The second stream is
-            # only used once graphs exist (eager allocations must not cross streams).
-            use_side = st.graphs.get("writer") is not None and ops.PROFILER is None
-            main = torch.cuda.current_stream()
-            if use_side:
-                st.side.wait_stream(main)
-                with torch.cuda.stream(st.side):
-                    self._run(st, "writer", lambda: self._part_writer(st), pool=st.writer_pool)
-            else:
-                self._run(st, "writer", lambda: self._part_writer(st), pool=st.writer_pool)
-            for ci in range(len(st.my_contexts)):
-                self._run(st, ("down", ci), lambda ci=ci: self._part_unet_down(st, ci))
-            if use_side:
-                main.wait_stream(st.side)
-            for ci in range(len(st.my_contexts)):
-                self._run(st, ("rest", ci), lambda ci=ci: self._part_unet_rest(st, ci))
-        elif not st.dist:
-            self._run(st, "writer", lambda: self._part_writer(st), pool=st.writer_pool)
-        else:
-            if st.bank_group is None or si >= st.bank_group_start + st.world_size or si < st.bank_group_start:
-                self._exchange_banks(st, si)
-            st.bank_now.copy_(st.bank_group[si - st.bank_group_start])   # static buffer: graph-stable addresses
-            self._unpack_banks(st.bank_now, st.writer, st.bank_shapes)
-        if not overlap:
-            for ci in range(len(st.my_contexts)):                                              # :757
-                self._run(st, ("unet", ci), lambda ci=ci: self._part_unet(st, ci))
-        if st.dist:                                                                            # replaces :796-809 + :819-821
+        for ci in range(len(st.calls)):                                                        # :757
+            self._run(st, ("unet", ci), lambda ci=ci: self._part_unet(st, ci))
+        if st.dist:   # replaces gather-to-root (:796-809) + broadcast (:819-821): ONE all_gather of the eps slices
             import torch.distributed as td
-            td.all_reduce(st.noise_pred)
-            td.all_reduce(st.counter)
+            td.all_gather_into_tensor(st.recv.view(-1), st.send.view(-1))
+        self._accumulate_all(st)
         c_x, c_eps, c_n = sch.coefficients(t, st.eta) if isinstance(sch, DDIMScheduler) else sch.coefficients(t)
         eps_out = torch.empty(st.C4 * st.f_tot * st.HW, device=dev, dtype=torch.float32) if st.return_eps else None
         ops.cfg_step(st.noise_pred, st.counter, st.latents, C_=st.C4, F=st.f_tot, HW=st.HW, guidance_scale=st.guidance_scale,
                      c_x=c_x, c_eps=c_eps, c_noise=c_n, seed=st.seed, step=si, eps_out=eps_out)  # :812-817 fused
         if st.return_eps:
             st.eps_trace.append(eps_out.view(1, st.C4, st.f_tot, st.h, st.w))
-        st.writer.clear()                                                                      # :823
 
     @torch.no_grad()
     def denoise(self, latents, ref_image_latents, text_embeddings, *, num_actual_inference_steps=None, callback=None,

@@ -34,7 +34,15 @@ class ReferenceAttentionControl:
         self.batch_size = batch_size
         self.order = unet.bank_order(fusion_blocks) if reference_attn else []
         self.bank = {p: [] for p in self.order}   # per block: list of (B_ref, L, C) tensors
+        self.kv_cache, self.kv_row, self.uc_units = None, None, 0
         unet._reference_control = self
+
+    def set_projected_banks(self, cache, row_index, uc_units):
+        """Fast path of the sampling loop (read mode).  `cache`: {block prefix: (K rows, V^T, L)} - the bank K / V^T
+        projections of a whole GROUP of timesteps, resident in HBM; `row_index`: device int32 word naming the row (timestep)
+        in use; `uc_units`: leading batch rows of the next UNet call that skip the bank (uncond units, :243-256).  The
+        per-step `update()` / bank lists are bypassed; pass cache=None to return to them."""
+        self.kv_cache, self.kv_row, self.uc_units = cache, row_index, uc_units
 
     # ---- hooks called by UNet3DConditionModel.forward
     def _prepare(self, c, unet):
@@ -42,6 +50,10 @@ class ReferenceAttentionControl:
             return
         c.active = set(self.order)
         c.bank_mode = self.mode
+        if self.mode == "read" and self.kv_cache is not None:
+            c.bank_kv, c.bank_row = self.kv_cache, self.kv_row
+            c.uc_batches = self.uc_units * c.F
+            return
         if self.mode == "read":
             nb = c.B * c.F
             c.uc_batches = (c.B // 2) * c.F if self.do_classifier_free_guidance else 0  # uc_mask (:186-197,245-250)

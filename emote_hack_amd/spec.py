@@ -33,6 +33,10 @@ class TransformerSpec:
     heads: int
     ctx_dim: int
     linear_proj: bool
+    # ReferenceNet only (magicanimate/models/appearance_encoder.py:613-621): the LAST transformer of the up path keeps norm,
+    # proj_in and norm1 (whose output is the last bank) and nothing else - attn1 projections are parameter-less, attn2 is None,
+    # norm2 / norm3 / ff / proj_out are Identity.  Everything behind its LN1 is dead (the ReferenceNet output is discarded).
+    gutted: bool = False
 
 
 @dataclass
@@ -65,7 +69,7 @@ class UNetSpec:
     controlnet: Optional[tuple] = None   # ControlNet: conditioning-embedding channels (16, 32, 96, 256); no up path
 
 
-def build_spec(cfg_kwargs, *, has_out=True, controlnet=None) -> UNetSpec:
+def build_spec(cfg_kwargs, *, has_out=True, controlnet=None, gut_last_transformer=False) -> UNetSpec:
     cfg = normalize_unet_config(dict(cfg_kwargs), strict=False)
     boc = cfg["block_out_channels"]
     temb = boc[0] * 4
@@ -134,6 +138,10 @@ def build_spec(cfg_kwargs, *, has_out=True, controlnet=None) -> UNetSpec:
         if i != n - 1:
             b.sampler = f"{b.prefix}.upsamplers.0"
         up.append(b)
+    if gut_last_transformer:   # appearance_encoder.py:613-621 names up_blocks[3].attentions[2]: the last transformer of the up path
+        last = [a for b in up for a in b.attentions if a is not None]
+        if last:
+            last[-1].gutted = True
     return UNetSpec(cfg, down, mid, up, has_out)
 
 
@@ -176,6 +184,10 @@ def _transformer_shapes(t: TransformerSpec, d):
     d[f"{p}.proj_in.weight"] = (c, c) if t.linear_proj else (c, c, 1, 1)
     d[f"{p}.proj_in.bias"] = (c,)
     tb = f"{p}.transformer_blocks.0"
+    if t.gutted:   # key order of the reference module tree: attn1 (no parameters left), norm1
+        d[f"{tb}.norm1.weight"] = (c,)
+        d[f"{tb}.norm1.bias"] = (c,)
+        return
     _attn_shapes(f"{tb}.attn1", c, c, d)
     d[f"{tb}.norm1.weight"] = (c,)
     d[f"{tb}.norm1.bias"] = (c,)

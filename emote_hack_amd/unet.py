@@ -52,6 +52,8 @@ class _Ctx:
         self.written = {}
         self.uc_batches = 0         # number of leading (b f) batches that skip the bank
         self.bank_skip = 0          # leading bank rows that were not materialised (cond-only ReferenceNet pass under CFG)
+        self.bank_kv = {}           # prefix -> (K rows, V^T, L): bank projections precomputed by the sampler
+        self.bank_row = None        # device int32 word: the row of bank_kv in use
         self.active = ()
 
 
@@ -59,12 +61,17 @@ class _State:
     """activations handed between the three forward stages"""
 
 
+_STOP = object()   # returned by the gutted last transformer of the ReferenceNet: the rest of the pass is dead
+
+
 class UNet3DConditionModel:
     def __init__(self, **kwargs):
         self._has_out = kwargs.pop("_has_out", True)
         self._controlnet = kwargs.pop("_controlnet", None)   # ControlNetModel: conditioning-embedding channels
+        self._gut_last = kwargs.pop("_gut_last_transformer", False)   # AppearanceEncoderModel (appearance_encoder.py:613-621)
         self.config: FrozenConfig = normalize_unet_config(kwargs)
-        self.spec: UNetSpec = build_spec(self.config, has_out=self._has_out, controlnet=self._controlnet)
+        self.spec: UNetSpec = build_spec(self.config, has_out=self._has_out, controlnet=self._controlnet,
+                                         gut_last_transformer=self._gut_last)
         self.sample_size = self.config["sample_size"]
         self.in_channels = self.config["in_channels"]
         self.num_upsamplers = len(self.config["block_out_channels"]) - 1
@@ -91,10 +98,14 @@ class UNet3DConditionModel:
         return {k: v.detach().cpu() for k, v in self._master.items()}
 
     def load_state_dict(self, sd, strict=True):
+        """torch semantics: returns (missing, unexpected) relative to the INCOMING dict; strict raises on either.  Partial
+        loads accumulate (the reference workflow is from_pretrained_2d(strict=False) followed by a second strict=False load of
+        the motion-module checkpoint, animation.py:116-135); the model (re-)packs whenever the merged master is complete."""
         missing = [k for k in self._shapes if k not in sd]
         unexpected = [k for k in sd if k not in self._shapes]
         if strict and (missing or unexpected):
-            raise RuntimeError(f"load_state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
+            raise RuntimeError(f"Error(s) in loading state_dict: {len(missing)} missing key(s) {missing[:5]}, "
+                               f"{len(unexpected)} unexpected key(s) {unexpected[:5]}")
         for k, shp in self._shapes.items():
             if k in sd and tuple(sd[k].shape) != tuple(shp):
                 raise RuntimeError(f"size mismatch for {k}: {tuple(sd[k].shape)} vs {tuple(shp)}")
@@ -103,9 +114,13 @@ class UNet3DConditionModel:
             if k in sd:
                 master[k] = sd[k].detach().to(torch.float32)
         self._master = master
-        if not missing:
+        self._w = None                      # packed weights are stale from here on
+        if not self._absent_keys():
             self._pack()
         return missing, unexpected
+
+    def _absent_keys(self):
+        return [k for k in self._shapes if self._master is None or k not in self._master]
 
     def to(self, *args, **kwargs):
         device, dtype = kwargs.get("device"), kwargs.get("dtype")
@@ -120,7 +135,7 @@ class UNet3DConditionModel:
             self.dtype = dtype
         if device is not None:
             self.device = torch.device(device)
-        if self._master is not None:
+        if self._master is not None and not self._absent_keys():
             self._pack()
         return self
 
@@ -160,6 +175,10 @@ class UNet3DConditionModel:
     def _pack(self):
         if self.device.type != "cuda":
             return  # packed on the first .to('cuda'); the product path has no CPU execution
+        absent = self._absent_keys()
+        if absent:
+            raise EmoHipError(f"UNet3DConditionModel: {len(absent)} parameter(s) were never loaded, e.g. {absent[:5]} "
+                              "(load_state_dict(strict=False) leaves the model unusable until every key has a value)")
         dev, dtp = self.device, self.dtype
         m = {k: v.to(dev) for k, v in self._master.items()}
         self._master = m
@@ -220,6 +239,9 @@ class UNet3DConditionModel:
                 tb = p + ".transformer_blocks.0"
                 w[p + ".norm.g"], w[p + ".norm.b"] = f32(p + ".norm.weight"), f32(p + ".norm.bias")
                 w[p + ".proj_in.w"], w[p + ".proj_in.b"] = lin(p + ".proj_in.weight"), f32(p + ".proj_in.bias")
+                if a.gutted:   # ReferenceNet's last transformer: norm, proj_in, norm1 only
+                    w[f"{tb}.norm1.g"], w[f"{tb}.norm1.b"] = f32(f"{tb}.norm1.weight"), f32(f"{tb}.norm1.bias")
+                    continue
                 w[p + ".proj_out.w"], w[p + ".proj_out.b"] = lin(p + ".proj_out.weight"), f32(p + ".proj_out.bias")
                 for n_ in ("norm1", "norm2", "norm3"):
                     w[f"{tb}.{n_}.g"], w[f"{tb}.{n_}.b"] = f32(f"{tb}.{n_}.weight"), f32(f"{tb}.{n_}.bias")
@@ -290,7 +312,31 @@ class UNet3DConditionModel:
         vt = ops.gemm(rows, wv, transpose_rows=L, transpose_ld=_round_up(L, 8))
         return k, vt
 
-    def _transformer(self, a, x, ctx_rows, ctx_len, ctx_div, c: _Ctx, H, W, out=None):
+    def transformer_prefixes(self):
+        return [a.prefix for blk in self.spec.down + [self.spec.mid] + self.spec.up for a in blk.attentions
+                if a is not None and not a.gutted]
+
+    def context_kv(self, ctx, dtype=None):
+        """attn2 K / V^T projections of a context (nb, L, D) for every transformer block: they depend on the context only
+        (orig_attention.py:594-600), not on the timestep or the latents, so a sampling loop computes them once per clip and
+        hands them to every step (`_ctx_kv=`).  Returns {prefix: (K rows, V^T)}."""
+        if self._w is None:
+            raise EmoHipError("context_kv: weights not loaded / model not on a HIP device")
+        ctx = ctx.to(self.device)
+        rows = ops.convert(ctx.float().reshape(-1, ctx.shape[2]), self.dtype)
+        out = {}
+        for p in self.transformer_prefixes():
+            tb = p + ".transformer_blocks.0"
+            out[p] = self._kv(rows, self._w[tb + ".attn2.k"], self._w[tb + ".attn2.v"], ctx.shape[1])
+        return out
+
+    def bank_kv(self, prefix, bank_rows, L):
+        """attn1 K / V^T projections of reference-bank rows (n*L, C) with THIS model's to_k / to_v
+        (mutual_self_attention.py:238-241: the bank is concatenated to the K/V input of attn1)."""
+        tb = prefix + ".transformer_blocks.0"
+        return self._kv(bank_rows, self._w[tb + ".attn1.k"], self._w[tb + ".attn1.v"], L)
+
+    def _transformer(self, a, x, ctx_rows, ctx_len, ctx_div, c: _Ctx, H, W, out=None, ctx_kv=None):
         """attention.py:112-161 + 276-320, and the write/read hooks of mutual_self_attention.py:199-284."""
         w, p = self._w, a.prefix
         tb = p + ".transformer_blocks.0"
@@ -304,20 +350,31 @@ class UNet3DConditionModel:
         n1 = ops.layer_norm(h, w[tb + ".norm1.g"], w[tb + ".norm1.b"])
         if c.bank_mode == "write" and p in c.active:
             c.written[p] = n1  # LN1 output (mutual_self_attention.py:230)
+        if a.gutted:
+            # ReferenceNet's last transformer (appearance_encoder.py:613-621): behind LN1 there are no parameters and the
+            # model's output is discarded - the pass ends here
+            return _STOP
         qk = ops.gemm(n1, w[tb + ".attn1.qk"])
         vt = ops.gemm(n1, w[tb + ".attn1.v"], transpose_rows=HW, transpose_ld=_round_up(HW, 8))
         kw = {}
-        if c.bank_mode == "read" and p in c.active and p in c.banks:
-            bank = c.banks[p]
-            Lb = bank.shape[0] // c.bank_rows
-            kb, vbt = self._kv(bank, w[tb + ".attn1.k"], w[tb + ".attn1.v"], Lb)
-            kw = dict(k1=kb, v1t=vbt, Lk1=Lb, seg1_div=c.F, seg1_first_batch=c.uc_batches, seg1_skip=c.bank_skip)
+        if c.bank_mode == "read" and p in c.active and (p in c.banks or p in c.bank_kv):
+            if p in c.bank_kv:    # projected once per group of timesteps by the sampler (pipeline._reference_group)
+                kb, vbt, Lb = c.bank_kv[p]
+                kw = dict(k1=kb, v1t=vbt, Lk1=Lb, seg1_div=nb, seg1_first_batch=c.uc_batches, seg1_row=c.bank_row)
+            else:
+                bank = c.banks[p]
+                Lb = bank.shape[0] // c.bank_rows
+                kb, vbt = self._kv(bank, w[tb + ".attn1.k"], w[tb + ".attn1.v"], Lb)
+                kw = dict(k1=kb, v1t=vbt, Lk1=Lb, seg1_div=c.F, seg1_first_batch=c.uc_batches, seg1_skip=c.bank_skip)
         att = ops.attention(qk[:, :C_], qk[:, C_:], vt, HW, B=nb, Lq=HW, heads=heads, d=d, scale=scale, **kw)
         h = ops.gemm(att, w[tb + ".attn1.o.w"], w[tb + ".attn1.o.b"], residual=h)
         # --- cross attention to the text / audio context
         n2 = ops.layer_norm(h, w[tb + ".norm2.g"], w[tb + ".norm2.b"])
         q2 = ops.gemm(n2, w[tb + ".attn2.q"])
-        kc, vct = self._kv(ctx_rows, w[tb + ".attn2.k"], w[tb + ".attn2.v"], ctx_len)
+        if ctx_kv is not None:
+            kc, vct = ctx_kv[p]
+        else:
+            kc, vct = self._kv(ctx_rows, w[tb + ".attn2.k"], w[tb + ".attn2.v"], ctx_len)
         att = ops.attention(q2, kc, vct, ctx_len, B=nb, Lq=HW, heads=heads, d=d, scale=scale, seg0_div=ctx_div)
         h = ops.gemm(att, w[tb + ".attn2.o.w"], w[tb + ".attn2.o.b"], residual=h)
         # --- GEGLU feed-forward
@@ -352,10 +409,12 @@ class UNet3DConditionModel:
     # ------------------------------------------------------------------ forward (three stages so that the sampler can
     # overlap the ReferenceNet pass with the bank-independent down path on a second HIP stream)
     def _begin(self, sample, timestep, encoder_hidden_states, audio_features=None, speed_embeddings=None,
-               down_block_additional_residuals=None, mid_block_additional_residual=None, add_after_conv_in=None):
+               down_block_additional_residuals=None, mid_block_additional_residual=None, add_after_conv_in=None, _ctx_kv=None):
         if self._w is None:
+            absent = self._absent_keys()
             raise EmoHipError("UNet3DConditionModel: weights not loaded / model not on a HIP device "
-                              "(load_state_dict + .to('cuda')); there is no CPU execution path")
+                              "(load_state_dict + .to('cuda')); there is no CPU execution path" +
+                              (f"; {len(absent)} parameter(s) have no value yet, e.g. {absent[:3]}" if absent and self._master else ""))
         if sample.dim() != 5:
             raise ValueError(f"Expected sample to have ndim=5, but got ndim={sample.dim()}.")
         cfg, w, dtp = self.config, self._w, self.dtype
@@ -392,10 +451,13 @@ class UNet3DConditionModel:
             s.ctx_div = 1
         elif ctx.shape[0] == B:
             s.ctx_div = F
+        elif ctx.shape[0] == 1 and _ctx_kv is not None:
+            s.ctx_div = B * F      # one context shared by every batch row (the sampler's batched ReferenceNet pass)
         else:
             raise ValueError(f"encoder_hidden_states batch {ctx.shape[0]} is neither B={B} nor B*F={B * F}")
         s.ctx_len = ctx.shape[1]
-        s.ctx_rows = ops.convert(ctx.float().reshape(-1, ctx.shape[2]), dtp)
+        s.ctx_kv = _ctx_kv        # {prefix: (K rows, V^T)} from context_kv(): attn2 projections hoisted out of the step
+        s.ctx_rows = None if _ctx_kv is not None else ops.convert(ctx.float().reshape(-1, ctx.shape[2]), dtp)
         s.ctrl = (down_block_additional_residuals, mid_block_additional_residual)
         x = ops.ncfhw_to_rows(sample, dtp, cpad=_round_up(Cin, 8))
         # Zero-copy skip connections: every skip tensor is produced straight into the RIGHT columns of the buffer the up
@@ -444,7 +506,7 @@ class UNet3DConditionModel:
                 slot = self._skip_slot(s, x.shape[0], r.cout)          # the sub-block's last op writes the skip in place
                 x = self._resnet(r, x, s.temb_all, c, h_, w_, out=slot if (a is None and mo is None) else None)
                 if a is not None:
-                    x = self._transformer(a, x, s.ctx_rows, s.ctx_len, s.ctx_div, c, h_, w_, out=slot if mo is None else None)
+                    x = self._transformer(a, x, s.ctx_rows, s.ctx_len, s.ctx_div, c, h_, w_, out=slot if mo is None else None, ctx_kv=s.ctx_kv)
                 if mo is not None:
                     x = self._motion(mo, x, c, h_, w_, out=slot)
                 self._push_skip(s, x)
@@ -462,7 +524,7 @@ class UNet3DConditionModel:
         spec, c, h_, w_ = self.spec, s.c, s.h, s.w
         sc = self.config["mid_block_scale_factor"]
         x = self._resnet(spec.mid.resnets[0], x, s.temb_all, c, h_, w_, sc)
-        x = self._transformer(spec.mid.attentions[0], x, s.ctx_rows, s.ctx_len, s.ctx_div, c, h_, w_)
+        x = self._transformer(spec.mid.attentions[0], x, s.ctx_rows, s.ctx_len, s.ctx_div, c, h_, w_, ctx_kv=s.ctx_kv)
         if spec.mid.motions[0] is not None:
             x = self._motion(spec.mid.motions[0], x, c, h_, w_)
         return self._resnet(spec.mid.resnets[1], x, s.temb_all, c, h_, w_, sc, out=out)
@@ -488,16 +550,20 @@ class UNet3DConditionModel:
                 slot = None if last else self._hidden_slot(s, skips, r.cout)
                 x = self._resnet(r, x, s.temb_all, c, h_, w_, out=slot if (a is None and mo is None) else None)
                 if a is not None:
-                    x = self._transformer(a, x, s.ctx_rows, s.ctx_len, s.ctx_div, c, h_, w_, out=slot if mo is None else None)
+                    x = self._transformer(a, x, s.ctx_rows, s.ctx_len, s.ctx_div, c, h_, w_, out=slot if mo is None else None, ctx_kv=s.ctx_kv)
+                    if x is _STOP:   # ReferenceNet: nothing behind the last bank write is ever read
+                        break
                 if mo is not None:
                     x = self._motion(mo, x, c, h_, w_, out=slot)
+            if x is _STOP:
+                break
             if blk.sampler:
                 x, h_, w_ = ops.conv3x3(x, w[blk.sampler + ".w"], w[blk.sampler + ".b"], B * F, h_, w_, upsample2x=True,
                                         out=None if not s.zero_copy or not skips else self._hidden_slot(s, skips, x.shape[1]))
         rc = self._reference_control
         if rc is not None:
             rc._finish(c, self)
-        if not spec.has_out:
+        if not spec.has_out or x is _STOP:
             return None
         x = ops.group_norm(x, w["conv_norm_out.g"], w["conv_norm_out.b"], B, cfg["norm_num_groups"], cfg["norm_eps"], True)
         x, _, _ = ops.conv3x3(x, w["conv_out.w"], w["conv_out.b"], B * F, h_, w_)
@@ -508,7 +574,7 @@ class UNet3DConditionModel:
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None,
                 down_block_additional_residuals: Optional[Tuple[torch.Tensor]] = None,
                 mid_block_additional_residual: Optional[torch.Tensor] = None, return_dict: bool = True,
-                audio_features=None, speed_embeddings=None, _return_rows=False) -> Union[UNet3DConditionOutput, Tuple]:
+                audio_features=None, speed_embeddings=None, _return_rows=False, _ctx_kv=None) -> Union[UNet3DConditionOutput, Tuple]:
         """unet_controlnet.py:328-483.  sample (B,C,F,h,w); timestep Tensor|int|float;
         encoder_hidden_states (B|B*F, L, D).  EMO extension kwargs (EMOAnimationPipeline.py:783-784):
         audio_features (B*F, L_a, D) per-frame attn2 context; speed_embeddings (B, 4*C0) added to emb."""
@@ -517,7 +583,7 @@ class UNet3DConditionModel:
         if class_labels is not None:
             raise NotImplementedError("class embeddings are outside the hot path")
         s = self._begin(sample, timestep, encoder_hidden_states, audio_features, speed_embeddings,
-                        down_block_additional_residuals, mid_block_additional_residual)
+                        down_block_additional_residuals, mid_block_additional_residual, _ctx_kv=_ctx_kv)
         if self._reference_control is not None:
             self._reference_control._prepare(s.c, self)
         self._run_down(s)

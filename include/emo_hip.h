@@ -152,6 +152,10 @@ typedef struct {
   int B; int Lq; int heads; int d;
   float scale;
   int dtype;
+  const int32_t* seg1_row;   /* optional DEVICE int32: when non-NULL every batch b >= seg1_first_batch reads bank row
+                                seg1_row[0] (seg1_div / seg1_skip unused).  A sampling loop keeps the projected banks of a
+                                whole group of timesteps resident and selects the current one by writing this word - the
+                                launch parameters (hence a captured hipGraph) stay the same from step to step. */
 } emo_attention_params;
 int emo_attention(const emo_attention_params* p, void* stream);
 
@@ -171,7 +175,10 @@ int emo_cfg_step(const float* noise_pred, const float* counter, float* latents, 
                  int HW, float guidance_scale, float c_x, float c_eps, float c_noise, uint32_t seed, uint32_t step,
                  void* stream);
 /* noise_pred[branch, :, frames[j]] += pred rows; counter[frames[j]] += 1 (EMOAnimationPipeline.py:790-794).
- * pred: rows ((j) h w, ld) in dtype for ONE branch of ONE window; frames: device int32 [nf]. */
+ * pred: rows ((j) h w, ld) in dtype for ONE branch of ONE window; frames: device int32 [nf].  The frames of a
+ * window must be distinct; a position with frames[j] < 0 is skipped (a wrapped window of the uniform scheduler with
+ * context_stride > 1 can list a frame twice: `noise_pred[:, :, c] = noise_pred[:, :, c] + pred` then keeps ONE
+ * occurrence - the host marks the others negative). */
 int emo_accumulate_window(const void* pred, int ld, float* noise_pred_branch, float* counter, const int32_t* frames,
                           int nf, int C, int F, int HW, int add_counter, int dtype, void* stream);
 

@@ -43,7 +43,7 @@ def test_ctypes_struct_layout_matches_header():
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     for cname, struct in (("emo_gemm_params", GemmParams), ("emo_attention_params", AttentionParams)):
         body = re.search(r"typedef struct \{((?:(?!typedef struct).)*?)\} " + cname, src, flags=re.S).group(1)
-        fields = re.findall(r"(?:const\s+)?(?:void|float|int64_t|uint32_t|int)\s*\*?\s*([A-Za-z_0-9]+)\s*;", body)
+        fields = re.findall(r"(?:const\s+)?(?:void|float|int64_t|uint32_t|int32_t|int)\s*\*?\s*([A-Za-z_0-9]+)\s*;", body)
         assert fields == [f[0] for f in struct._fields_], (cname, fields)
 
 
