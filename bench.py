@@ -8,17 +8,20 @@ classifier-free guidance 7.5 (uncond + cond branch batched), ReferenceNet on (mi
 modules at every resolution, text context (1,77,768), bf16, synthetic latents + name-keyed random weights of
 the SD-1.5 architecture (1277 M-parameter Backbone + 860 M-parameter ReferenceNet).
 
-A "step" = ONE iteration of the sampling loop over one batch of synthetic input: ReferenceNet write pass, bank
-hand-off, Backbone UNet forward on the CFG-doubled window, window accumulate, fused CFG + scheduler step -
-i.e. everything EMOAnimationPipeline.py:698-823 does per timestep.  Inputs are resident in HBM when the timed
-region starts.  value = frames / (num_inference_steps * seconds_per_step)   [whole job, all GPUs].
-Weak scaling: every GPU owns one 12-frame window of a 12*N-frame clip (context_frames=12, overlap 0); per step
-the ranks all_reduce the window accumulators, and the ReferenceNet passes are dealt round-robin over ranks and
-exchanged with one all_gather per N steps.
+A "step" = ONE iteration of the sampling loop over one batch of synthetic input: Backbone UNet forward on the rank's
+(window x CFG-branch) units, eps hand-off, window accumulate, fused CFG + scheduler step - everything
+EMOAnimationPipeline.py:698-823 does per timestep - plus its share of the ReferenceNet work: the write pass is batched
+over REF_GROUP = 10 timesteps (the banks depend on the timestep only) and launched once per 10 steps on a second stream,
+one group ahead of the Backbone.  Any window of K consecutive steps contains K/10 such passes (the driver's --steps 20
+contains two), i.e. exactly the per-step share of a full 50-step run; the final synchronise covers both streams.
+Inputs are resident in HBM when the timed region starts.  value = frames / (num_inference_steps * s_per_step), whole job.
+Weak scaling: an N-GPU run denoises a 12*N-frame clip as N windows = 2N (window x branch) units; rank r owns both
+branches of window r (U[r::N] of the branch-major unit list), one all_gather of the eps slices per step, a group's
+ReferenceNet timesteps dealt over the ranks + one all_gather of the banks per group.
 
 Adds to the JSON line:  "roofline" for the dominant kernel (live HIP-event timing of every launch of that
-kernel in the timed region; algorithmic FLOPs per launch = 2*M*N*K for the GEMM/conv kernel) and
-"cpu_baseline" (the CPU oracle timed on the host cores on a bounded sample, rank 0, N=1 only).
+kernel family in an eager pass right after the timed region; algorithmic FLOPs per launch = 2*M*N*K for the GEMM/conv
+kernel) and "cpu_baseline" (the CPU oracle timed on the host cores on a bounded sample, rank 0, N=1 only).
 """
 from __future__ import annotations
 
@@ -36,6 +39,7 @@ import torch  # noqa: E402
 MFMA_PEAK_BF16_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 NUM_INFERENCE_STEPS = 50
+REF_GROUP = 10
 # algorithmic TFLOP per UNet forward at cfg2 (cond with ReferenceNet K/V, uncond, ReferenceNet image)
 TFLOP_COND, TFLOP_UNCOND, TFLOP_REFNET = 14.319, 13.251, 0.803
 
@@ -56,9 +60,13 @@ def build_models(dev, dtype):
 
 
 def cpu_baseline(unet, ref):
-    """The oracle (kind 'port': plain-PyTorch fp32 CPU restatement, pinned by the reference's goldens) on the
-    host cores, bounded sample: ONE uncond Backbone forward on a 2-frame 512^2 window + ONE ReferenceNet
-    forward (batch 1), extrapolated to the 50-step CFG loop: t_step = 2*t_unet + 2*t_ref."""
+    """The oracle (kind 'port': plain-PyTorch fp32 CPU restatement, pinned by the reference's goldens) on the host cores,
+    bounded sample (~25 s): WARM timings (second of two runs) of one uncond Backbone forward on a 2-frame 512^2 window and
+    of one ReferenceNet forward, extrapolated like the reference would run cfg2: per step one uncond + one cond forward of
+    the 12-frame window (conv / linear / spatial attention scale linearly in F - 6x the 2-frame time; cond carries the
+    reference K/V: x 14.319 / 13.251 by FLOPs) + the ReferenceNet on two copies of the image (EMOAnimationPipeline.py:711-716),
+    once per window, not per frame.  Also one cold 1-frame forward on 8 threads (the survey's thread count) and BASELINE
+    configs[0] ("cfg1": 256x256 single frame, no motion module) in full."""
     from oracle import unet_ref as U
     from tests import cases
     from emote_hack_amd.synth import seeded_randn
@@ -66,32 +74,63 @@ def cpu_baseline(unet, ref):
     torch.set_num_threads(cores)
     sd_u = {k: v.float().cpu() for k, v in unet.state_dict().items()}
     sd_r = {k: v.float().cpu() for k, v in ref.state_dict().items()}
-    Fs = 1
+    Fs = 2
     x, ctx = seeded_randn((1, 4, Fs, 64, 64), 1), seeded_randn((1, 77, 768), 2)
+
+    def timed(fn, warm=True):
+        if warm:
+            fn()
+        t0 = time.time()
+        fn()
+        return time.time() - t0
     with torch.no_grad():
-        t0 = time.time()
-        U.unet_forward(sd_u, cases.SD15_MOTION, x, 981, ctx)
-        t_unet = time.time() - t0
-        t0 = time.time()
-        U.unet_forward(sd_r, cases.SD15, x[:, :, :1], 981, ctx, bank_mode="write")
-        t_ref = time.time() - t0
-    t_step = 2 * t_unet + 2 * t_ref
-    return {"value": Fs / (NUM_INFERENCE_STEPS * t_step), "unit": "denoised frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32: 1 uncond UNet fwd on a {Fs}-frame 512x512 window ({t_unet:.1f}s) + 1 ReferenceNet fwd "
-                      f"({t_ref:.1f}s); step = 2*unet + 2*refnet, x{NUM_INFERENCE_STEPS} steps"}
+        t_unet = timed(lambda: U.unet_forward(sd_u, cases.SD15_MOTION, x, 981, ctx))
+        t_ref = timed(lambda: U.unet_forward(sd_r, cases.SD15, x[:, :, :1], 981, ctx, bank_mode="write"))
+        sd_1 = {k: v for k, v in sd_u.items() if "motion_modules" not in k}
+        x1 = seeded_randn((1, 4, 1, 32, 32), 1)
+        t_cfg1 = timed(lambda: U.unet_forward(sd_1, cases.SD15, x1, 981, ctx))
+        torch.set_num_threads(min(8, cores))
+        t_unet8 = timed(lambda: U.unet_forward(sd_u, cases.SD15_MOTION, x[:, :, :1], 981, ctx), warm=False)
+        torch.set_num_threads(cores)
+    F_WIN = 12
+    t_uncond = t_unet * F_WIN / Fs
+    t_cond = t_uncond * TFLOP_COND / TFLOP_UNCOND
+    t_step = t_uncond + t_cond + 2 * t_ref
+    t_step8 = (t_unet8 * F_WIN) * (1 + TFLOP_COND / TFLOP_UNCOND) + 2 * t_ref * (t_unet8 / (t_unet / Fs))
+    return {"value": F_WIN / (NUM_INFERENCE_STEPS * t_step), "unit": "denoised frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32, warm: 1 uncond UNet fwd on a {Fs}-frame 512x512 window ({t_unet:.1f}s) + 1 ReferenceNet fwd "
+                      f"({t_ref:.1f}s); 12-frame step = 6 x uncond + 6.48 x (cond) + 2 x refnet = {t_step:.0f}s, x{NUM_INFERENCE_STEPS} steps",
+            "value_8_threads": F_WIN / (NUM_INFERENCE_STEPS * t_step8),
+            "sample_8_threads": f"1 cold 1-frame uncond fwd on 8 threads ({t_unet8:.1f}s), same extrapolation",
+            "cfg1_seconds_per_forward": t_cfg1, "cfg1": "BASELINE configs[0]: (1,4,1,32,32), t=981, ctx 77x768, no motion module, full forward"}
 
 
 def pmc_traffic(family):
-    """HBM bytes per launch of the kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
-    collected in separate runs of this same command, FETCH x2 gfx950 correction) - profiles/r*_pmc.json.
-    PMC counters cannot be read from inside the process, so this is the latest committed measurement or null."""
+    """HBM bytes per launch of the kernel family from the LATEST committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
+    collected in separate runs of this same command, FETCH x2 gfx950 correction) - profiles/r*_pmc.json.  PMC counters
+    cannot be read from inside the process: the figure is tagged with the profile (round) it came from, or null."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
     if not files:
         return None
     try:
         d = json.load(open(files[-1]))["per_kernel_family"].get(family)
-        return {"hbm_bytes_per_launch": d["hbm_bytes_per_launch"], "source": os.path.relpath(files[-1], ROOT)} if d else None
+        return {"hbm_bytes_per_launch": d["hbm_bytes_per_launch"], "source": os.path.relpath(files[-1], ROOT),
+                "note": "from the committed profile named in `source` (same command, earlier run), not from this run"} if d else None
+    except Exception:
+        return None
+
+
+def mfma_util_from_profiles():
+    """MFMA utilisation of the path from the committed SQ counter pass (profiles/r*_mfma.json, tools/pmc_to_json.py):
+    SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES-equivalent) - tagged with its source; null before the first pass."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return {"mfma_busy_frac": d["mfma_busy_frac"], "source": os.path.relpath(files[-1], ROOT)}
     except Exception:
         return None
 
@@ -99,12 +138,13 @@ def pmc_traffic(family):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event instrumentation pass")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel from Python instead of replaying HIP graphs")
+    ap.add_argument("--ref-group", type=int, default=REF_GROUP, help="ReferenceNet timesteps per batched pass")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -116,16 +156,11 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    force_dist = world == 1 and os.environ.get("EMO_FORCE_DIST") == "1"   # single-GPU run of the multi-GPU code path (diagnostic)
-    dist = world > 1 or force_dist
+    dist = world > 1
     if dist:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if force_dist:
-            os.environ.setdefault("MASTER_PORT", "29533")
-            td.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        else:
-            td.init_process_group("nccl", device_id=dev)
+        td.init_process_group("nccl", device_id=dev)
 
     from emote_hack_amd import DDPMScheduler, ops
     from emote_hack_amd.pipeline import EMOAnimationPipeline
@@ -139,8 +174,8 @@ def main():
     st = pipe.prepare_denoise(seeded_randn((1, 4, f_tot, 64, 64), 1).to(dev), seeded_randn((1, 4, 64, 64), 3),
                               seeded_randn((2, 77, 768), 2), appearance_encoder=ref, num_inference_steps=NUM_INFERENCE_STEPS,
                               guidance_scale=7.5, context_frames=F_WIN, context_stride=1, context_overlap=0, seed=0,
-                              dist=dist, rank=rank, world_size=world, use_graphs=not a.no_graphs)
-    assert len(st.global_context) == world, (len(st.global_context), world)
+                              dist=dist, rank=rank, world_size=world, use_graphs=not a.no_graphs, reference_group=a.ref_group)
+    assert len(st.windows) == world and len(st.units) == 2 * world and sum(len(c.units) for c in st.calls) == 2
 
     def sync():
         torch.cuda.synchronize()
@@ -155,22 +190,29 @@ def main():
         si += 1
     sync()
     t0 = time.perf_counter()
+    groups_before = st.groups_launched
     for _ in range(a.steps):
         pipe.denoise_step(st, si % NUM_INFERENCE_STEPS)
         si += 1
     host_s = time.perf_counter() - t0   # host time to ENQUEUE the steps (launches are asynchronous)
     sync()
     dt_s = time.perf_counter() - t0
+    ref_passes = st.groups_launched - groups_before
     # per-kernel roofline pass: the SAME steps launched eagerly with every launch bracketed by HIP events on the launch
-    # stream (a graph replay cannot host per-launch events); kernels and shapes are identical to the timed region
-    prof = None
+    # stream (a graph replay cannot host per-launch events); kernels and shapes are identical to the timed region.  The
+    # ReferenceNet group pass (one per REF_GROUP steps) is profiled separately and enters per step with weight 1/REF_GROUP.
+    prof = prof_ref = None
     if not a.no_profile:
         prof = ops.KernelProfiler()
         ops.PROFILER = prof
         prof_steps = min(a.steps, 2)
-        for _ in range(prof_steps):
-            pipe.denoise_step(st, si % NUM_INFERENCE_STEPS)
-            si += 1
+        base, glen = st.group_ready * st.T, len(st.groups[st.group_ready])   # steps of the resident group: no ReferenceNet work
+        for i in range(prof_steps):
+            pipe.denoise_step(st, base + min(1 + i, glen - 1))
+        sync()
+        prof_ref = ops.KernelProfiler()
+        ops.PROFILER = prof_ref
+        pipe._reference_group(st, st.group_ready)      # recompute the resident group in place (same values)
         sync()
         ops.PROFILER = None
     if dist:
@@ -187,44 +229,65 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "cfg2: 512x512 latents 64x64, 12-frame window per GPU, 50-step DDPM, CFG 7.5 (uc+c batched), "
-                                   "ReferenceNet on (midup), motion modules res 1/2/4/8, ctx 77x768; 1 step = 1 loop iteration",
+                                   "ReferenceNet on (midup), motion modules res 1/2/4/8, ctx 77x768; 1 step = 1 loop iteration "
+                                   f"+ 1/{st.T} of a {st.T}-timestep ReferenceNet pass",
                        "frames_total": f_tot, "num_inference_steps": NUM_INFERENCE_STEPS,
-                       "parallelism": f"window-sharded x{world} (all_reduce eps accumulators, all_gather ReferenceNet banks)",
+                       "parallelism": f"(window x CFG-branch) units x{world}: rank r owns both branches of window r; all_gather of eps "
+                                      "slices per step, all_gather of ReferenceNet banks per group",
                        "latents_finite": finite, "host_enqueue_ms_per_step": host_s / a.steps * 1e3,
-                       "hip_graphs": not a.no_graphs},
+                       "hip_graphs": not a.no_graphs, "reference_group": st.T,
+                       "reference_passes_in_timed_region": ref_passes,
+                       "reference_passes_fair_share": a.steps / st.T},
         }
         # algorithmic work per step: cond + uncond Backbone per window + the ReferenceNet pass.  The reference
         # runs the ReferenceNet on [uncond-text, cond-text] copies of the image (2 x 0.803 TFLOP); the uncond copy's features
-        # are never read (mutual_self_attention.py:243-256 overwrites the uc rows), so this path computes the cond copy only.
-        # Both figures are reported; the achieved rate is priced on the work actually executed.
+        # are never read (mutual_self_attention.py:243-256 overwrites the uc rows) and everything behind the last bank write
+        # is dead, so this path computes less.  The achieved rate is priced on the SURVEY figure for the cond copy only.
         tflop_ref = world * (TFLOP_COND + TFLOP_UNCOND) + 2 * TFLOP_REFNET
         tflop_step = world * (TFLOP_COND + TFLOP_UNCOND) + 1 * TFLOP_REFNET
         out["config"]["algorithmic_tflop_per_step_reference"] = tflop_ref
         out["config"]["algorithmic_tflop_per_step"] = tflop_step
-        out["config"]["achieved_tflops_whole_path"] = tflop_step / (dt_s / a.steps)
+        out["config"]["achieved_tflops_whole_path"] = tflop_step / (dt_s / a.steps) / world
+        out["config"]["whole_path_frac_of_mfma_peak"] = tflop_step / (dt_s / a.steps) / world / MFMA_PEAK_BF16_TFLOPS
         if prof is not None:
-            summ = prof.summary()
-            dom = max((k for k in summ if summ[k]["flops"] > 0), key=lambda k: summ[k]["ms"])
-            d = summ[dom]
+            summ, summ_ref = prof.summary(), prof_ref.summary()
+            merged = {}
+            for src, wgt in ((summ, 1.0 / prof_steps), (summ_ref, 1.0 / st.T)):
+                for k, v in src.items():
+                    m = merged.setdefault(k, dict(launches=0.0, ms=0.0, flops=0.0, bytes=0.0))
+                    for f in m:
+                        m[f] += v[f] * wgt
+            dom = max((k for k in merged if merged[k]["flops"] > 0), key=lambda k: merged[k]["ms"])
+            d = merged[dom]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             out["roofline"] = {"kernel": {"gemm_dense": "gemm_kernel<bf16,false>", "gemm_conv3x3": "gemm_kernel<bf16,true>",
                                           "attention": "attention_kernel", "temporal_attention": "temporal_attention_kernel"}[dom],
                                "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / MFMA_PEAK_BF16_TFLOPS, "traffic": pmc_traffic(dom),
-                               "launches": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
+                               "launches_per_step": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
                                "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
-                               "algorithmic_mbytes_per_launch": d["bytes"] / d["launches"] / 1e6}
-            out["roofline"]["measured_in"] = f"eager HIP-event pass of {prof_steps} steps right after the timed region (same kernels/shapes)"
-            out["kernels"] = {k: {"launches": v["launches"], "ms_per_step": v["ms"] / prof_steps,
+                               "algorithmic_mbytes_per_launch": d["bytes"] / d["launches"] / 1e6,
+                               "mfma_util": mfma_util_from_profiles()}
+            out["roofline"]["measured_in"] = (f"eager HIP-event pass of {prof_steps} steps + one ReferenceNet group pass (weight 1/{st.T}) right "
+                                              "after the timed region (same kernels/shapes)")
+            out["kernels"] = {k: {"launches_per_step": v["launches"], "ms_per_step": v["ms"],
                                   "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None,
-                                  "gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in sorted(summ.items())}
+                                  "gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in sorted(merged.items())}
+            out["config"]["executed_tflop_per_step"] = sum(v["flops"] for v in merged.values()) / 1e12
+            out["config"]["reference_group_kernel_ms"] = sum(v["ms"] for v in summ_ref.values())
         if prof is not None and os.environ.get("EMO_BENCH_SHAPES"):
-            rows = sorted(prof.by_shape().items(), key=lambda kv: -kv[1]["ms"])
+            rows = {}
+            for src, wgt in ((prof.by_shape(), 1.0 / prof_steps), (prof_ref.by_shape(), 1.0 / st.T)):
+                for k, v in src.items():
+                    m = rows.setdefault(k, dict(launches=0.0, ms=0.0, flops=0.0, bytes=0.0))
+                    for f in m:
+                        m[f] += v[f] * wgt
+            rows = sorted(rows.items(), key=lambda kv: -kv[1]["ms"])
             with open(os.environ["EMO_BENCH_SHAPES"], "w") as f:
                 f.write("| kernel | shape | launches/step | ms/step | TFLOP/s | GB/s (algorithmic) |\n|---|---|---|---|---|---|\n")
-                for (name, tag), v in rows[:60]:
+                for (name, tag), v in rows[:70]:
                     tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["flops"] else 0.0
-                    f.write(f"| {name} | {tag} | {v['launches'] / prof_steps:.1f} | {v['ms'] / prof_steps:.3f} | {tf:.0f} | "
+                    f.write(f"| {name} | {tag} | {v['launches']:.1f} | {v['ms']:.3f} | {tf:.0f} | "
                             f"{v['bytes'] / (v['ms'] * 1e-3) / 1e9:.0f} |\n")
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(unet, ref)

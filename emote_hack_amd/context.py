@@ -3,7 +3,7 @@ reference (goldens in tests/golden/ints.json)."""
 from __future__ import annotations
 
 import math
-from typing import Callable, List, Optional
+from typing import Callable, Optional
 
 
 def ordered_halving(val: int) -> float:
@@ -31,10 +31,3 @@ def get_context_scheduler(name: str) -> Callable:
     if name == "uniform":
         return uniform
     raise ValueError(f"Unknown context_overlap policy {name}")
-
-
-def get_total_steps(scheduler, timesteps: List[int], num_steps: Optional[int] = None, num_frames: int = ...,
-                    context_size: Optional[int] = None, context_stride: int = 3, context_overlap: int = 4,
-                    closed_loop: bool = True):
-    return sum(len(list(scheduler(i, num_steps, num_frames, context_size, context_stride, context_overlap)))
-               for i in range(len(timesteps)))

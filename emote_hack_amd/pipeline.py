@@ -122,7 +122,9 @@ class EMOAnimationPipeline:
         # world_size 1 that is exactly the reference's [uc x cbs, c x cbs] batch (:759-763).
         st.dist = bool(dist)
         st.rank, st.world_size = (int(rank), int(world_size)) if st.dist else (0, 1)
-        st.units = [(w, br) for w in range(len(st.windows)) for br in (0, 1)]
+        # (branch-major order: with as many windows as ranks a rank owns BOTH branches of one window - balanced, the cond
+        # branch costs ~8 % more - and with twice as many ranks as windows, BASELINE configs[3], every rank owns one unit)
+        st.units = [(w, br) for br in (0, 1) for w in range(len(st.windows))]
         mine = st.units[st.rank::st.world_size]
         st.n_slots = -(-len(st.units) // st.world_size)                    # units per rank, padded
         st.calls = []
@@ -177,7 +179,7 @@ class EMOAnimationPipeline:
         st.ref_t = torch.zeros(T, dtype=torch.int64, device=dev)
         st.row_table = torch.tensor([((s_ // T) % 2) * T + s_ % T for s_ in range(n_steps)], dtype=torch.int32, device=dev)
         st.bank_idx = torch.zeros(1, dtype=torch.int32, device=dev)
-        st.kv_all, st.group_ready, st.group_pending = None, -1, -1
+        st.kv_all, st.group_ready, st.group_pending, st.groups_launched = None, -1, -1, 0
         st.ref_sel, st.ref_recv, st.ref_gath, st.bank_pg = {}, {}, {}, None
         spec_r = appearance_encoder.spec
         chan = {a.prefix: a.channels for blk in spec_r.down + [spec_r.mid] + spec_r.up for a in blk.attentions if a is not None}
@@ -250,6 +252,7 @@ class EMOAnimationPipeline:
         """Compute group g's projected banks on the CURRENT stream and store them in slot g % 2 of the resident cache."""
         steps = st.groups[g]
         Tg, T, slot = len(steps), st.T, g % 2
+        st.groups_launched += 1
         st.ref_t[:Tg].copy_(st.t_table[steps[0]:steps[0] + Tg], non_blocking=True)
         self._run(st, ("ref_write", Tg), lambda: self._part_reference_write(st, Tg), pool=st.writer_pool)
         if st.world_size > 1:

@@ -94,6 +94,53 @@ def test_state_dict_keys_match_reference(ints):
         assert n_params == d["n_params"]
 
 
+def test_appearance_encoder_key_set_is_the_gutted_reference_class(ints):
+    """A15: the ReferenceNet of the reference replaces nine sub-modules of up_blocks[3].attentions[2] by parameter-less
+    ones (appearance_encoder.py:613-621; golden = those assignments read from the reference ctor by AST).  The product class
+    must own exactly the F=1 no-motion UNet's keys (conv_norm_out / conv_out dropped) minus everything under a replaced
+    path - a reference-shaped checkpoint then loads strictly - and only norm / proj_in / norm1 may remain in that block."""
+    from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
+    from emote_hack_amd.spec import build_spec, param_shapes
+    repl = ints["appearance_encoder_gutted"]
+    assert len(repl) == 9 and all(n == 0 for _, _, n in repl)
+    for cfg in (cases.SD15, cases.TINY):
+        full = param_shapes(build_spec(cfg, has_out=False))
+        want = {k: tuple(v) for k, v in full.items() if not any(k == p or k.startswith(p + ".") for p, _, _ in repl)}
+        m = AppearanceEncoderModel(**cfg)
+        got = {k: tuple(v) for k, v in m._shapes.items()}
+        assert got == want
+        blk = sorted(k for k in got if k.startswith("up_blocks.3.attentions.2."))
+        assert blk == sorted("up_blocks.3.attentions.2." + n for n in (
+            "norm.weight", "norm.bias", "proj_in.weight", "proj_in.bias",
+            "transformer_blocks.0.norm1.weight", "transformer_blocks.0.norm1.bias"))
+        sd = {k: torch.zeros(s) for k, s in want.items()}
+        assert m.load_state_dict(sd, strict=True) == ([], [])
+        with pytest.raises(RuntimeError, match="unexpected"):   # a full-UNet checkpoint is NOT a ReferenceNet checkpoint
+            m.load_state_dict({k: torch.zeros(s) for k, s in full.items()}, strict=True)
+        # the last bank of the pairing order is the gutted block's LN1 output
+        assert "up_blocks.3.attentions.2" in m.bank_order("midup")
+
+
+def test_load_state_dict_merges_partial_loads():
+    """The reference loads the 2-D checkpoint and then the motion-module checkpoint, both strict=False
+    (unet_controlnet.py:485-525, animation.py:116-135): `missing` is relative to each incoming dict, the model becomes usable
+    once the MERGED master is complete, and an incomplete model names its absent keys instead of dying in a KeyError."""
+    from emote_hack_amd._lib import EmoHipError
+    from emote_hack_amd.unet import UNet3DConditionModel
+    m = UNet3DConditionModel(**cases.TINY_MOTION)
+    sd = {k: torch.zeros(s) for k, s in m._shapes.items()}
+    base = {k: v for k, v in sd.items() if "motion_modules" not in k}
+    mm = {"module." + k: v for k, v in sd.items() if "motion_modules" in k}
+    missing, unexpected = m.load_state_dict(base, strict=False)
+    assert missing and all("motion_modules" in k for k in missing) and not unexpected
+    assert len(m._absent_keys()) == len(missing)
+    with pytest.raises(EmoHipError, match="no value yet"):
+        m._begin(torch.zeros(1, 4, 1, 16, 16), 1, torch.zeros(1, 5, 32))
+    stripped = {k[len("module."):]: v for k, v in mm.items()}       # animation.py:126-133 strips the prefixes
+    missing2, _ = m.load_state_dict(stripped, strict=False)
+    assert set(missing2) == set(base) and m._absent_keys() == []
+
+
 def test_bank_pairing_order(ints):
     from emote_hack_amd.spec import build_spec, reference_block_order
     strip = lambda names: [n.replace(".transformer_blocks.0", "") for n in names]
@@ -154,6 +201,51 @@ def test_context_windows_bit_exact(ints):
     for c in ints["windows_step"]:
         f, ctx, stride, ov = c["args"]
         assert list(uniform(c["step"], 50, f, ctx, stride, ov)) == c["windows"]
+
+
+def test_scheduler_tables_golden(ints):
+    """A3 regression pin: INT timestep tables bit-exact, update coefficients to 1e-12 (tests/golden/ints.json
+    "scheduler_tables", generated from oracle/scheduler_ref.py - parity UNPINNED against diffusers, which is absent)."""
+    from emote_hack_amd import DDIMScheduler, DDPMScheduler
+    for name, tab in ints["scheduler_tables"].items():
+        kind, n = name.split("_")
+        sch = DDIMScheduler() if kind == "ddim" else DDPMScheduler()
+        assert sch.set_timesteps(int(n)) == tab["timesteps"]
+        for t, want in zip(tab["timesteps"], tab["coefficients"]):
+            got = sch.coefficients(t)
+            assert all(abs(a - b) <= 1e-12 * max(1.0, abs(b)) for a, b in zip(got, want)), (name, t, got, want)
+
+
+def test_ddim_step_inverts_the_in_tree_next_step():
+    """The only scheduler algebra the reference holds in tree is the DDIM inversion `next_step`
+    (EMOAnimationPipeline.py:379-400): alpha_t from `timestep - T // n` (final_alpha_cumprod below 0), pred_x0 =
+    (x - sqrt(1-a) eps) / sqrt(a), x_next = sqrt(a_next) pred_x0 + sqrt(1 - a_next) eps.  Restated here over the PRODUCT
+    scheduler object (same attribute names as diffusers': alphas_cumprod, final_alpha_cumprod, config.num_train_timesteps,
+    num_inference_steps); it must undo the product's eta=0 DDIM update with the same eps at every step of the table, and its
+    pred_x0 must be the x0 the forward process started from."""
+    from emote_hack_amd import DDIMScheduler
+    from emote_hack_amd.synth import seeded_randn
+    sch = DDIMScheduler()
+    ts = sch.set_timesteps(50)
+
+    def next_step(model_output, timestep, x):                       # :379-400
+        nxt = timestep
+        timestep = min(timestep - sch.config.num_train_timesteps // sch.num_inference_steps, 999)
+        a_t = float(sch.alphas_cumprod[timestep]) if timestep >= 0 else float(sch.final_alpha_cumprod)
+        a_next = float(sch.alphas_cumprod[nxt])
+        pred_x0 = (x - (1 - a_t) ** 0.5 * model_output) / a_t ** 0.5
+        return a_next ** 0.5 * pred_x0 + (1 - a_next) ** 0.5 * model_output, pred_x0
+
+    x0, eps = seeded_randn((1, 4, 2, 8, 8), 1).double(), seeded_randn((1, 4, 2, 8, 8), 2).double()
+    for t in ts:
+        a_t = float(sch.alphas_cumprod[t])
+        x_t = a_t ** 0.5 * x0 + (1 - a_t) ** 0.5 * eps
+        c_x, c_eps, c_n = sch.coefficients(t, 0.0)
+        assert c_n == 0.0
+        x_prev = c_x * x_t + c_eps * eps                             # what emo_cfg_step applies (:817)
+        back, pred_x0 = next_step(eps, t, x_prev)
+        torch.testing.assert_close(back, x_t, rtol=1e-9, atol=1e-9)
+        torch.testing.assert_close(pred_x0, x0, rtol=1e-8, atol=1e-8)
 
 
 @pytest.mark.parametrize("kind", ["ddim", "ddpm"])

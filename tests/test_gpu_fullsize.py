@@ -1,0 +1,134 @@
+"""GPU parity at BASELINE.json's FULL sizes, through size-independent properties (the CPU oracle needs minutes per forward
+at these sizes; the f32 HIP path is pinned to the oracle / reference goldens at the small sizes of test_gpu_unet.py):
+
+  configs[4] ("cfg5"): the 4-level SD-1.5 network + motion modules at 768x768 (96x96 latents), a 24-frame window, fp16,
+      speed-layer embeddings AND per-frame audio context (48, 5, 768) - fp16 HIP vs f32 HIP within the reference's own fp16
+      error scale, CFG batch rows independent of each other.
+  configs[1]/[2] ("cfg2"/"cfg3") with the ReferenceNet ON: full-size write pass -> projected banks -> sampling-loop steps;
+      eager launches vs HIP-graph replay bit-identical, ReferenceNet timesteps batched 1 / 3 per pass equal within the
+      bf16 error scale, bf16 vs f32 eps of the first step within the reference's own bf16 error scale.
+"""
+import pytest
+import torch
+
+from emote_hack_amd.synth import seeded_randn, synth_state_dict
+from tests import cases
+from tests.test_gpu_unet import check
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def build(cfg, dtype, prefix="", cls=None):
+    from emote_hack_amd.spec import param_shapes
+    from emote_hack_amd.unet import UNet3DConditionModel
+    m = (cls or UNet3DConditionModel)(**cfg)
+    m.load_state_dict(synth_state_dict(param_shapes(m.spec), prefix=prefix, device=DEV))   # device generator: seconds, not minutes
+    return m.to(DEV, dtype)
+
+
+def test_cfg5_full_network_fp16_speed_and_audio():
+    x = seeded_randn((2, 4, 24, 96, 96), 1)
+    ctx = seeded_randn((2, 77, 768), 2)
+    audio = seeded_randn((2 * 24, 5, 768), 4)
+    speed = 0.1 * seeded_randn((2, 4 * 320), 5)
+    kw = lambda sl=slice(None): dict(audio_features=audio.reshape(2, 24, 5, 768)[sl].reshape(-1, 5, 768).to(DEV),
+                                     speed_embeddings=speed[sl].to(DEV))
+    torch.manual_seed(0)
+    m32 = build(cases.SD15_MOTION, torch.float32)
+    sd = {k: v for k, v in m32._master.items()}
+    y32 = m32(x.to(DEV), 500, ctx.to(DEV), **kw()).sample.float().cpu()
+    del m32
+    torch.cuda.empty_cache()
+    from emote_hack_amd.unet import UNet3DConditionModel
+    m16 = UNet3DConditionModel(**cases.SD15_MOTION)
+    m16.load_state_dict(sd)
+    m16.to(DEV, torch.float16)
+    y16 = m16(x.to(DEV), 500, ctx.to(DEV), **kw()).sample
+    assert y16.shape == (2, 4, 24, 96, 96) and bool(torch.isfinite(y16).all())
+    check(y16, y32, torch.float16)
+    # batch rows are independent (GroupNorm is per batch row): the cond row alone reproduces row 1 of the batched call
+    y1 = m16(x[1:].to(DEV), 500, ctx[1:].to(DEV), **kw(slice(1, 2))).sample
+    torch.testing.assert_close(y1.float().cpu(), y16[1:].float().cpu(), rtol=2e-2, atol=2e-2)
+    # the audio context and the speed embedding are live inputs
+    y_na = m16(x.to(DEV), 500, ctx.to(DEV), speed_embeddings=speed.to(DEV)).sample
+    y_ns = m16(x.to(DEV), 500, ctx.to(DEV), audio_features=kw()["audio_features"]).sample
+    assert float((y_na.float() - y16.float()).abs().mean()) > 1e-3 and float((y_ns.float() - y16.float()).abs().mean()) > 1e-4
+
+
+@pytest.fixture(scope="module")
+def cfg2_models():
+    from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
+    torch.manual_seed(0)
+    unet = build(cases.SD15_MOTION, torch.bfloat16)
+    ref = build(cases.SD15, torch.bfloat16, cases.REF_PREFIX, cls=AppearanceEncoderModel)
+    return unet, ref
+
+
+def _run_loop(unet, ref, steps, *, graphs, ref_group, audio=None, n_steps=50):
+    from emote_hack_amd import DDPMScheduler
+    from emote_hack_amd.pipeline import EMOAnimationPipeline
+    pipe = EMOAnimationPipeline(unet=unet, scheduler=DDPMScheduler())
+    st = pipe.prepare_denoise(seeded_randn((1, 4, 12, 64, 64), 1).to(DEV), seeded_randn((1, 4, 64, 64), 3), seeded_randn((2, 77, 768), 2),
+                              appearance_encoder=ref, num_inference_steps=n_steps, guidance_scale=7.5, context_frames=12,
+                              context_stride=1, context_overlap=0, seed=0, use_graphs=graphs, reference_group=ref_group,
+                              return_eps=True, audio_features=audio)
+    for si in range(steps):
+        pipe.denoise_step(st, si)
+    torch.cuda.synchronize()
+    return st.latents.clone(), [e.clone() for e in st.eps_trace]
+
+
+def test_cfg2_reference_net_on_eager_vs_graph_replay_bit_identical(cfg2_models):
+    """4 steps of the full-size loop (ReferenceNet write pass, projected banks with Lk = 4096 + 4096 at d = 40, cond-only bank
+    segment, fused sampler step): HIP-graph replay (steps 2, 3 are replays) must reproduce the eager launches BIT for bit -
+    same kernels, same order, same addresses-independent arithmetic."""
+    unet, ref = cfg2_models
+    lat_e, eps_e = _run_loop(unet, ref, 4, graphs=False, ref_group=3)
+    lat_g, eps_g = _run_loop(unet, ref, 4, graphs=True, ref_group=3)
+    assert bool(torch.isfinite(lat_e).all())
+    for a, b in zip(eps_e, eps_g):
+        assert torch.equal(a, b)
+    assert torch.equal(lat_e, lat_g)
+
+
+def test_cfg2_reference_group_size_does_not_change_the_result(cfg2_models):
+    """ReferenceNet timesteps batched 3 per pass vs the reference's one pass per step: the same banks up to the summation
+    order of the (larger-M) GEMM tiles."""
+    unet, ref = cfg2_models
+    _, eps_1 = _run_loop(unet, ref, 2, graphs=False, ref_group=1)
+    _, eps_3 = _run_loop(unet, ref, 2, graphs=False, ref_group=3)
+    for a, b in zip(eps_1, eps_3):
+        e = (a - b).abs()
+        assert float(e.mean()) < 2e-3 * float(a.abs().mean()) + 1e-5, (float(e.mean()), float(a.abs().mean()))
+
+
+def test_cfg2_reference_net_on_bf16_vs_f32(cfg2_models):
+    """eps of the first step, bf16 HIP vs f32 HIP, ReferenceNet on, CFG 7.5: within the reference's own bf16 error scale
+    (the guidance formula amplifies the per-branch error by up to 1 + 2 * 7.5)."""
+    from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
+    from emote_hack_amd.unet import UNet3DConditionModel
+    unet, ref = cfg2_models
+    _, eps_b = _run_loop(unet, ref, 1, graphs=False, ref_group=1)
+    u32 = UNet3DConditionModel(**cases.SD15_MOTION)
+    u32.load_state_dict(unet._master)
+    u32.to(DEV, torch.float32)
+    r32 = AppearanceEncoderModel(**cases.SD15)
+    r32.load_state_dict(ref._master)
+    r32.to(DEV, torch.float32)
+    _, eps_f = _run_loop(u32, r32, 1, graphs=False, ref_group=1)
+    from tests.test_gpu_unet import yardstick
+    k_mean, _ = yardstick(torch.bfloat16)
+    e = (eps_b[0] - eps_f[0]).abs()
+    assert float(e.mean()) <= 16 * 1.25 * k_mean * float(eps_f[0].abs().mean()), (float(e.mean()), float(eps_f[0].abs().mean()))
+
+
+def test_cfg3_audio_context_in_the_loop(cfg2_models):
+    """BASELINE configs[2]: cfg2 with per-frame wav2vec audio tokens (12, 5, 768) as the attn2 context of the cond units (uncond
+    units get a zero context): runs through graphs, is finite, and differs from the text-context run."""
+    unet, ref = cfg2_models
+    audio = seeded_randn((12, 5, 768), 4)
+    lat_a, eps_a = _run_loop(unet, ref, 3, graphs=True, ref_group=3, audio=audio)
+    lat_t, eps_t = _run_loop(unet, ref, 3, graphs=True, ref_group=3)
+    assert bool(torch.isfinite(lat_a).all())
+    assert float((eps_a[0] - eps_t[0]).abs().mean()) > 1e-3

@@ -1,8 +1,8 @@
 """GPU parity tests, model level: the HIP UNet / ReferenceNet / sampling loop vs (a) golden vectors
 captured from the reference (tests/golden) and (b) the CPU oracle on seeded inputs.
-f32 mode: rtol 1e-3 / atol 1e-4 (north_star).  bf16 mode: vs the same fp32 goldens with the measured
-yard-stick of SURVEY.md section 7 (reference's own bf16-vs-fp32: max-abs 1.9e-2, mean-abs 3.2e-3 at
-output mean-abs 0.32)."""
+f32 mode: rtol 1e-3 / atol 1e-4 (north_star).  bf16 / fp16 mode: vs the same fp32 goldens, bounded by the reference's
+OWN error in that dtype on the same model and inputs (goldens motion/out_bf16 etc.: mean 8.7e-3 / max 4.8e-2 at
+output mean-abs 0.47 in bf16, 1.1e-3 / 5.2e-3 in fp16)."""
 import os
 
 import pytest
@@ -27,17 +27,39 @@ def build(cfg, dtype, prefix="", cls=None, has_out=True):
     return m.to(DEV, dtype)
 
 
-def check(got, ref, dtype):
+_YARD = {}
+
+
+def yardstick(dtype):
+    """The reference's OWN low-precision error on the tiny motion UNet (tests/golden/unet_tiny.safetensors motion/out_bf16 and
+    motion/out_fp16: the reference model run in that dtype on the CPU by tools/oracle/gen_golden.py) relative to the scale
+    of the fp32 output: (mean err / mean|ref|, max err / max|ref|).  bf16: 1.8e-2 / 1.6e-2..., fp16: 2.3e-3 / ..."""
+    if dtype not in _YARD:
+        t = load_file(os.path.join(G, "unet_tiny.safetensors"))
+        ref, low = t["motion/out"], t["motion/out_bf16" if dtype == torch.bfloat16 else "motion/out_fp16"]
+        e = (low - ref).abs()
+        _YARD[dtype] = (float(e.mean()) / float(ref.abs().mean()), float(e.max()) / float(ref.abs().max()))
+    return _YARD[dtype]
+
+
+def check(got, ref, dtype, lowp_ref=None):
+    """f32 mode: north_star's rtol 1e-3 / atol 1e-4.  bf16 / fp16 mode: no worse than the reference's own forward in that
+    dtype - against `lowp_ref` (the reference's low-precision output for the SAME inputs) when the goldens hold one: mean
+    error <= 1.15x and max error <= 1.35x the reference's; otherwise against the relative yard-stick of the tiny motion UNet
+    (mean <= 1.25x, max <= 1.5x, scaled by the tensor's own mean / max magnitude)."""
     got = got.float().cpu()
     if dtype == torch.float32:
         torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-4)
-    else:
-        # bf16 yard-stick relative to the tensor's own scale (UNet output mean-abs ~0.3, LN banks ~0.8):
-        # mean error < 3 % of mean |ref|, max error < 10 % of max |ref|; fp16 (11 significand bits) 8x tighter
-        k = 1.0 if dtype == torch.bfloat16 else 0.125
-        err = (got - ref).abs()
-        assert float(err.mean()) < k * 0.03 * float(ref.abs().mean()) + 1e-3, (float(err.mean()), float(ref.abs().mean()))
-        assert float(err.max()) < k * 0.10 * float(ref.abs().max()) + 1e-2, (float(err.max()), float(ref.abs().max()))
+        return
+    err = (got - ref).abs()
+    if lowp_ref is not None:
+        ref_err = (lowp_ref - ref).abs()
+        assert float(err.mean()) <= 1.15 * float(ref_err.mean()), (float(err.mean()), float(ref_err.mean()))
+        assert float(err.max()) <= 1.35 * float(ref_err.max()), (float(err.max()), float(ref_err.max()))
+        return
+    k_mean, k_max = yardstick(dtype)
+    assert float(err.mean()) <= 1.25 * k_mean * float(ref.abs().mean()) + 1e-5, (float(err.mean()), float(ref.abs().mean()))
+    assert float(err.max()) <= 1.5 * k_max * float(ref.abs().max()) + 1e-4, (float(err.max()), float(ref.abs().max()))
 
 
 @pytest.fixture(scope="module")
@@ -49,14 +71,16 @@ def tiny():
 def test_unet_tiny_plain(tiny, dtype):
     x, ctx = cases.tiny_inputs(2, 4)
     m = build(cases.TINY, dtype)
-    check(m(x[:, :, :2].to(DEV), 981, ctx.to(DEV)).sample, tiny["plain/out"], dtype)
+    low = {torch.bfloat16: "plain/out_bf16", torch.float16: "plain/out_fp16"}.get(dtype)
+    check(m(x[:, :, :2].to(DEV), 981, ctx.to(DEV)).sample, tiny["plain/out"], dtype, tiny[low] if low else None)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_unet_tiny_motion(tiny, dtype):
     x, ctx = cases.tiny_inputs(2, 4)
     m = build(cases.TINY_MOTION, dtype)
-    check(m(x.to(DEV), torch.tensor(961), ctx.to(DEV)).sample, tiny["motion/out"], dtype)
+    low = {torch.bfloat16: "motion/out_bf16", torch.float16: "motion/out_fp16"}.get(dtype)
+    check(m(x.to(DEV), torch.tensor(961), ctx.to(DEV)).sample, tiny["motion/out"], dtype, tiny[low] if low else None)
 
 
 def test_unet_tiny_linear_projection(tiny):
@@ -92,15 +116,18 @@ def test_reference_write_read(tiny, dtype):
     reader.update(writer)
     y = unet(x.to(DEV), 961, ctx.to(DEV)).sample
     reader.clear()
-    check(y, tiny["read/out"], dtype)
+    check(y, tiny["read/out"], dtype, tiny["read/out_fp16"] if dtype == torch.float16 else None)
     if dtype == torch.float32:  # uc rows equal the no-bank run
         torch.testing.assert_close(y[:1].cpu(), tiny["motion/out"][:1], rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("ref_group", [10, 2, 1])
 @pytest.mark.parametrize("graphs", [False, True])
 @pytest.mark.parametrize("kind", ["ddim", "ddpm"])
-def test_denoise_loop_vs_golden(kind, graphs):
-    """3 steps, 8 frames in overlapping windows of 4 - the loop of EMOAnimationPipeline.py:698-823."""
+def test_denoise_loop_vs_golden(kind, graphs, ref_group):
+    """3 steps, 8 frames in overlapping windows of 4 - the loop of EMOAnimationPipeline.py:698-823.  ref_group = ReferenceNet
+    timesteps per batched pass: 10 -> one group of 3; 2 -> groups [0,1],[2] (second HBM slot, look-ahead on the side stream);
+    1 -> the reference's per-step order."""
     from emote_hack_amd import DDIMScheduler, DDPMScheduler
     from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
     from emote_hack_amd.pipeline import EMOAnimationPipeline
@@ -111,16 +138,18 @@ def test_denoise_loop_vs_golden(kind, graphs):
     pipe = EMOAnimationPipeline(unet=unet, scheduler=sch)
     lat, eps = pipe.denoise(seeded_randn((1, 4, 8, 16, 16), 5).to(DEV), seeded_randn((1, 4, 16, 16), 3), seeded_randn((2, 5, 32), 2),
                             appearance_encoder=ref, num_inference_steps=3, guidance_scale=7.5, context_frames=4,
-                            context_stride=1, context_overlap=2, seed=0, return_eps=True, use_graphs=graphs)
+                            context_stride=1, context_overlap=2, seed=0, return_eps=True, use_graphs=graphs,
+                            reference_group=ref_group)
     for i in range(3):
         torch.testing.assert_close(eps[i].cpu(), g[f"{kind}/eps{i}"], rtol=2e-3, atol=2e-4)
     torch.testing.assert_close(lat.cpu(), g[f"{kind}/latents"], rtol=2e-3, atol=2e-4)
 
 
 @pytest.mark.parametrize("graphs", [False, True])
-def test_denoise_loop_multi_gpu_code_path_single_rank(graphs, monkeypatch):
-    """The multi-GPU branch of the loop (ReferenceNet passes dealt over ranks + all_gather of the packed banks, all_reduce of
-    the window accumulators, graph-captured write pass) on ONE rank over RCCL: same goldens as the single-process loop."""
+def test_denoise_loop_multi_gpu_code_path_single_rank(graphs):
+    """The multi-GPU branch of the loop (eps slices through the all_gather buffer, accumulate from the gathered rows) on ONE
+    rank over RCCL: same goldens as the single-process loop.  (world_size > 1 is covered by the gloo tests on CPU; the driver
+    runs the 8-GPU bench.)"""
     import socket
     import torch.distributed as td
     from emote_hack_amd import DDPMScheduler
@@ -131,7 +160,6 @@ def test_denoise_loop_multi_gpu_code_path_single_rank(graphs, monkeypatch):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    monkeypatch.setenv("EMO_FORCE_DIST", "1")
     td.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         g = load_file(os.path.join(G, "loop_tiny.safetensors"))

@@ -82,6 +82,53 @@ def module_names(unet, mods):
     return [rev[id(m)] for m in mods]
 
 
+def gutted_listing():
+    """The ReferenceNet ctor (magicanimate/models/appearance_encoder.py:217-633) cannot run here (its blocks are diffusers
+    2-D blocks), but what it does to `up_blocks[3].attentions[2]` is plain in-tree Python (:613-621): read those assignments
+    by AST - target path, replacement kind - and instantiate the two in-tree replacement classes to count their parameters.
+    The product's AppearanceEncoderModel must own the F=1 UNet's keys minus everything under a replaced path."""
+    import ast
+    path = "/root/reference/magicanimate/models/appearance_encoder.py"
+    tree = ast.parse(open(path).read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "AppearanceEncoderModel")
+    init = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "__init__")
+    repl = shim.extract_classes(path, ["Identity", "_LoRACompatibleLinear"], extra_ns={"LoRALinearLayer": object})
+
+    def dotted(t):
+        if isinstance(t, ast.Attribute):
+            base = dotted(t.value)
+            return t.attr if base == "self" else f"{base}.{t.attr}"
+        if isinstance(t, ast.Subscript):
+            return f"{dotted(t.value)}.{ast.literal_eval(t.slice)}"
+        if isinstance(t, ast.Name):
+            return t.id
+        raise ValueError(ast.dump(t))
+
+    def kind(v):
+        if isinstance(v, ast.Constant) and v.value is None:
+            return "None", 0
+        if isinstance(v, ast.Call) and isinstance(v.func, ast.Name):
+            m = repl[v.func.id]()
+            return v.func.id, sum(p.numel() for p in m.parameters())
+        if isinstance(v, ast.Call) and isinstance(v.func, ast.Attribute) and v.func.attr == "ModuleList":
+            ks = [kind(e) for e in v.args[0].elts]
+            return "ModuleList[" + ",".join(k for k, _ in ks) + "]", sum(n for _, n in ks)
+        raise ValueError(ast.dump(v))
+
+    rows = []
+    for n in ast.walk(init):
+        if isinstance(n, ast.Assign) and len(n.targets) == 1 and isinstance(n.targets[0], ast.Attribute):
+            try:
+                tp = dotted(n.targets[0])
+            except ValueError:
+                continue
+            if tp.startswith("up_blocks.") and ".attentions." in tp:
+                k, npar = kind(n.value)
+                rows.append([tp, k, int(npar)])
+    assert rows, "no gutted-block assignments found"
+    return rows
+
+
 # =============================================================================== ints
 def gen_ints():
     out = {}
@@ -107,6 +154,17 @@ def gen_ints():
         lst = key_listing(m)
         out[name + "_digest"] = dict(n_keys=len(lst), sha256=listing_digest(lst),
                                      n_params=int(sum(p.numel() for p in m.parameters())))
+    out["appearance_encoder_gutted"] = gutted_listing()
+    # A3 regression pin (NOT a reference pin: diffusers is absent, parity unpinned): timestep tables (INT) and the per-step
+    # update coefficients of oracle/scheduler_ref.py, so that a silent change of either restatement is caught
+    from oracle.scheduler_ref import SchedulerRef
+    out["scheduler_tables"] = {}
+    for kind in ("ddim", "ddpm"):
+        for n in (50, 25, 3):
+            sch = SchedulerRef(kind)
+            ts = sch.set_timesteps(n)
+            out["scheduler_tables"][f"{kind}_{n}"] = dict(timesteps=[int(t) for t in ts],
+                                                          coefficients=[[float(c) for c in sch.coefficients(t)] for t in ts])
     # pairing order of the reference-attention banks
     out["bank_order_tiny_midup"] = module_names(tiny, sorted_blocks(tiny, "midup"))
     out["bank_order_tiny_full"] = module_names(tiny, sorted_blocks(tiny, "full"))
@@ -214,6 +272,18 @@ def gen_unet_tiny():
     for i, b in enumerate(banks):
         T[f"banks/{i}"] = b
     T["read/out"] = run_reader(u1, x, 961, ctx, banks)
+    # (d) the reference's OWN low-precision forwards of the same models / inputs: the yard-stick for the bf16 / fp16 HIP
+    # modes (their error against the fp32 goldens is compared with the error of these tensors against the fp32 goldens)
+    import copy
+    for name, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
+        try:
+            um = copy.deepcopy(u1).to(dt)
+            T[f"motion/out_{name}"] = um(x.to(dt), torch.tensor(961), ctx.to(dt)).sample.float()
+            up = copy.deepcopy(u0).to(dt)
+            T[f"plain/out_{name}"] = up(x[:, :, :2].to(dt), 981, ctx.to(dt)).sample.float()
+            T[f"read/out_{name}"] = run_reader(um, x.to(dt), 961, ctx.to(dt), [b.to(dt) for b in banks]).float()
+        except Exception as ex:   # a CPU op without a half kernel
+            print(f"reference forward in {name} failed: {ex}")
     save_file({k: v.contiguous() for k, v in T.items()}, os.path.join(GOLD, "unet_tiny.safetensors"))
     print("unet_tiny.safetensors", {k: tuple(v.shape) for k, v in T.items() if not k.startswith("banks")})
     return u1, ref
