@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event instrumentation pass")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel from Python instead of replaying HIP graphs")
     ap.add_argument("--ref-group", type=int, default=REF_GROUP, help="ReferenceNet timesteps per batched pass")
+    ap.add_argument("--no-ln-fold", action="store_true", help="A/B: explicit LayerNorm launches instead of the GEMM fold")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -167,6 +168,9 @@ def main():
     from emote_hack_amd.synth import seeded_randn
 
     dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[a.dtype]
+    if a.no_ln_fold:
+        from emote_hack_amd import unet as unet_mod
+        unet_mod.FOLD_LAYERNORM = False
     unet, ref = build_models(dev, dtype)
     F_WIN = 12
     f_tot = F_WIN * world
@@ -290,7 +294,10 @@ def main():
                     f.write(f"| {name} | {tag} | {v['launches']:.1f} | {v['ms']:.3f} | {tf:.0f} | "
                             f"{v['bytes'] / (v['ms'] * 1e-3) / 1e9:.0f} |\n")
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(unet, ref)
+            try:
+                out["cpu_baseline"] = cpu_baseline(unet, ref)
+            except Exception as ex:   # the baseline leg must never cost the measurement
+                out["cpu_baseline"] = {"error": f"{type(ex).__name__}: {ex}"}
         print(json.dumps(out))
     if dist:
         td.barrier()

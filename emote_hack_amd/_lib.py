@@ -33,6 +33,8 @@ class GemmParams(C.Structure):
         ("upsample2x", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
         ("dtype", C.c_int),
         ("split_k", C.c_int), ("workspace", C.c_void_p),
+        ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
+        ("tile", C.c_int),
     ]
 
 

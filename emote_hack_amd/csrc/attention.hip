@@ -240,11 +240,9 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
       wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
-#ifndef EMO_ATT_ABL_NOLOAD
     if constexpr (NSR > 1) {
       if (t + NSR - 1 < ntiles) issue(t + NSR - 1, (t + NSR - 1) % NSR);
     }
-#endif
     const bool s1 = t >= tiles0;
     const int k0 = (s1 ? t - tiles0 : t) * TK;
     const int Lk = s1 ? p.Lk1 : p.Lk0;
@@ -317,12 +315,8 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
         for (int r = 0; r < 16; r += 2) {
           const v2f a = {s0[r], s0[r + 1]}, b = {s1[r], s1[r + 1]};
           const v2f ea = a * cc - mm, eb = b * cc - mm;      // v_pk_fma_f32
-#ifdef EMO_ATT_ABL_NOEXP
-          p0[r] = ea.x; p0[r + 1] = ea.y; p1[r] = eb.x; p1[r + 1] = eb.y;
-#else
           p0[r] = __builtin_amdgcn_exp2f(ea.x); p0[r + 1] = __builtin_amdgcn_exp2f(ea.y);
           p1[r] = __builtin_amdgcn_exp2f(eb.x); p1[r + 1] = __builtin_amdgcn_exp2f(eb.y);
-#endif
         }
       }
       if (!ones_row) {   // no pad row (d = 160): the denominator is summed on the VALU
@@ -378,9 +372,6 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
         for (int t = 0; t < QT; t++)
 #pragma unroll
           for (int nt = 0; nt < NT; nt++) {
-#ifdef EMO_ATT_ABL_NOPV
-            if (sp == 0 && nt == 0)
-#endif
             o[t][nt] = mma16<T>(vf[sp][nt], pf[t][st][sp], o[t][nt]);
           }
     }
@@ -452,8 +443,7 @@ static int launch_attention3(const emo_attention_params& p, hipStream_t st) {
   const int64_t nblk = (int64_t)((p.Lq + BQ * QT - 1) / (BQ * QT)) * p.heads * p.B;
   if (nblk >= (1ll << 31)) return emo_fail(EMO_ERR_BAD_SHAPE, "emo_attention: too many blocks");
   dim3 grid((unsigned)nblk);
-  static const int order_mode = getenv("EMO_ATT_ORDER") ? atoi(getenv("EMO_ATT_ORDER")) : 2;   // measurement hook: 0 plain, 1 contiguous runs, 2 chunk round-robin
-  kern<<<grid, ATT_THREADS, lds, st>>>(p, L::STAGE_BYTES, order_mode);
+  kern<<<grid, ATT_THREADS, lds, st>>>(p, L::STAGE_BYTES, /*order_mode: (b, head) chunks round-robin over the XCDs*/ 2);
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }

@@ -127,6 +127,37 @@ template <> __device__ __forceinline__ f32x16 mma16<float>(const uint4& a, const
   c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
   return c;
 }
+// acc + <a, b> over one 16-byte chunk pair (bf16 / f16: v_dot2_f32_*; f32: fma chain)
+template <typename T> __device__ __forceinline__ float dot16(const uint4& a, const uint4& b, float acc);
+template <> __device__ __forceinline__ float dot16<float>(const uint4& a, const uint4& b, float acc) {
+  acc += __uint_as_float(a.x) * __uint_as_float(b.x);
+  acc += __uint_as_float(a.y) * __uint_as_float(b.y);
+  acc += __uint_as_float(a.z) * __uint_as_float(b.z);
+  acc += __uint_as_float(a.w) * __uint_as_float(b.w);
+  return acc;
+}
+template <> __device__ __forceinline__ float dot16<f16_t>(const uint4& a, const uint4& b, float acc) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a.x), __builtin_bit_cast(h2, b.x), acc, false);   // v_dot2_f32_f16
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a.y), __builtin_bit_cast(h2, b.y), acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a.z), __builtin_bit_cast(h2, b.z), acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a.w), __builtin_bit_cast(h2, b.w), acc, false);
+  return acc;
+}
+template <> __device__ __forceinline__ float dot16<bf16_t>(const uint4& a, const uint4& b, float acc) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.x), __builtin_bit_cast(bf2, b.x), acc, false);   // v_dot2_f32_bf16
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.y), __builtin_bit_cast(bf2, b.y), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.z), __builtin_bit_cast(bf2, b.z), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.w), __builtin_bit_cast(bf2, b.w), acc, false);
+  return acc;
+}
+// 1.0 in T replicated over a 16-byte chunk (sum of a chunk = dot16(chunk, ones))
+template <typename T> __device__ __forceinline__ uint4 ones16();
+template <> __device__ __forceinline__ uint4 ones16<float>() { return make_uint4(0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u); }
+template <> __device__ __forceinline__ uint4 ones16<bf16_t>() { return make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u); }
+template <> __device__ __forceinline__ uint4 ones16<f16_t>() { return make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u); }
+
 // k-values consumed by one mma16 step
 template <typename T> struct MmaK { static constexpr int value = 2 * TT<T>::VEC; };
 

@@ -5,9 +5,9 @@
 extern template int gemm_run<float>(const emo_gemm_params&, const GemmPlan&, int, hipStream_t);
 extern template int gemm_run<bf16_t>(const emo_gemm_params&, const GemmPlan&, int, hipStream_t);
 extern template int gemm_run<f16_t>(const emo_gemm_params&, const GemmPlan&, int, hipStream_t);
-extern template int gemm_run_halo<float>(const emo_gemm_params&, int64_t, hipStream_t);
-extern template int gemm_run_halo<bf16_t>(const emo_gemm_params&, int64_t, hipStream_t);
-extern template int gemm_run_halo<f16_t>(const emo_gemm_params&, int64_t, hipStream_t);
+extern template int gemm_run_halo<float>(const emo_gemm_params&, int, int64_t, hipStream_t);
+extern template int gemm_run_halo<bf16_t>(const emo_gemm_params&, int, int64_t, hipStream_t);
+extern template int gemm_run_halo<f16_t>(const emo_gemm_params&, int, int64_t, hipStream_t);
 
 extern "C" int emo_gemm_suggest_split_k(int64_t M, int N, int K, int dtype, int geglu, int transpose_out) {
   return plan_gemm(M, N, K, dtype, geglu, transpose_out).split_k;
@@ -43,20 +43,29 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
     EMO_CHECK(((uintptr_t)p.C % 16) == 0 && (!p.residual || ((uintptr_t)p.residual % 8) == 0), EMO_ERR_BAD_SHAPE, "emo_gemm: C/residual alignment");
   }
   const int S = p.split_k > 1 ? p.split_k : 1;
+  if (p.ln_colsum) {
+    EMO_CHECK(!conv && S == 1 && p.ln_eps > 0.f, EMO_ERR_UNSUPPORTED,
+              "emo_gemm: the LayerNorm fold needs a dense, single-pass GEMM (conv=%d split_k=%d)", (int)conv, S);
+    EMO_CHECK(p.N % 4 == 0 && ((uintptr_t)p.ln_colsum % 16) == 0 && (!p.bias || ((uintptr_t)p.bias % 16) == 0), EMO_ERR_BAD_SHAPE,
+              "emo_gemm: the LayerNorm fold needs N %% 4 == 0 and 16-byte aligned colsum / bias");
+  }
   {
-    static const int halo_mode = env_int("EMO_CONV_HALO", 1);
     const int bk = KBYTES / (p.dtype == EMO_F32 ? 4 : 2);
-    if (halo_mode && conv && p.stride == 1 && !p.upsample2x && !p.transpose_out && !p.geglu && S == 1 && p.Cin % bk == 0 &&
-        p.H % HaloGeom::PH == 0 && p.W_ % HaloGeom::PW == 0 && (p.N & 3) == 0 &&
+    if (conv && p.stride == 1 && !p.upsample2x && !p.transpose_out && !p.geglu && S == 1 && p.Cin % bk == 0 &&
+        p.H % 8 == 0 && p.W_ % HaloGeom::PW == 0 && (p.N & 3) == 0 &&
         (!p.rowbias || (p.rows_per_batch % (p.H * p.W_) == 0 && (p.ld_rowbias & 3) == 0))) {
-      const int64_t tiles = (p.M / 128) * ((p.N + HaloGeom::BN - 1) / HaloGeom::BN);
-      const int64_t gx = tiles > 512 ? 512 : tiles;
+      const int64_t nt = (p.N + HaloGeom::BN - 1) / HaloGeom::BN;
+      // 16-row patches (8 waves, one block per CU) when they still give (nearly) every CU a block; p.tile 1 / 2 pins 8 / 16
+      const int64_t tiles16 = (p.M / 256) * nt;
+      const bool ph16 = p.H % 16 == 0 && (p.tile == 2 || (p.tile != 1 && tiles16 >= 200));
+      const int64_t tiles = ph16 ? tiles16 : (p.M / 128) * nt, slots = ph16 ? 256 : 512;
+      const int64_t gx = tiles > slots ? slots : tiles;
       int rc_h = EMO_OK;
-      EMO_DISPATCH(p.dtype, "emo_gemm", rc_h = gemm_run_halo<T>(p, gx, as_stream(stream)));
+      EMO_DISPATCH(p.dtype, "emo_gemm", rc_h = gemm_run_halo<T>(p, ph16 ? 16 : 8, gx, as_stream(stream)));
       return rc_h;
     }
   }
-  GemmPlan pl = plan_gemm(p.M, p.N, p.K, p.dtype, p.geglu, p.transpose_out);
+  GemmPlan pl = plan_gemm(p.M, p.N, p.K, p.dtype, p.geglu, p.transpose_out, p.tile, p.ln_colsum != nullptr);
   if (S > 1) {
     EMO_CHECK(p.workspace != nullptr && S <= 65535, EMO_ERR_NULL, "emo_gemm: split_k=%d needs a workspace", S);
     EMO_CHECK(p.N % 4 == 0, EMO_ERR_BAD_SHAPE, "emo_gemm: split-K needs N %% 4 == 0");

@@ -42,8 +42,10 @@
 // Epilogue fused: bias, per-batch row bias (temb), GEGLU, residual, scale, row-major or V^T store.
 // Split-K (small M): f32 partial slabs + a fixed-order reduce/epilogue kernel (deterministic).
 // conv3x3_halo_kernel (below): the stride-1 3x3 convs with input-halo reuse instead of the im2col loader.
-// EMO_ABL_* / EMO_FORCE_* / EMO_LATE_ISSUE macros and the EMO_GEMM_* environment knobs are measurement hooks (ablations and
-// tile-choice overrides quoted in DESIGN.md 7), not product configuration.
+// LayerNorm fold (template LN): the LayerNorms of the transformer blocks all feed a Linear; with ln_colsum set the kernel
+// multiplies the RAW rows and applies rstd_m * (acc - mean_m * colsum[n]) in the epilogue, the row statistics coming from
+// v_dot2 sums over the A fragments the MFMA loop reads anyway - the LayerNorm launches and their HBM round trip disappear.
+// emo_gemm_params.tile pins a tile shape (0 = planned); the planner's thresholds are the measured ones of DESIGN.md 7.
 #pragma once
 #include "gemm_api.h"
 
@@ -56,7 +58,6 @@ static constexpr int RPB = 256 / KBYTES;         // LDS rows per 256-byte bank r
 __device__ __forceinline__ int swz(int row) { return (row / RPB) & (CPR - 1); }
 
 static __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0, 0, 0, 0};   // one copy per dtype TU
-static __device__ int g_gemm_lds_epi = 1;   // experiment switch (EMO_GEMM_LDS_EPI=0): 0 = row-per-lane epilogue everywhere
 
 template <int WTM, int WTN, int WVM, int WVN, int NS_> struct GemmTile {
   static constexpr int NS = NS_;   // LDS ring depth
@@ -87,9 +88,12 @@ __device__ __forceinline__ uint4 lds_read16(unsigned addr) {
 
 // Row-major fused epilogue of one 32-row MFMA tile row (lane <-> output row m; register quad g of tile j <-> columns
 // j*32 + 8*g + 4*half + {0..3}): bias, per-batch row bias, GEGLU, residual, scale, 8-byte (bf16) / 16-byte (f32) stores.
+// ln_s != nullptr: LayerNorm folded into the GEMM - the accumulator holds A.W^T of the RAW rows and becomes
+// rstd_m * (acc - mean_m * colsum[n]) before the bias (see emo_gemm_params.ln_colsum).
 template <typename T, int WTN>
 __device__ __forceinline__ void epilogue_row(const f32x16 (&acc)[WTN], const emo_gemm_params& p, int64_t m, bool m_ok, int wn0, int half,
-                                             T* __restrict__ C, const T* __restrict__ R) {
+                                             T* __restrict__ C, const T* __restrict__ R, const float* __restrict__ ln_s = nullptr,
+                                             float ln_mean = 0.f, float ln_rstd = 1.f) {
   const float* rbias = (p.rowbias && m_ok) ? p.rowbias + (m / p.rows_per_batch) * p.ld_rowbias : nullptr;
   const int n_out = p.geglu ? p.N / 2 : p.N;
   const bool vec_ok = (p.N & 3) == 0 && ((p.ldc | (R ? p.ldr : 0)) & 3) == 0 && (!p.rowbias || (p.ld_rowbias & 3) == 0);
@@ -103,11 +107,23 @@ __device__ __forceinline__ void epilogue_row(const f32x16 (&acc)[WTN], const emo
       if (nw0 >= p.N) continue;
       float o[4] = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
       if (vec_ok) {   // the whole quad is in range (N % 4 == 0)
+        if (ln_s) {
+          const float4 s4 = *(const float4*)(ln_s + nw0);
+          const float nm = -ln_mean;
+          o[0] = ln_rstd * fmaf(nm, s4.x, o[0]); o[1] = ln_rstd * fmaf(nm, s4.y, o[1]);
+          o[2] = ln_rstd * fmaf(nm, s4.z, o[2]); o[3] = ln_rstd * fmaf(nm, s4.w, o[3]);
+        }
         if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
         if (rbias) { const float4 b4 = *(const float4*)(rbias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
         if (p.geglu) {
           float gt[4] = {acc[(j + 1) % WTN][4 * g], acc[(j + 1) % WTN][4 * g + 1], acc[(j + 1) % WTN][4 * g + 2],
                          acc[(j + 1) % WTN][4 * g + 3]};
+          if (ln_s) {
+            const float4 s4 = *(const float4*)(ln_s + nw0 + 32);
+            const float nm = -ln_mean;
+            gt[0] = ln_rstd * fmaf(nm, s4.x, gt[0]); gt[1] = ln_rstd * fmaf(nm, s4.y, gt[1]);
+            gt[2] = ln_rstd * fmaf(nm, s4.z, gt[2]); gt[3] = ln_rstd * fmaf(nm, s4.w, gt[3]);
+          }
           if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0 + 32); gt[0] += b4.x; gt[1] += b4.y; gt[2] += b4.z; gt[3] += b4.w; }
           if constexpr (sizeof(T) == 2) {
             float g0, g1, g2, g3;
@@ -132,23 +148,20 @@ __device__ __forceinline__ void epilogue_row(const f32x16 (&acc)[WTN], const emo
         }
 #pragma unroll
         for (int e = 0; e < 4; e++) o[e] *= p.out_scale;
-#ifdef EMO_ABL_NOSTORE
-        if (o[0] == 123.456f)
-#endif
-        {
         if constexpr (sizeof(T) == 2) *(uint2*)(C + m * p.ldc + no0) = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
         else *(float4*)(C + m * p.ldc + no0) = make_float4(o[0], o[1], o[2], o[3]);
-        }
       } else {   // ragged N / unaligned leading dims: scalar path
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const int nw = nw0 + e;
           if (nw >= p.N || !m_ok) continue;
           float v = o[e];
+          if (ln_s) v = ln_rstd * (v - ln_mean * ln_s[nw]);
           if (p.bias) v += p.bias[nw];
           if (rbias) v += rbias[nw];
           if (p.geglu) {
             float gt = acc[(j + 1) % WTN][4 * g + e];
+            if (ln_s) gt = ln_rstd * (gt - ln_mean * ln_s[nw + 32]);
             if (p.bias) gt += p.bias[nw + 32];
             v *= gelu_for<T>(gt);
           }
@@ -176,7 +189,8 @@ __device__ __forceinline__ void lds_write8(unsigned addr, unsigned lo, unsigned 
 // m_of(i, row) -> global output row of row `row` (0..31) of this wave's MFMA tile row i, or -1 if it does not exist
 template <typename T, int WTM, int WTN, int NW, int XBYTES, bool GEGLU, typename MF>
 __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], const emo_gemm_params& p, MF m_of, int wn0, int wave, int lane,
-                                             unsigned xbase, T* __restrict__ C, const T* __restrict__ R) {
+                                             unsigned xbase, T* __restrict__ C, const T* __restrict__ R,
+                                             const float* __restrict__ ln_s, const float (&ln_mean)[WTM], const float (&ln_rstd)[WTM]) {
   static_assert(sizeof(T) == 2, "the staged epilogue is for the 2-byte element types");
   constexpr int OTW = GEGLU ? WTN / 2 : WTN;                  // 32-column output tiles per wave row
   constexpr int JMAX = (XBYTES / (NW * 32) - 16) / 64;        // tiles per pass that fit this wave's share of the slot
@@ -220,10 +234,20 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], cons
           const int nw0 = wn0 + jv * 32 + 8 * g + 4 * half;    // column in W-row space
           float o[4] = {acc[i][jv][4 * g], acc[i][jv][4 * g + 1], acc[i][jv][4 * g + 2], acc[i][jv][4 * g + 3]};
           if (nw0 < p.N) {
+            if (ln_s) {   // LayerNorm folded into the GEMM: rstd_m * (acc - mean_m * colsum[n])
+              const float4 s4 = *(const float4*)(ln_s + nw0);
+              const float nm = -ln_mean[i], rs = ln_rstd[i];
+              o[0] = rs * fmaf(nm, s4.x, o[0]); o[1] = rs * fmaf(nm, s4.y, o[1]); o[2] = rs * fmaf(nm, s4.z, o[2]); o[3] = rs * fmaf(nm, s4.w, o[3]);
+            }
             if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
             if (rbias) { const float4 b4 = *(const float4*)(rbias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
             if constexpr (GEGLU) {
               float gt[4] = {acc[i][jv + 1][4 * g], acc[i][jv + 1][4 * g + 1], acc[i][jv + 1][4 * g + 2], acc[i][jv + 1][4 * g + 3]};
+              if (ln_s) {
+                const float4 s4 = *(const float4*)(ln_s + nw0 + 32);
+                const float nm = -ln_mean[i], rs = ln_rstd[i];
+                gt[0] = rs * fmaf(nm, s4.x, gt[0]); gt[1] = rs * fmaf(nm, s4.y, gt[1]); gt[2] = rs * fmaf(nm, s4.z, gt[2]); gt[3] = rs * fmaf(nm, s4.w, gt[3]);
+              }
               if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0 + 32); gt[0] += b4.x; gt[1] += b4.y; gt[2] += b4.z; gt[3] += b4.w; }
               float g0, g1, g2, g3;
               gelu_erf_poly2(gt[0], gt[1], g0, g1);
@@ -289,8 +313,9 @@ __device__ __forceinline__ void init_acc_bias(f32x16 (&acc)[WTM][WTN], const flo
 
 struct ConvRow { int img, iy0, ix0; };
 
-template <typename T, bool CONV, bool TRANS, int WTM, int WTN, int WVM, int WVN, int NS>
+template <typename T, bool CONV, bool TRANS, int WTM, int WTN, int WVM, int WVN, int NS, bool LN = false>
 __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::WPE)) void gemm_kernel(const emo_gemm_params p) {
+  static_assert(!(LN && CONV), "the LayerNorm fold is for the dense loader");
   using Tile = GemmTile<WTM, WTN, WVM, WVN, NS>;
   constexpr int NW = Tile::NW;
   constexpr int V = TT<T>::VEC;          // elements per 16 B
@@ -433,12 +458,12 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
   T* __restrict__ C = (T*)p.C;
   const T* __restrict__ R = (const T*)p.residual;
   // row-major single-pass outputs start their accumulators at the bias; the epilogues then see bias == nullptr
-  const bool bias_in_acc = !TRANS && nsplit == 1 && p.bias != nullptr && (p.N & 3) == 0;
+  const bool bias_in_acc = !LN && !TRANS && nsplit == 1 && p.bias != nullptr && (p.N & 3) == 0;
   emo_gemm_params pe = p;
   if (bias_in_acc) pe.bias = nullptr;
   // coalesced LDS-staged epilogue (bf16, row-major, single pass): needs whole 16-byte chunks everywhere
   const int n_out_all = p.geglu ? p.N / 2 : p.N;
-  const bool use_lds_epi = !TRANS && sizeof(T) == 2 && nsplit == 1 && nk > 0 && g_gemm_lds_epi && (n_out_all & 7) == 0 && (p.N & 3) == 0 &&
+  const bool use_lds_epi = !TRANS && sizeof(T) == 2 && nsplit == 1 && nk > 0 && (n_out_all & 7) == 0 && (p.N & 3) == 0 &&
                            (p.ldc & 7) == 0 && (!R || (p.ldr & 7) == 0) && (!p.rowbias || (p.ld_rowbias & 3) == 0) &&
                            (!p.geglu || (WTN % 2 == 0));
 
@@ -472,6 +497,11 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
   }
+  // LayerNorm fold: per-lane partial (sum, sum of squares) of the A rows this lane reads as MFMA fragments; lanes l and
+  // l + 32 hold the two halves of every row's chunks
+  float ln_sum[WTM], ln_sq[WTM];
+#pragma unroll
+  for (int i = 0; i < WTM; i++) { ln_sum[i] = 0.f; ln_sq[i] = 0.f; }
 
   for (int kt = 0; kt < nk; kt++, gs++) {
     // stage gs must have landed; up to NS-2 younger stages may still be in flight - fewer at the end of the stream, and none
@@ -500,48 +530,33 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
 #pragma unroll
     for (int j = 0; j < WTN; j++) fb[0][j] = lds_read16(st + fb0[j]);
     constexpr int NMMA = WTM * WTN, NRD = WTM + WTN;
-#ifndef EMO_LATE_ISSUE
     // the whole next ring stage is requested right behind the barrier: it then has this stage's full MFMA time to land
     // (spreading the glds between the MFMAs left the last ones ~no time: +10-20 % on the K >= 2560 shapes, 8192^3 980 -> 1130 TF/s)
     if (more) {
       static_for<LA>([&](auto I) { issue_a(kt_next, slot_next, I); });
       static_for<LB>([&](auto I) { issue_b(kt_next, slot_next, I); });
     }
-#endif
     static_for<KSTEPS>([&](auto KK) {
       constexpr int kk = decltype(KK)::value, cur = kk & 1, nxt = cur ^ 1;
       wait_lgkmcnt<0>();                       // fragments of step kk
       __builtin_amdgcn_sched_barrier(0);
-      // side ops of this cluster: the next step's fragment reads, then this cluster's share of the glds
+      // side ops of this cluster: the next step's fragment reads, one at a time between the MFMAs
       constexpr int n_rd = (kk + 1 < KSTEPS) ? NRD : 0;
-      constexpr int g_begin = kk * LPS / KSTEPS, g_end = (kk + 1) * LPS / KSTEPS;
-      constexpr int n_side = n_rd + (g_end - g_begin);
+      constexpr int n_side = n_rd;
       static_for<NMMA>([&](auto Q) {
         constexpr int q = decltype(Q)::value, i = q / WTN, j = q % WTN;
-#ifndef EMO_ABL_NOMMA
         if constexpr (TRANS) acc[i][j] = mma16<T>(fa[cur][i], fb[cur][j], acc[i][j]);   // rows = m, lane = n
         else acc[i][j] = mma16<T>(fb[cur][j], fa[cur][i], acc[i][j]);                   // rows = n, lane = m
-#endif
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LN && (q % WTN) == 0) {   // row statistics of fragment row i, on the VALU beside the MFMAs that consume it
+          ln_sum[i] = dot16<T>(fa[cur][i], ones16<T>(), ln_sum[i]);
+          ln_sq[i] = dot16<T>(fa[cur][i], fa[cur][i], ln_sq[i]);
+        }
         static_for<n_side>([&](auto O) {
           constexpr int o = decltype(O)::value;
           if constexpr ((o * NMMA) / n_side == q) {
-            if constexpr (o < n_rd) {
-#ifndef EMO_ABL_NOREAD
-              if constexpr (o < WTM) fa[nxt][o] = lds_read16((st + fa0[o]) ^ (((kk + 1) % KSTEPS) << 5));
-              else fb[nxt][o - WTM] = lds_read16((st + fb0[o - WTM]) ^ (((kk + 1) % KSTEPS) << 5));
-#endif
-            } else {
-              constexpr int g = g_begin + (o - n_rd);
-#if defined(EMO_ABL_NOLOAD) || !defined(EMO_LATE_ISSUE)
-              if (false) {
-#else
-              if (more) {
-#endif
-                if constexpr (g < LA) issue_a(kt_next, slot_next, std::integral_constant<int, g>{});
-                else issue_b(kt_next, slot_next, std::integral_constant<int, g - LA>{});
-              }
-            }
+            if constexpr (o < WTM) fa[nxt][o] = lds_read16((st + fa0[o]) ^ (((kk + 1) % KSTEPS) << 5));
+            else fb[nxt][o - WTM] = lds_read16((st + fb0[o - WTM]) ^ (((kk + 1) % KSTEPS) << 5));
           }
         });
         __builtin_amdgcn_sched_barrier(0);
@@ -553,6 +568,22 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
   const int64_t wm0 = bm + wvm * 32 * WTM;
   const int wn0 = bn + wvn * 32 * WTN;
 
+  float ln_mean[WTM], ln_rstd[WTM];
+  const float* ln_s = LN ? p.ln_colsum : nullptr;
+  if constexpr (LN) {
+    const float invK = 1.0f / (float)p.K;
+#pragma unroll
+    for (int i = 0; i < WTM; i++) {
+      const float su = ln_sum[i] + __shfl_xor(ln_sum[i], 32, 64), sq = ln_sq[i] + __shfl_xor(ln_sq[i], 32, 64);
+      const float mean = su * invK;
+      ln_mean[i] = mean;
+      ln_rstd[i] = rsqrtf(fmaxf(sq * invK - mean * mean, 0.f) + p.ln_eps);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < WTM; i++) { ln_mean[i] = 0.f; ln_rstd[i] = 1.f; }
+  }
+
   bool lds_epilogue = false;
   if constexpr (!TRANS && sizeof(T) == 2) {
     lds_epilogue = use_lds_epi;
@@ -563,9 +594,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
       const unsigned xbase = lds_base + ((gs + NS - 1) % NS) * Tile::STAGE_BYTES;
       auto m_of = [&](int i, int row) -> int64_t { const int64_t m = wm0 + i * 32 + row; return m < p.M ? m : -1; };
       if (p.geglu) {
-        if constexpr (WTN % 2 == 0) epilogue_lds<T, WTM, WTN, NW, Tile::STAGE_BYTES, true>(acc, pe, m_of, wn0, wave, lane, xbase, C, R);
+        if constexpr (WTN % 2 == 0) epilogue_lds<T, WTM, WTN, NW, Tile::STAGE_BYTES, true>(acc, pe, m_of, wn0, wave, lane, xbase, C, R, ln_s, ln_mean, ln_rstd);
       } else {
-        epilogue_lds<T, WTM, WTN, NW, Tile::STAGE_BYTES, false>(acc, pe, m_of, wn0, wave, lane, xbase, C, R);
+        epilogue_lds<T, WTM, WTN, NW, Tile::STAGE_BYTES, false>(acc, pe, m_of, wn0, wave, lane, xbase, C, R, ln_s, ln_mean, ln_rstd);
       }
     }
   }
@@ -588,11 +619,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
           }
         continue;
       }
-#ifndef EMO_ABL_NOEPI
-      epilogue_row<T, WTN>(acc[i], pe, m, m_ok, wn0, half, C, R);
-#else
-      if (acc[i][0][0] == 123.456f) epilogue_row<T, WTN>(acc[i], pe, m, m_ok, wn0, half, C, R);
-#endif
+      epilogue_row<T, WTN>(acc[i], pe, m, m_ok, wn0, half, C, R, ln_s, ln_mean[i], ln_rstd[i]);
     }
   } else {
     // TRANS: lane <-> column n; register quad g <-> rows 8*g + 4*half + {0..3} (4 CONSECUTIVE rows), which are 4
@@ -605,9 +632,18 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
         const int n = wn0 + j * 32 + l31;
         if (n >= p.N) continue;
         const float bias_v = p.bias ? p.bias[n] : 0.f;
+        const float ln_sn = LN ? p.ln_colsum[n] : 0.f;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
           const int64_t m0 = wm0 + i * 32 + 8 * g + 4 * half;
+          float rmean[4], rrstd[4];   // LayerNorm fold: statistics of rows 8g + 4half + e live in lane (row) of this wave
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            if constexpr (LN) {
+              rmean[e] = __shfl(ln_mean[i], 8 * g + 4 * half + e, 64);
+              rrstd[e] = __shfl(ln_rstd[i], 8 * g + 4 * half + e, 64);
+            } else { rmean[e] = 0.f; rrstd[e] = 1.f; }
+          }
           if (m0 >= p.M) continue;
           if (nsplit > 1) {
 #pragma unroll
@@ -618,7 +654,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
           float o[4];
 #pragma unroll
           for (int e = 0; e < 4; e++) {
-            float v = acc[i][j][4 * g + e] + bias_v;
+            float v = acc[i][j][4 * g + e];
+            if constexpr (LN) v = rrstd[e] * (v - rmean[e] * ln_sn);
+            v += bias_v;
             if (p.rowbias && m0 + e < p.M) v += p.rowbias[((m0 + e) / p.rows_per_batch) * p.ld_rowbias + n];
             o[e] = v * p.out_scale;
           }
@@ -653,21 +691,27 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
 //     barrier), vmcnt(0) + one s_barrier per tap-stage.
 //   * epilogue = the GEMM's row-major fused epilogue (bias, temb row bias, residual), rows mapped through the patch.
 // Needs Cin % (128 B of channels) == 0, H % 8 == 0, W % 16 == 0; everything else stays on the im2col loader.
-struct Halo {
-  static constexpr int PH = HaloGeom::PH, PW = HaloGeom::PW, HW_ = PW + 2, HPIX = (PH + 2) * (PW + 2);   // 180 halo pixels
-  static constexpr int PIECES = (HPIX + 7) / 8;                 // 1 KB glds pieces of 8 pixels: 23
-  static constexpr int LH = (PIECES + 3) / 4;                   // pieces per wave: 6 (the last round is partial)
-  static constexpr int HALO_BYTES = PIECES * 1024;              // 23 KB
-  static constexpr int BN = HaloGeom::BN, LB = BN / 32;         // weight tile rows, glds per wave per stage
+// PH_ = patch height: 8 (4 waves, 128 output pixels, 78 KB of LDS, 2 blocks per CU) or 16 (8 waves, 256 pixels, 114 KB,
+// 1 block per CU).  The weight tile is the larger stream: 16 KB per tap-stage against 2.6 KB of halo (PH 8) - the 16-row
+// patch feeds twice the MFMAs from the same weights, 4.9 KB of LDS-DMA traffic per MFLOP instead of 8.9 (the direct-to-LDS
+// path, ~9 TB/s chip-wide, is what the 8-row kernel sits on at 1000-1050 TFLOP/s).
+template <int PH_> struct HaloT {
+  static constexpr int PH = PH_, PW = HaloGeom::PW, NW = PH_ / 2, HW_ = PW + 2, HPIX = (PH + 2) * (PW + 2);   // 180 / 324 halo pixels
+  static constexpr int PIECES = (HPIX + 7) / 8;                 // 1 KB glds pieces of 8 pixels: 23 / 41
+  static constexpr int LH = (PIECES + NW - 1) / NW;             // pieces per wave: 6 (the last round is partial)
+  static constexpr int HALO_BYTES = PIECES * 1024;              // 23 / 41 KB
+  static constexpr int BN = HaloGeom::BN, LB = BN / (8 * NW);   // weight tile rows, glds per wave per stage
   static constexpr int B_BYTES = BN * KBYTES;                   // 16 KB
   static constexpr int B_OFF = 2 * HALO_BYTES;
-  static constexpr int LDS_BYTES = 2 * HALO_BYTES + 2 * B_BYTES;   // 79872
+  static constexpr int LDS_BYTES = 2 * HALO_BYTES + 2 * B_BYTES;   // 79872 / 116736
+  static_assert(LH == 6, "the halo pieces ride on taps 0..5");
 };
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const emo_gemm_params p) {
+template <typename T, int PH_>
+__global__ __launch_bounds__(32 * PH_, 2) void conv3x3_halo_kernel(const emo_gemm_params p) {
+  using Halo = HaloT<PH_>;
   constexpr int V = TT<T>::VEC, BK = KBYTES / (int)sizeof(T);
-  constexpr int WTM = 2, WTN = 2, NW = 4, LH = Halo::LH, LB = Halo::LB, BN = Halo::BN;
+  constexpr int WTM = 2, WTN = 2, NW = Halo::NW, LH = Halo::LH, LB = Halo::LB, BN = Halo::BN;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -786,7 +830,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const emo_gemm_par
   emo_gemm_params pe = p;     // the accumulators start at bias + temb row bias: the epilogue sees neither
   pe.bias = nullptr;
   pe.rowbias = nullptr;
-  const bool lds_epi = sizeof(T) == 2 && g_gemm_lds_epi && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!R || (p.ldr & 7) == 0);
+  const bool lds_epi = sizeof(T) == 2 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!R || (p.ldr & 7) == 0);
 
   // ---- stream prologue: halo of the first chunk, weights of the first stage
   setup_halo(h_iter);
@@ -886,7 +930,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const emo_gemm_par
         auto m_of = [&](int i, int row) -> int64_t {
           return ((int64_t)img * p.H + y0 + (wvm * WTM + i) * 2 + (row >> 4)) * p.W_ + x0 + (row & 15);
         };
-        epilogue_lds<T, WTM, WTN, NW, Halo::HALO_BYTES, false>(acc, pe, m_of, wn0, wave, lane, lds_base + ((gc + 1) & 1) * Halo::HALO_BYTES, C, R);
+        const float no_ln[WTM] = {0.f, 0.f};
+        epilogue_lds<T, WTM, WTN, NW, Halo::HALO_BYTES, false>(acc, pe, m_of, wn0, wave, lane, lds_base + ((gc + 1) & 1) * Halo::HALO_BYTES, C, R,
+                                                               nullptr, no_ln, no_ln);
         staged = true;
       }
     }
@@ -965,10 +1011,10 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(const emo_gem
 }
 
 // ------------------------------------------------------------------------------------------ host side
-template <typename T, bool CONV, bool TRANS, int WTM, int WTN, int WVM, int WVN, int NS>
+template <typename T, bool CONV, bool TRANS, int WTM, int WTN, int WVM, int WVN, int NS, bool LN>
 static int launch_gemm(const emo_gemm_params& p, int S, hipStream_t st) {
   using Tile = GemmTile<WTM, WTN, WVM, WVN, NS>;
-  auto kern = gemm_kernel<T, CONV, TRANS, WTM, WTN, WVM, WVN, NS>;
+  auto kern = gemm_kernel<T, CONV, TRANS, WTM, WTN, WVM, WVN, NS, LN>;
   if (Tile::LDS_BYTES > 64 * 1024) {
     static bool once = false;
     if (!once) {
@@ -981,63 +1027,46 @@ static int launch_gemm(const emo_gemm_params& p, int S, hipStream_t st) {
   if (tiles >= (1ll << 31)) return emo_fail(EMO_ERR_BAD_SHAPE, "emo_gemm: too many tiles");
   // persistent launch: as many blocks as the chip holds at once (by LDS, <= 4 per CU), each walking its tiles; a
   // multiple of 8 so that a block's tiles all map to its own XCD
-  static const int persist = env_int("EMO_GEMM_PERSIST", 1);
-  static const int lds_epi_set = [] {
-    const int v = env_int("EMO_GEMM_LDS_EPI", 1);
-    if (v != 1) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_lds_epi), &v, sizeof(int));
-    return v;
-  }();
-  (void)lds_epi_set;
   int64_t slots = (256 * Tile::BPC / S) & ~7;
   if (slots < 8) slots = 8;
-  const int64_t gx = (persist && tiles > slots) ? slots : tiles;
+  const int64_t gx = tiles > slots ? slots : tiles;
   dim3 grid((unsigned)gx, (unsigned)S);
   kern<<<grid, Tile::THREADS, Tile::LDS_BYTES, st>>>(p);
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
 
-#ifndef EMO_NS11
-#define EMO_NS11 2
-#endif
-#ifndef EMO_NS15
-#define EMO_NS15 2
-#endif
-#ifndef EMO_NS22
-#define EMO_NS22 2
-#endif
-template <typename T, bool CONV, bool TRANS>
+// tile shapes (GemmPlan.tile / emo_gemm_params.tile):
+//   EMO_TILE_64x64    2x2 waves of 32x32   few-block short-K shapes, V^T outputs (4 co-resident blocks per CU)
+//   EMO_TILE_128x128  2x2 waves of 64x64
+//   EMO_TILE_128x160  4x1 waves of 32x160  (every SD-1.5 width is a multiple of 160)
+//   EMO_TILE_256x256  2x4 waves of 128x64  the big compute-bound shapes: 7.8 KB of LDS-DMA traffic per MFLOP instead of 15.6
+//   EMO_TILE_256x160  8x1 waves of 32x160  10.2 KB / MFLOP for N = 320 / 640 / 960 / 1920 ... with M large
+//   EMO_TILE_256x320  4x2 waves of 64x160   7.0 KB / MFLOP, A panel read once for N = 320
+// (4-wave 128x256 / 256x128, 192x128, 128x192, 128x320 tiles were measured 15-35 % slower than these at equal LDS traffic per MFMA)
+template <typename T, bool CONV, bool TRANS, bool LN>
 static int dispatch_tile(const emo_gemm_params& p, const GemmPlan& pl, int S, hipStream_t st) {
-  // (4-wave 128x256 / 256x128 tiles were measured 15-35 % slower than the 8-wave 256x256 at equal LDS traffic per MFMA)
-#ifdef EMO_FORCE22
-  return launch_gemm<T, CONV, TRANS, 2, 2, 2, 2, EMO_NS22>(p, S, st);
-#endif
-#ifdef EMO_FORCE_3222   // experiment: 192x128 tile, 4 waves of 96x64, 2 blocks per CU
-  if (!CONV && !TRANS && S == 1) return launch_gemm<T, CONV, TRANS, 3, 2, 2, 2, 2>(p, S, st);
-#endif
-#ifdef EMO_FORCE_2322   // experiment: 128x192 tile, 4 waves of 64x96, 2 blocks per CU
-  if (!CONV && !TRANS && S == 1 && !p.geglu) return launch_gemm<T, CONV, TRANS, 2, 3, 2, 2, 2>(p, S, st);
-#endif
-#ifdef EMO_FORCE_2224   // experiment: 128x256 tile, 8 waves of 64x64
-  if (!CONV && !TRANS && S == 1) return launch_gemm<T, CONV, TRANS, 2, 2, 2, 4, 2>(p, S, st);
-#endif
-#ifdef EMO_FORCE_1542   // experiment: 128x320 tile, 8 waves of 32x160
-  if (!CONV && !TRANS && S == 1 && !p.geglu) return launch_gemm<T, CONV, TRANS, 1, 5, 4, 2, 2>(p, S, st);
-#endif
-  if (pl.big && S == 1) return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, 2>(p, S, st);   // 2x4 waves of 128x64, 2 x 64 KB ring
-  if (pl.small) return launch_gemm<T, CONV, TRANS, 1, 1, 2, 2, EMO_NS11>(p, S, st);   // 2x2 waves of 32x32, 2 x 16 KB ring
-  if (pl.nt5) return launch_gemm<T, CONV, TRANS, 1, 5, 4, 1, EMO_NS15>(p, S, st);   // 4x1 waves of 32x160, 2 x 36 KB ring
-#ifndef EMO_NS22
-#define EMO_NS22 2
-#endif
-  return launch_gemm<T, CONV, TRANS, 2, 2, 2, 2, EMO_NS22>(p, S, st);               // 2x2 waves of 64x64, 4 x 16 KB ring
+  switch (pl.tile) {
+    case EMO_TILE_256x256: return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, 2, LN>(p, S, st);
+    case EMO_TILE_64x64: return launch_gemm<T, CONV, TRANS, 1, 1, 2, 2, 2, LN>(p, S, st);
+    case EMO_TILE_128x160: return launch_gemm<T, CONV, TRANS, 1, 5, 4, 1, 2, LN>(p, S, st);
+    case EMO_TILE_256x160:
+      if constexpr (!CONV && !TRANS) return launch_gemm<T, CONV, TRANS, 1, 5, 8, 1, 2, LN>(p, S, st);
+      break;
+    case EMO_TILE_256x320:
+      if constexpr (!CONV && !TRANS && sizeof(T) == 2) return launch_gemm<T, CONV, TRANS, 2, 5, 4, 2, 2, LN>(p, S, st);
+      break;
+    default: break;
+  }
+  return launch_gemm<T, CONV, TRANS, 2, 2, 2, 2, 2, LN>(p, S, st);
 }
 
 template <typename T>
 static int dispatch_gemm(const emo_gemm_params& p, const GemmPlan& pl, int S, hipStream_t st) {
   const bool conv = p.conv_taps != 0;
-  if (p.transpose_out) return conv ? dispatch_tile<T, true, true>(p, pl, S, st) : dispatch_tile<T, false, true>(p, pl, S, st);
-  return conv ? dispatch_tile<T, true, false>(p, pl, S, st) : dispatch_tile<T, false, false>(p, pl, S, st);
+  if (p.ln_colsum) return p.transpose_out ? dispatch_tile<T, false, true, true>(p, pl, S, st) : dispatch_tile<T, false, false, true>(p, pl, S, st);
+  if (p.transpose_out) return conv ? dispatch_tile<T, true, true, false>(p, pl, S, st) : dispatch_tile<T, false, true, false>(p, pl, S, st);
+  return conv ? dispatch_tile<T, true, false, false>(p, pl, S, st) : dispatch_tile<T, false, false, false>(p, pl, S, st);
 }
 
 
@@ -1053,14 +1082,19 @@ template <typename T> int gemm_run(const emo_gemm_params& p, const GemmPlan& pl,
   return EMO_OK;
 }
 
-template <typename T> int gemm_run_halo(const emo_gemm_params& p, int64_t gx, hipStream_t st) {
+template <typename T, int PH_> static int launch_halo(const emo_gemm_params& p, int64_t gx, hipStream_t st) {
+  using Halo = HaloT<PH_>;
   static bool once = false;
   if (!once) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, PH_>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo::LDS_BYTES);
     if (e != hipSuccess) return emo_fail(EMO_ERR_HIP, "emo_gemm: hipFuncSetAttribute(halo conv): %s", hipGetErrorString(e));
     once = true;
   }
-  conv3x3_halo_kernel<T><<<(unsigned)gx, 256, Halo::LDS_BYTES, st>>>(p);
+  conv3x3_halo_kernel<T, PH_><<<(unsigned)gx, 64 * Halo::NW, Halo::LDS_BYTES, st>>>(p);
   EMO_LAUNCH_CHECK();
   return EMO_OK;
+}
+
+template <typename T> int gemm_run_halo(const emo_gemm_params& p, int ph, int64_t gx, hipStream_t st) {
+  return ph == 16 ? launch_halo<T, 16>(p, gx, st) : launch_halo<T, 8>(p, gx, st);
 }

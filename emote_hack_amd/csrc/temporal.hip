@@ -14,31 +14,7 @@
 
 static constexpr int TA_THREADS = 256;
 
-// <q, k> over one 16-byte chunk pair
-template <typename T> __device__ __forceinline__ float dot16(const uint4& a, const uint4& b, float acc);
-template <> __device__ __forceinline__ float dot16<float>(const uint4& a, const uint4& b, float acc) {
-  acc += __uint_as_float(a.x) * __uint_as_float(b.x);
-  acc += __uint_as_float(a.y) * __uint_as_float(b.y);
-  acc += __uint_as_float(a.z) * __uint_as_float(b.z);
-  acc += __uint_as_float(a.w) * __uint_as_float(b.w);
-  return acc;
-}
-template <> __device__ __forceinline__ float dot16<f16_t>(const uint4& a, const uint4& b, float acc) {
-  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a.x), __builtin_bit_cast(h2, b.x), acc, false);   // v_dot2_f32_f16
-  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a.y), __builtin_bit_cast(h2, b.y), acc, false);
-  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a.z), __builtin_bit_cast(h2, b.z), acc, false);
-  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a.w), __builtin_bit_cast(h2, b.w), acc, false);
-  return acc;
-}
-template <> __device__ __forceinline__ float dot16<bf16_t>(const uint4& a, const uint4& b, float acc) {
-  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.x), __builtin_bit_cast(bf2, b.x), acc, false);   // v_dot2_f32_bf16
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.y), __builtin_bit_cast(bf2, b.y), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.z), __builtin_bit_cast(bf2, b.z), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.w), __builtin_bit_cast(bf2, b.w), acc, false);
-  return acc;
-}
+// (dot16<T>: <q, k> over one 16-byte chunk pair - common.h)
 
 // All index arithmetic is thread-fixed or incremental: the first version decomposed a flat index with runtime div / mod in
 // every loop iteration and was VALU-bound on that (124 us for 252 MB at the 64x64 level).

@@ -200,9 +200,14 @@ def layer_norm(x: torch.Tensor, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0
 
 
 # ----------------------------------------------------------------------------- GEMM / conv
+GEMM_TILE = 0   # tuning hook for tools/bench: pins emo_gemm_params.tile of every dense GEMM that does not pass tile=
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, geglu=False,
-         out_scale=1.0, out=None, transpose_rows=0, transpose_ld=0, conv=None, split_k=None) -> torch.Tensor:
+         out_scale=1.0, out=None, transpose_rows=0, transpose_ld=0, conv=None, split_k=None, ln=None, tile=None) -> torch.Tensor:
     """out = epilogue(a @ w.T).  a (M, K) rows view; w (N, K) contiguous in the compute dtype.
+    ln = (colsum f32 (N,), eps): LayerNorm over K folded into the GEMM - a holds the RAW rows, w / bias carry the folded
+    affine (emo_hip.h emo_gemm_params.ln_colsum).
     conv = dict(H, W, Cin, stride, upsample2x, Ho, Wo) selects the implicit 3x3 conv loader (then a is
     the (B*F*H*W, >=Cin) NHWC input and M = B*F*Ho*Wo).
     transpose_rows=L stores V^T per batch of L rows: out (M/L, N, transpose_ld)."""
@@ -242,6 +247,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
         p.conv_taps, p.H, p.W_, p.Cin = 9, conv["H"], conv["W"], conv["Cin"]
         p.stride, p.upsample2x, p.Ho, p.Wo = conv["stride"], int(conv["upsample2x"]), conv["Ho"], conv["Wo"]
     p.dtype = dt(a)
+    p.tile = int(tile if tile is not None else (GEMM_TILE if conv is None else 0))
+    if ln is not None:
+        colsum, eps = ln
+        assert conv is None and colsum.dtype == torch.float32 and colsum.numel() == N
+        p.ln_colsum, p.ln_eps = colsum.data_ptr(), float(eps)
+        split_k = 1   # the row statistics are accumulated over the whole K by one block
     lib = _lib.load()
     sk = lib.emo_gemm_suggest_split_k(M, N, K, p.dtype, int(bool(geglu)), int(bool(transpose_rows))) if split_k is None else split_k
     ws = None
@@ -253,7 +264,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
             esz * (float(M) * (K if conv is None else conv["Cin"]) + float(N) * K + float(M) * n_out),
             lambda: check(_lib.load().emo_gemm(C.byref(p), _stream()), "emo_gemm"),
             tag=f"M={M} N={N} K={K}" + (" geglu" if geglu else "") + (" T" if transpose_rows else "") +
-                (f" s{conv['stride']}{'u' if conv['upsample2x'] else ''}" if conv is not None else "") + (f" sk{sk}" if sk > 1 else ""))
+                (f" s{conv['stride']}{'u' if conv['upsample2x'] else ''}" if conv is not None else "") + (f" sk{sk}" if sk > 1 else "") +
+                (" ln" if ln is not None else ""))
     return out
 
 

@@ -41,6 +41,13 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+# Every LayerNorm of the transformer / motion blocks feeds a Linear (attention.py:279-316, motion_module.py:216-224,282-303):
+# the affine is folded into the Linear's operands at load and the normalisation into the GEMM (emo_gemm_params.ln_colsum) -
+# the LayerNorm launches and the HBM round trip of the normalised tokens disappear.  The one exception is the LN1 of a block
+# whose output is WRITTEN to a reference bank (mutual_self_attention.py:230): that tensor has to exist.
+FOLD_LAYERNORM = True
+
+
 class _Ctx:
     """Per-forward geometry + reference-attention state."""
 
@@ -200,6 +207,29 @@ class UNet3DConditionModel:
             o[..., :ci] = t.permute(0, 2, 3, 1)
             return o.reshape(co, 9 * cip).to(dtp).contiguous()
 
+        def ln_fold(wt, b, norm):
+            """(W, bias) of a Linear behind LayerNorm `norm` -> (W * gamma rounded to the compute dtype, its row sums, bias +
+            W . beta): LN(x) W^T + b = rstd (x W'^T - mean colsum) + b'."""
+            g_, be = m[norm + ".weight"].float(), m[norm + ".bias"].float()
+            wt = wt.reshape(wt.shape[0], -1).float()
+            wp = (wt * g_[None, :]).to(dtp)
+            bp = wt.to(dtp).float() @ be
+            if b is not None:
+                bp = bp + b.float()
+            return wp.contiguous(), wp.float().sum(1).contiguous(), bp.contiguous()
+
+        def geglu_rows(t):  # interleave (32 value, 32 gate) rows / entries
+            n = t.shape[0] // 2
+            if n % 32:
+                raise EmoHipError("GEGLU width must be a multiple of 32")
+            return torch.cat([t[:n].reshape(n // 32, 32, *t.shape[1:]), t[n:].reshape(n // 32, 32, *t.shape[1:])], 1).reshape(t.shape)
+
+        def geglu_ln(prefix, norm):
+            wp, cs, bp = ln_fold(m[prefix + ".weight"], m[prefix + ".bias"], norm)
+            return geglu_rows(wp).contiguous(), geglu_rows(cs).contiguous(), geglu_rows(bp).contiguous()
+
+        fold = self._fold_ln = bool(FOLD_LAYERNORM)
+
         def geglu(prefix):  # interleave (32 value, 32 gate)
             wt, b = m[prefix + ".weight"], m[prefix + ".bias"]
             n = wt.shape[0] // 2
@@ -249,12 +279,18 @@ class UNet3DConditionModel:
                 w[tb + ".attn1.k"] = lin(tb + ".attn1.to_k.weight")
                 w[tb + ".attn1.v"] = lin(tb + ".attn1.to_v.weight")
                 w[tb + ".attn1.o.w"], w[tb + ".attn1.o.b"] = lin(tb + ".attn1.to_out.0.weight"), f32(tb + ".attn1.to_out.0.bias")
-                w[tb + ".attn2.q"] = lin(tb + ".attn2.to_q.weight")
                 w[tb + ".attn2.k"] = lin(tb + ".attn2.to_k.weight")
                 w[tb + ".attn2.v"] = lin(tb + ".attn2.to_v.weight")
                 w[tb + ".attn2.o.w"], w[tb + ".attn2.o.b"] = lin(tb + ".attn2.to_out.0.weight"), f32(tb + ".attn2.to_out.0.bias")
-                w[tb + ".ff1.w"], w[tb + ".ff1.b"] = geglu(tb + ".ff.net.0.proj")
                 w[tb + ".ff2.w"], w[tb + ".ff2.b"] = lin(tb + ".ff.net.2.weight"), f32(tb + ".ff.net.2.bias")
+                if fold:
+                    w[tb + ".attn1.qk_ln"] = ln_fold(torch.cat([m[tb + ".attn1.to_q.weight"], m[tb + ".attn1.to_k.weight"]], 0), None, tb + ".norm1")
+                    w[tb + ".attn1.v_ln"] = ln_fold(m[tb + ".attn1.to_v.weight"], None, tb + ".norm1")
+                    w[tb + ".attn2.q_ln"] = ln_fold(m[tb + ".attn2.to_q.weight"], None, tb + ".norm2")
+                    w[tb + ".ff1_ln"] = geglu_ln(tb + ".ff.net.0.proj", tb + ".norm3")
+                else:
+                    w[tb + ".attn2.q"] = lin(tb + ".attn2.to_q.weight")
+                    w[tb + ".ff1.w"], w[tb + ".ff1.b"] = geglu(tb + ".ff.net.0.proj")
             for mo in blk.motions:
                 if mo is None:
                     continue
@@ -265,13 +301,22 @@ class UNet3DConditionModel:
                 w[p + ".proj_out.w"], w[p + ".proj_out.b"] = lin(p + ".proj_out.weight"), f32(p + ".proj_out.bias")
                 for k in range(mo.n_attn):
                     ab = f"{tb}.attention_blocks.{k}"
-                    w[ab + ".qkv"] = torch.cat([m[ab + ".to_q.weight"], m[ab + ".to_k.weight"], m[ab + ".to_v.weight"]], 0).to(dtp).contiguous()
+                    wqkv = torch.cat([m[ab + ".to_q.weight"], m[ab + ".to_k.weight"], m[ab + ".to_v.weight"]], 0)
                     w[ab + ".o.w"], w[ab + ".o.b"] = lin(ab + ".to_out.0.weight"), f32(ab + ".to_out.0.bias")
-                    w[f"{tb}.norms.{k}.g"], w[f"{tb}.norms.{k}.b"] = f32(f"{tb}.norms.{k}.weight"), f32(f"{tb}.norms.{k}.bias")
-                    if mo.pe_len:
-                        w[ab + ".pe"] = m[ab + ".pos_encoder.pe"][0].float().contiguous()
-                w[tb + ".ff_norm.g"], w[tb + ".ff_norm.b"] = f32(tb + ".ff_norm.weight"), f32(tb + ".ff_norm.bias")
-                w[tb + ".ff1.w"], w[tb + ".ff1.b"] = geglu(tb + ".ff.net.0.proj")
+                    if fold:
+                        w[ab + ".qkv_ln"] = ln_fold(wqkv, None, f"{tb}.norms.{k}")
+                        if mo.pe_len:   # (LN(x) + pe[f]) W^T = LN(x) W^T + (pe W^T)[f]: a per-frame row bias (motion_module.py:246-248,282-283)
+                            w[ab + ".pe_w"] = (m[ab + ".pos_encoder.pe"][0].float() @ wqkv.to(dtp).float().t()).contiguous()
+                    else:
+                        w[ab + ".qkv"] = wqkv.to(dtp).contiguous()
+                        w[f"{tb}.norms.{k}.g"], w[f"{tb}.norms.{k}.b"] = f32(f"{tb}.norms.{k}.weight"), f32(f"{tb}.norms.{k}.bias")
+                        if mo.pe_len:
+                            w[ab + ".pe"] = m[ab + ".pos_encoder.pe"][0].float().contiguous()
+                if fold:
+                    w[tb + ".ff1_ln"] = geglu_ln(tb + ".ff.net.0.proj", tb + ".ff_norm")
+                else:
+                    w[tb + ".ff_norm.g"], w[tb + ".ff_norm.b"] = f32(tb + ".ff_norm.weight"), f32(tb + ".ff_norm.bias")
+                    w[tb + ".ff1.w"], w[tb + ".ff1.b"] = geglu(tb + ".ff.net.0.proj")
                 w[tb + ".ff2.w"], w[tb + ".ff2.b"] = lin(tb + ".ff.net.2.weight"), f32(tb + ".ff.net.2.bias")
             if blk.sampler:
                 w[blk.sampler + ".w"], w[blk.sampler + ".b"] = conv3(blk.sampler + ".conv.weight"), f32(blk.sampler + ".conv.bias")
@@ -290,6 +335,7 @@ class UNet3DConditionModel:
                 w[f"controlnet_down_blocks.{k}.w"], w[f"controlnet_down_blocks.{k}.b"] = lin(f"controlnet_down_blocks.{k}.weight"), f32(f"controlnet_down_blocks.{k}.bias")
             w["controlnet_mid_block.w"], w["controlnet_mid_block.b"] = lin("controlnet_mid_block.weight"), f32("controlnet_mid_block.bias")
         self._w = w
+        self._pe_rows = {}
 
     # ------------------------------------------------------------------ blocks (all HIP launches)
     def _resnet(self, r, x, temb_all, c: _Ctx, H, W, scale=1.0, out=None):
@@ -347,15 +393,23 @@ class UNet3DConditionModel:
         h = ops.group_norm(x, w[p + ".norm.g"], w[p + ".norm.b"], nb, self.config["norm_num_groups"], 1e-6, False)
         h = ops.gemm(h, w[p + ".proj_in.w"], w[p + ".proj_in.b"])
         # --- self attention (+ reference bank)
-        n1 = ops.layer_norm(h, w[tb + ".norm1.g"], w[tb + ".norm1.b"])
-        if c.bank_mode == "write" and p in c.active:
-            c.written[p] = n1  # LN1 output (mutual_self_attention.py:230)
-        if a.gutted:
-            # ReferenceNet's last transformer (appearance_encoder.py:613-621): behind LN1 there are no parameters and the
-            # model's output is discarded - the pass ends here
-            return _STOP
-        qk = ops.gemm(n1, w[tb + ".attn1.qk"])
-        vt = ops.gemm(n1, w[tb + ".attn1.v"], transpose_rows=HW, transpose_ld=_round_up(HW, 8))
+        fold = self._fold_ln and not a.gutted and not (c.bank_mode == "write" and p in c.active)
+        LN_EPS = 1e-5   # nn.LayerNorm default (attention.py:240-252)
+        if fold:        # LN1 folded into the q|k and V^T projections
+            wq, cs, bq = w[tb + ".attn1.qk_ln"]
+            qk = ops.gemm(h, wq, bq, ln=(cs, LN_EPS))
+            wv, cs, bv = w[tb + ".attn1.v_ln"]
+            vt = ops.gemm(h, wv, bv, ln=(cs, LN_EPS), transpose_rows=HW, transpose_ld=_round_up(HW, 8))
+        else:
+            n1 = ops.layer_norm(h, w[tb + ".norm1.g"], w[tb + ".norm1.b"])
+            if c.bank_mode == "write" and p in c.active:
+                c.written[p] = n1  # LN1 output (mutual_self_attention.py:230)
+            if a.gutted:
+                # ReferenceNet's last transformer (appearance_encoder.py:613-621): behind LN1 there are no parameters and the
+                # model's output is discarded - the pass ends here
+                return _STOP
+            qk = ops.gemm(n1, w[tb + ".attn1.qk"])
+            vt = ops.gemm(n1, w[tb + ".attn1.v"], transpose_rows=HW, transpose_ld=_round_up(HW, 8))
         kw = {}
         if c.bank_mode == "read" and p in c.active and (p in c.banks or p in c.bank_kv):
             if p in c.bank_kv:    # projected once per group of timesteps by the sampler (pipeline._reference_group)
@@ -369,8 +423,12 @@ class UNet3DConditionModel:
         att = ops.attention(qk[:, :C_], qk[:, C_:], vt, HW, B=nb, Lq=HW, heads=heads, d=d, scale=scale, **kw)
         h = ops.gemm(att, w[tb + ".attn1.o.w"], w[tb + ".attn1.o.b"], residual=h)
         # --- cross attention to the text / audio context
-        n2 = ops.layer_norm(h, w[tb + ".norm2.g"], w[tb + ".norm2.b"])
-        q2 = ops.gemm(n2, w[tb + ".attn2.q"])
+        if self._fold_ln:
+            wq, cs, bq = w[tb + ".attn2.q_ln"]
+            q2 = ops.gemm(h, wq, bq, ln=(cs, LN_EPS))
+        else:
+            n2 = ops.layer_norm(h, w[tb + ".norm2.g"], w[tb + ".norm2.b"])
+            q2 = ops.gemm(n2, w[tb + ".attn2.q"])
         if ctx_kv is not None:
             kc, vct = ctx_kv[p]
         else:
@@ -378,8 +436,12 @@ class UNet3DConditionModel:
         att = ops.attention(q2, kc, vct, ctx_len, B=nb, Lq=HW, heads=heads, d=d, scale=scale, seg0_div=ctx_div)
         h = ops.gemm(att, w[tb + ".attn2.o.w"], w[tb + ".attn2.o.b"], residual=h)
         # --- GEGLU feed-forward
-        n3 = ops.layer_norm(h, w[tb + ".norm3.g"], w[tb + ".norm3.b"])
-        g = ops.gemm(n3, w[tb + ".ff1.w"], w[tb + ".ff1.b"], geglu=True)
+        if self._fold_ln:
+            wf, cs, bf = w[tb + ".ff1_ln"]
+            g = ops.gemm(h, wf, bf, geglu=True, ln=(cs, LN_EPS))
+        else:
+            n3 = ops.layer_norm(h, w[tb + ".norm3.g"], w[tb + ".norm3.b"])
+            g = ops.gemm(n3, w[tb + ".ff1.w"], w[tb + ".ff1.b"], geglu=True)
         h = ops.gemm(g, w[tb + ".ff2.w"], w[tb + ".ff2.b"], residual=h)
         return ops.gemm(h, w[p + ".proj_out.w"], w[p + ".proj_out.b"], residual=x, out=out)
 
@@ -397,12 +459,26 @@ class UNet3DConditionModel:
         h = ops.gemm(h, w[p + ".proj_in.w"], w[p + ".proj_in.b"])
         for k in range(mo.n_attn):
             ab = f"{tb}.attention_blocks.{k}"
-            n = ops.layer_norm(h, w[f"{tb}.norms.{k}.g"], w[f"{tb}.norms.{k}.b"], pe=w.get(ab + ".pe"), rows_per_frame=HW, frames=c.F)
-            qkv = ops.gemm(n, w[ab + ".qkv"])
+            if self._fold_ln:   # LN folded into the q|k|v projection, the positional encoding into a per-frame row bias
+                wq, cs, bq = w[ab + ".qkv_ln"]
+                kw = {}
+                if mo.pe_len:
+                    key = (ab, c.B, c.F)
+                    if key not in self._pe_rows:
+                        self._pe_rows[key] = w[ab + ".pe_w"][:c.F].repeat(c.B, 1).contiguous()
+                    kw = dict(rowbias=self._pe_rows[key], rows_per_batch=HW)
+                qkv = ops.gemm(h, wq, bq, ln=(cs, 1e-5), **kw)
+            else:
+                n = ops.layer_norm(h, w[f"{tb}.norms.{k}.g"], w[f"{tb}.norms.{k}.b"], pe=w.get(ab + ".pe"), rows_per_frame=HW, frames=c.F)
+                qkv = ops.gemm(n, w[ab + ".qkv"])
             att = ops.temporal_attention(qkv, c.B, c.F, HW, heads, d, d ** -0.5)
             h = ops.gemm(att, w[ab + ".o.w"], w[ab + ".o.b"], residual=h)
-        n = ops.layer_norm(h, w[tb + ".ff_norm.g"], w[tb + ".ff_norm.b"])
-        g = ops.gemm(n, w[tb + ".ff1.w"], w[tb + ".ff1.b"], geglu=True)
+        if self._fold_ln:
+            wf, cs, bf = w[tb + ".ff1_ln"]
+            g = ops.gemm(h, wf, bf, geglu=True, ln=(cs, 1e-5))
+        else:
+            n = ops.layer_norm(h, w[tb + ".ff_norm.g"], w[tb + ".ff_norm.b"])
+            g = ops.gemm(n, w[tb + ".ff1.w"], w[tb + ".ff1.b"], geglu=True)
         h = ops.gemm(g, w[tb + ".ff2.w"], w[tb + ".ff2.b"], residual=h)
         return ops.gemm(h, w[p + ".proj_out.w"], w[p + ".proj_out.b"], residual=x, out=out)
 

@@ -123,6 +123,15 @@ typedef struct {
    * emo_gemm_workspace_bytes(p) bytes) and a second kernel reduces them in a fixed order (deterministic)
    * and applies the epilogue.  split_k <= 1: single pass, workspace unused. */
   int split_k; void* workspace;
+  /* LayerNorm folded into the GEMM (attention.py:279-316, motion_module.py:216-224: every LayerNorm of the transformer
+   * blocks feeds a Linear).  With ln_colsum != NULL the kernel computes
+   *     C = epilogue( ((A - mean_m) * rstd_m) . W^T ),   mean_m / rstd_m = LayerNorm statistics of row m of A over K (eps ln_eps)
+   * as rstd_m * (A.W^T - mean_m * ln_colsum[n]) with ln_colsum[n] = sum_k W[n][k]; the row statistics are accumulated from
+   * the A fragments the MFMA loop reads anyway (no extra pass over A, no normalised copy of A in HBM).  The caller folds
+   * the LayerNorm affine into the operands once at load: W <- W * gamma[k], bias <- bias + W . beta.  Dense, split_k <= 1. */
+  const float* ln_colsum; float ln_eps;
+  int tile;   /* 0 = planned from the shape; 1..6 pin a tile (64x64, 128x128, 128x160, 256x256, 256x160, 256x320) - tuning hook
+                 in the spirit of a BLAS algorithm id; combinations a tile cannot serve fall back to the nearest one that can */
 } emo_gemm_params;
 int emo_gemm(const emo_gemm_params* p, void* stream);
 /* heuristic split factor for (M, N, K) and the workspace it needs */

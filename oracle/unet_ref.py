@@ -112,6 +112,12 @@ def feed_forward(sd, p, x):
     return _lin(sd, p + ".net.2", h * F.gelu(gate))
 
 
+class GuttedBlock(Exception):
+    """Raised by the ReferenceNet's last transformer block (appearance_encoder.py:613-621: attn1 projections parameter-less,
+    attn2 None, norm2 / norm3 / ff / proj_out Identity): behind its LN1 - the last bank - nothing carries parameters and the
+    model output is discarded (EMOAnimationPipeline.py:711-716), so the oracle's write pass ends there."""
+
+
 def basic_transformer_block(sd, p, x, ctx, heads, frames, bank=None, bank_mode=None, uc_rows=None,
                             written=None, upcast=False):
     """attention.py:276-320 (plain) and mutual_self_attention.py:199-284 (write / read hooks).
@@ -123,6 +129,8 @@ def basic_transformer_block(sd, p, x, ctx, heads, frames, bank=None, bank_mode=N
     n1 = F.layer_norm(x, x.shape[-1:], sd[p + ".norm1.weight"], sd[p + ".norm1.bias"])
     if bank_mode == "write":
         written.append(n1.clone())
+    if (p + ".attn1.to_q.weight") not in sd:
+        raise GuttedBlock(p)
     if bank_mode == "read" and bank is not None:
         rep = bank.unsqueeze(1).repeat(1, frames, 1, 1).reshape(-1, *bank.shape[1:])[: x.shape[0]]
         h = attention(sd, p + ".attn1", n1, torch.cat([n1, rep], dim=1), heads, upcast) + x
@@ -273,8 +281,11 @@ def unet_forward(sd, cfg, sample, timestep, encoder_hidden_states, *, bank_mode=
             if bank_mode == "write":
                 lst = []
                 kw.update(bank_mode="write", written=lst)
-                y = transformer3d(sd, p, x, ctx, heads, G, ulp, **kw)
-                written[p] = lst[0]
+                try:
+                    y = transformer3d(sd, p, x, ctx, heads, G, ulp, **kw)
+                finally:
+                    if lst:
+                        written[p] = lst[0]
                 return y
             kw.update(bank_mode="read", bank=(banks or {}).get(p), uc_rows=uc_rows)
         return transformer3d(sd, p, x, ctx, heads, G, ulp, **kw)
@@ -307,16 +318,21 @@ def unet_forward(sd, cfg, sample, timestep, encoder_hidden_states, *, bank_mode=
         x = x + mid_block_additional_residual
 
     rhd = list(reversed(hd))
-    for i, t in enumerate(cfg["up_block_types"]):
-        p = f"up_blocks.{i}"
-        for j in range(cfg["layers_per_block"] + 1):
-            x = torch.cat([x, skips.pop()], dim=1)  # unet_3d_blocks.py:627-629,729-731
-            x = resnet_block(sd, f"{p}.resnets.{j}", x, emb, G, eps)
-            if t.startswith("CrossAttn"):
-                x = tf(f"{p}.attentions.{j}", x, rhd[i])
-            x = mm(f"{p}.motion_modules.{j}", x)
-        if (p + ".upsamplers.0.conv.weight") in sd:
-            x = upsample(sd, p + ".upsamplers.0", x)
+    try:
+        for i, t in enumerate(cfg["up_block_types"]):
+            p = f"up_blocks.{i}"
+            for j in range(cfg["layers_per_block"] + 1):
+                x = torch.cat([x, skips.pop()], dim=1)  # unet_3d_blocks.py:627-629,729-731
+                x = resnet_block(sd, f"{p}.resnets.{j}", x, emb, G, eps)
+                if t.startswith("CrossAttn"):
+                    x = tf(f"{p}.attentions.{j}", x, rhd[i])
+                x = mm(f"{p}.motion_modules.{j}", x)
+            if (p + ".upsamplers.0.conv.weight") in sd:
+                x = upsample(sd, p + ".upsamplers.0", x)
+    except GuttedBlock:
+        if bank_mode != "write":
+            raise
+        return None, written
 
     if "conv_out.weight" in sd:  # the AppearanceEncoder has no conv_norm_out/conv_out
         x = F.silu(group_norm_5d(sd, "conv_norm_out", x, G, eps))

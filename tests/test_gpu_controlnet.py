@@ -113,11 +113,11 @@ def test_denoise_loop_with_controlnet_vs_oracle(graphs):
     from emote_hack_amd.pipeline import EMOAnimationPipeline
     cn, cn_sd = build_controlnet(torch.float32)
     usd = synth_state_dict(param_shapes(build_spec(cases.TINY_MOTION)))
-    rsd = synth_state_dict(param_shapes(build_spec(cases.TINY, has_out=False)), prefix=cases.REF_PREFIX)
     unet = UNet3DConditionModel(**cases.TINY_MOTION)
     unet.load_state_dict(usd)
     unet.to(DEV, torch.float32)
     ref = AppearanceEncoderModel(**cases.TINY)
+    rsd = synth_state_dict(param_shapes(ref.spec), prefix=cases.REF_PREFIX)   # the reference-shaped (gutted) ReferenceNet key set
     ref.load_state_dict(rsd)
     ref.to(DEV, torch.float32)
     lat, refl, text = seeded_randn((1, 4, 8, 16, 16), 5), seeded_randn((1, 4, 16, 16), 3), seeded_randn((2, 5, 32), 2)

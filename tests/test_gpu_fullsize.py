@@ -92,34 +92,42 @@ def test_cfg2_reference_net_on_eager_vs_graph_replay_bit_identical(cfg2_models):
     assert torch.equal(lat_e, lat_g)
 
 
-def test_cfg2_reference_group_size_does_not_change_the_result(cfg2_models):
-    """ReferenceNet timesteps batched 3 per pass vs the reference's one pass per step: the same banks up to the summation
-    order of the (larger-M) GEMM tiles."""
-    unet, ref = cfg2_models
-    _, eps_1 = _run_loop(unet, ref, 2, graphs=False, ref_group=1)
-    _, eps_3 = _run_loop(unet, ref, 2, graphs=False, ref_group=3)
-    for a, b in zip(eps_1, eps_3):
-        e = (a - b).abs()
-        assert float(e.mean()) < 2e-3 * float(a.abs().mean()) + 1e-5, (float(e.mean()), float(a.abs().mean()))
-
-
-def test_cfg2_reference_net_on_bf16_vs_f32(cfg2_models):
-    """eps of the first step, bf16 HIP vs f32 HIP, ReferenceNet on, CFG 7.5: within the reference's own bf16 error scale
-    (the guidance formula amplifies the per-branch error by up to 1 + 2 * 7.5)."""
+@pytest.fixture(scope="module")
+def cfg2_models_f32(cfg2_models):
     from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
     from emote_hack_amd.unet import UNet3DConditionModel
     unet, ref = cfg2_models
-    _, eps_b = _run_loop(unet, ref, 1, graphs=False, ref_group=1)
     u32 = UNet3DConditionModel(**cases.SD15_MOTION)
     u32.load_state_dict(unet._master)
     u32.to(DEV, torch.float32)
     r32 = AppearanceEncoderModel(**cases.SD15)
     r32.load_state_dict(ref._master)
     r32.to(DEV, torch.float32)
+    return u32, r32
+
+
+def test_cfg2_reference_group_size_does_not_change_the_result(cfg2_models_f32):
+    """ReferenceNet timesteps batched 3 per pass vs the reference's one pass per step (and the second HBM slot / the row
+    index / the look-ahead stream that come with it), in f32 where a wrong bank row would show: the same eps at north_star's
+    tolerance (only the summation order of the larger-M GEMM tiles differs)."""
+    u32, r32 = cfg2_models_f32
+    _, eps_1 = _run_loop(u32, r32, 3, graphs=False, ref_group=1)
+    _, eps_3 = _run_loop(u32, r32, 3, graphs=False, ref_group=2)
+    for a, b in zip(eps_1, eps_3):
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-4)
+
+
+def test_cfg2_reference_net_on_bf16_vs_f32(cfg2_models, cfg2_models_f32):
+    """eps of the first step, bf16 HIP vs f32 HIP, ReferenceNet on, CFG 7.5: within the reference's own bf16 error scale
+    (the guidance formula amplifies the per-branch error by up to 1 + 2 * 7.5)."""
+    unet, ref = cfg2_models
+    u32, r32 = cfg2_models_f32
+    _, eps_b = _run_loop(unet, ref, 1, graphs=False, ref_group=1)
     _, eps_f = _run_loop(u32, r32, 1, graphs=False, ref_group=1)
     from tests.test_gpu_unet import yardstick
     k_mean, _ = yardstick(torch.bfloat16)
     e = (eps_b[0] - eps_f[0]).abs()
+    print("cfg2 eps bf16 vs f32: mean err", float(e.mean()), "mean |eps|", float(eps_f[0].abs().mean()))
     assert float(e.mean()) <= 16 * 1.25 * k_mean * float(eps_f[0].abs().mean()), (float(e.mean()), float(eps_f[0].abs().mean()))
 
 

@@ -212,6 +212,93 @@ def test_conv3x3_halo_path(dtype, n, H, W, Cin, Cout):
     close(got, ref.permute(0, 2, 3, 1).reshape(-1, Cout), dtype)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ph", [8, 16])
+@pytest.mark.parametrize("n,H,W,Cin,Cout", [(3, 16, 32, 128, 320), (2, 32, 16, 64, 132), (5, 16, 16, 192, 128)])
+def test_conv3x3_halo_patch_heights(dtype, ph, n, H, W, Cin, Cout):
+    """Both patch heights of the halo kernel (8 rows / 4 waves and 16 rows / 8 waves; the planner picks by tile count, the test
+    pins them through emo_gemm_params.tile) on the same inputs - several patches per frame, ragged N, temb row bias per frame."""
+    o = ops()
+    x = q(seeded_randn((n, Cin, H, W), 131), dtype)
+    wt, bias = q(seeded_randn((Cout, Cin, 3, 3), 132) / math.sqrt(9 * Cin), dtype), 0.1 * seeded_randn((Cout,), 133)
+    res = q(seeded_randn((n, Cout, H, W), 134), dtype)
+    rb = seeded_randn((n, Cout), 135)
+    ref = F.conv2d(x, wt, bias, padding=1) + rb[:, :, None, None] + res
+    rows = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous()
+    wp = wt.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)
+    rrows = res.permute(0, 2, 3, 1).reshape(-1, Cout).contiguous()
+    got, _, _ = o.conv3x3(rows.to(DEV).to(dtype), wp.to(DEV).to(dtype).contiguous(), bias.to(DEV), n, H, W,
+                          rowbias=rb.to(DEV), rows_per_batch=H * W, residual=rrows.to(DEV).to(dtype), split_k=1, tile=1 if ph == 8 else 2)
+    close(got, ref.permute(0, 2, 3, 1).reshape(-1, Cout), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("M,N,K,res", [(1000, 320, 320, True), (700, 640, 192, False), (513, 960, 64, True)])
+def test_gemm_every_tile_shape(dtype, tile, M, N, K, res):
+    """emo_gemm_params.tile pins 64x64 / 128x128 / 128x160 / 256x256 / 256x160 / 256x320: every tile shape must produce the
+    same GEMM (ragged M and N edges, residual epilogue)."""
+    o = ops()
+    a, w = q(seeded_randn((M, K), 112), dtype), q(seeded_randn((N, K), 113) / math.sqrt(K), dtype)
+    bias, r = 0.1 * seeded_randn((N,), 114), q(seeded_randn((M, N), 115), dtype)
+    ref = F.linear(a, w, bias) + (r if res else 0)
+    got = o.gemm(a.to(DEV).to(dtype), w.to(DEV).to(dtype), bias.to(DEV), residual=r.to(DEV).to(dtype) if res else None, tile=tile, split_k=1)
+    close(got, ref, dtype)
+
+
+def _ln_fold(wt, bias, gamma, beta, dtype):
+    """what unet._pack does: (W * gamma rounded to the compute dtype, its row sums, bias + W . beta)"""
+    wp = (wt * gamma[None, :]).to(dtype)
+    bp = wt.to(dtype).float() @ beta + (bias if bias is not None else 0)
+    return wp, wp.float().sum(1), bp
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("M,N,K,mode", [(1000, 640, 320, "plain"), (520, 2560, 320, "geglu"), (768, 320, 320, "trans"),
+                                        (2 * 3 * 64, 960, 320, "pe"), (300, 1280, 1280, "plain")])
+def test_gemm_layernorm_fold(dtype, tile, M, N, K, mode):
+    """LayerNorm folded into the GEMM (attention.py:279-316 LN -> Linear; motion_module.py:282-283 LN -> +PE -> Linear):
+    out = LN(x) W^T + b, with a mean offset 2x the spread to exercise the colsum subtraction - plain / GEGLU / V^T epilogues, the
+    temporal PE as a per-frame row bias, every tile shape."""
+    o = ops()
+    if mode == "geglu" and tile in (1, 3, 5):
+        pytest.skip("GEGLU pairs 32-column tiles: planner falls back")
+    x = q(seeded_randn((M, K), 120) * 1.5 + 3.0 * seeded_randn((M, 1), 121), dtype)
+    wt = seeded_randn((N, K), 122) / math.sqrt(K)
+    bias = 0.1 * seeded_randn((N,), 123) if mode != "trans" else None
+    gamma, beta = 1 + 0.2 * seeded_randn((K,), 124), 0.2 * seeded_randn((K,), 125)
+    n = F.layer_norm(x, (K,), gamma, beta)
+    wq = q(wt, dtype)
+    kw, y = {}, None
+    if mode == "pe":
+        frames, rpf = 3, M // 6
+        pe = seeded_randn((24, K), 126)
+        fr = (torch.arange(M) // rpf) % frames
+        y = F.linear(n + pe[fr], wq, bias)
+        pe_w = (pe @ wq.t())[:frames].repeat(2, 1).contiguous()
+        kw = dict(rowbias=pe_w.to(DEV), rows_per_batch=rpf)
+    else:
+        y = F.linear(n, wq, bias)
+    if mode == "geglu":
+        y = y[:, :N // 2] * F.gelu(y[:, N // 2:])
+    wp, cs, bp = _ln_fold(wt, bias, gamma, beta, dtype)
+    if mode == "geglu":   # (32 value, 32 gate) row interleave of unet._pack
+        il = lambda t: torch.cat([t[:N // 2].reshape(N // 64, 32, *t.shape[1:]), t[N // 2:].reshape(N // 64, 32, *t.shape[1:])], 1).reshape(t.shape)
+        wp, cs, bp = il(wp), il(cs), il(bp)
+    a = x.to(DEV).to(dtype)
+    if mode == "trans":
+        L = M // 3
+        got = o.gemm(a, wp.to(DEV).contiguous(), bp.to(DEV), ln=(cs.to(DEV).contiguous(), 1e-5), transpose_rows=L, transpose_ld=L, tile=tile)
+        got = got.float().cpu().permute(0, 2, 1).reshape(M, N)
+    else:
+        got = o.gemm(a, wp.to(DEV).contiguous(), bp.to(DEV).contiguous(), ln=(cs.to(DEV).contiguous(), 1e-5), geglu=(mode == "geglu"),
+                     tile=tile, **kw)
+    # the fold rounds W * gamma (not LN(x)) to the compute dtype: same error scale as the unfused pair
+    tol = TOL[dtype]
+    torch.testing.assert_close(got.float().cpu(), y, rtol=tol["rtol"], atol=tol["atol"] * (2.0 if dtype != torch.float32 else 1.0))
+
+
 def attn_ref(qh, k, v, scale):
     s = torch.matmul(qh, k.transpose(-1, -2)) * scale
     return torch.matmul(s.softmax(-1), v)
