@@ -33,8 +33,9 @@ class GemmParams(C.Structure):
         ("upsample2x", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
         ("dtype", C.c_int),
         ("split_k", C.c_int), ("workspace", C.c_void_p),
-        ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
+        ("ln_colsum", C.c_void_p), ("ln_stats", C.c_void_p),
         ("tile", C.c_int),
+        ("conv_asym", C.c_int),
     ]
 
 
@@ -69,6 +70,7 @@ SIGNATURES = {
     "emo_groupnorm_stats": (_i, [_p, _i, _p, _i, _i64, _i, _i, _i, _p]),
     "emo_groupnorm_apply": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _f, _i, _i, _p]),
     "emo_layernorm": (_i, [_p, _i, _p, _p, _p, _i, _i64, _i, _f, _p, _i, _i, _i, _p]),
+    "emo_layernorm_stats": (_i, [_p, _i, _p, _i64, _i, _f, _i, _p]),
     "emo_gemm": (_i, [C.POINTER(GemmParams), _p]),
     "emo_gemm_suggest_split_k": (_i, [_i64, _i, _i, _i, _i, _i]),
     "emo_gemm_workspace_bytes": (C.c_size_t, [_i64, _i, _i]),
@@ -81,6 +83,9 @@ SIGNATURES = {
     "emo_speed_bucket": (_i, [_p, _p, _p, _i, _i, _p]),
     "emo_gather_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "emo_add_rowbias": (_i, [_p, _i, _p, _i, _p, _i, _i64, _i, _i, _i, _p]),
+    "emo_softmax_rows": (_i, [_p, _i64, _p, _i64, _i64, _i, _f, _i, _p]),
+    "emo_audio_windows": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "emo_rows_to_video": (_i, [_p, _i64, _p, _i, _i, _i, _i, _f, _f, _f, _f, _i, _p]),
 }
 
 _lib = None

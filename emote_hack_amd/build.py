@@ -15,7 +15,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libemo_hip.so")
 # the GEMM / conv kernels are instantiated per element type in their own translation units (parallel compile)
 SOURCES = ["elementwise.hip", "norm.hip", "gemm.hip", "gemm_f32.hip", "gemm_bf16.hip", "gemm_f16.hip", "attention.hip", "temporal.hip",
-           "conditioning.hip"]
+           "conditioning.hip", "frontend.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-pass-failed"]

@@ -291,3 +291,22 @@ def stage3_combine(unet_fn, noisy_latents, face_features, speed_embed):
     o = ops.ncfhw_to_rows(out.to(dev).unsqueeze(2), torch.float32)
     o = ops.add_rowbias(o, speed_embed.to(dev).float().contiguous(), H * W)
     return ops.rows_to_ncfhw(o, B, out.shape[1], 1, H, W).squeeze(2)
+
+
+# ----------------------------------------------------------------------------- audio front-end
+def audio_windows(hidden_states: torch.Tensor, m: int = 2, n: int = 2) -> torch.Tensor:
+    """Wav2VecFeatureExtractor.extract_features_from_wav, the windowing half (Net.py:649-667): for every audio frame f the
+    wav2vec2 `last_hidden_state` rows [f - m, f + n], zero-padded where they fall outside the clip, flattened -
+    (T, D) or (1, T, D) -> (T, (m + n + 1) * D).  The wav2vec2 encoder itself (third-party `transformers`, weights from the
+    network) stays caller-supplied: pass its `last_hidden_state`.  Bit-exact (a gather; emo_audio_windows)."""
+    hs = hidden_states[0] if hidden_states.dim() == 3 else hidden_states
+    return ops.audio_windows(hs, m, n).reshape(hs.shape[0], -1)
+
+
+def audio_context_tokens(windows: torch.Tensor, num_video_frames: int, feature_dim: int = 768) -> torch.Tensor:
+    """Per-video-frame attn2 context for the UNet (`audio_features=`): windows (T_a, W * D) -> (F, W, D).  The reference never
+    aligns the 50 Hz wav2vec frames with the video frames (the audio path is unwired); this picks audio frame
+    floor(i * T_a / F) for video frame i (index arithmetic only - a documented design choice, not reference behaviour)."""
+    Ta = windows.shape[0]
+    idx = torch.div(torch.arange(num_video_frames, device=windows.device) * Ta, num_video_frames, rounding_mode="floor").clamp_(max=Ta - 1)
+    return windows.index_select(0, idx).reshape(num_video_frames, -1, feature_dim)

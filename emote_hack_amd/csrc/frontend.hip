@@ -1,0 +1,130 @@
+// frontend.hip - the small kernels either side of the denoising loop:
+//   emo_softmax_rows   : softmax(scale * x) over the columns of a materialised score matrix - the single-head, 512-wide
+//                        attention of the VAE mid block (diffusers AutoencoderKL, called at EMOAnimationPipeline.py:291-307,
+//                        402-414) runs as two MFMA GEMMs around it (head dim 512 is outside the flash kernel's register
+//                        budget, and at one frame per call the 32 MB score matrix is cheap)
+//   emo_audio_windows  : per audio frame, the wav2vec features of frames [f-m, f+n] zero-padded at the ends
+//                        (Net.py:649-667 Wav2VecFeatureExtractor.extract_features_from_wav) - pure indexing, bit-exact
+//   emo_rows_to_video  : decoded NHWC rows -> (B, C, F, H, W) f32 with video = (x / 2 + 0.5).clamp(0, 1)
+//                        (EMOAnimationPipeline.py:303-306)
+// All HBM-bound and tiny; 16-byte accesses where the geometry allows.
+#include "common.h"
+
+static inline int fgrid(int64_t work, int block) {
+  int64_t g = (work + block - 1) / block;
+  if (g > 256 * 8) g = 256 * 8;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// one wavefront per row; two passes over the row (online max / sum, then normalise).  N is a few thousand (h*w of a latent)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, int64_t M,
+                                                           int N, float scale) {
+  constexpr int V = TT<T>::VEC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float c = scale * 1.4426950408889634f;
+  for (int64_t m = (int64_t)blockIdx.x * 4 + wave; m < M; m += (int64_t)gridDim.x * 4) {
+    const T* xr = x + m * ldx;
+    T* yr = y + m * ldy;
+    float mx = -3.0e38f, sum = 0.f;
+    const int NV = N / V;
+    for (int i = lane; i < NV; i += 64) {
+      float f[V];
+      unpack16<T>(*(const uint4*)(xr + i * V), f);
+      float lm = f[0];
+#pragma unroll
+      for (int e = 1; e < V; e++) lm = fmaxf(lm, f[e]);
+      const float nm = fmaxf(mx, lm);
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < V; e++) s += exp2f((f[e] - nm) * c);
+      sum = sum * exp2f((mx - nm) * c) + s;
+      mx = nm;
+    }
+    for (int i = NV * V + lane; i < N; i += 64) {   // ragged tail
+      const float v = TT<T>::ld(xr + i), nm = fmaxf(mx, v);
+      sum = sum * exp2f((mx - nm) * c) + exp2f((v - nm) * c);
+      mx = nm;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float om = __shfl_xor(mx, o, 64), os = __shfl_xor(sum, o, 64);
+      const float nm = fmaxf(mx, om);
+      sum = sum * exp2f((mx - nm) * c) + os * exp2f((om - nm) * c);
+      mx = nm;
+    }
+    const float inv = 1.0f / sum;
+    for (int i = lane; i < NV; i += 64) {
+      float f[V];
+      unpack16<T>(*(const uint4*)(xr + i * V), f);
+#pragma unroll
+      for (int e = 0; e < V; e++) f[e] = exp2f((f[e] - mx) * c) * inv;
+      *(uint4*)(yr + i * V) = pack16<T>(f);
+    }
+    for (int i = NV * V + lane; i < N; i += 64) TT<T>::st(yr + i, exp2f((TT<T>::ld(xr + i) - mx) * c) * inv);
+  }
+}
+
+extern "C" int emo_softmax_rows(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t M, int N, float scale, int dtype, void* stream) {
+  EMO_CHECK(x && y, EMO_ERR_NULL, "emo_softmax_rows: null pointer");
+  EMO_CHECK(emo_dtype_ok(dtype), EMO_ERR_BAD_DTYPE, "emo_softmax_rows: dtype %d", dtype);
+  const int V = emo_dtype_vec(dtype);
+  EMO_CHECK(M > 0 && N > 0 && ldx >= N && ldy >= N && ldx % V == 0 && ldy % V == 0, EMO_ERR_BAD_SHAPE,
+            "emo_softmax_rows: M=%lld N=%d ldx=%lld ldy=%lld", (long long)M, N, (long long)ldx, (long long)ldy);
+  EMO_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0, EMO_ERR_BAD_SHAPE, "emo_softmax_rows: 16-byte alignment");
+  EMO_DISPATCH(dtype, "emo_softmax_rows", (softmax_rows_kernel<T><<<fgrid(M, 4), 256, 0, as_stream(stream)>>>((const T*)x, ldx, (T*)y, ldy, M, N, scale)));
+  EMO_LAUNCH_CHECK();
+  return EMO_OK;
+}
+
+// out[t][j][:] = feats[t - m + j][:] if 0 <= t - m + j < T else 0     (j = 0 .. m + n)
+template <typename T>
+__global__ __launch_bounds__(256) void audio_windows_kernel(const T* __restrict__ feats, T* __restrict__ out, int Tn, int D, int m, int n) {
+  const int wlen = m + n + 1;
+  const int64_t total = (int64_t)Tn * wlen * D;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const int64_t r = i / D;
+    const int j = (int)(r % wlen), t = (int)(r / wlen);
+    const int src = t - m + j;
+    out[i] = (src >= 0 && src < Tn) ? feats[(int64_t)src * D + d] : (T)0;
+  }
+}
+
+extern "C" int emo_audio_windows(const void* feats, void* out, int T_, int D, int m, int n, int dtype, void* stream) {
+  EMO_CHECK(feats && out, EMO_ERR_NULL, "emo_audio_windows: null pointer");
+  EMO_CHECK(T_ > 0 && D > 0 && m >= 0 && n >= 0, EMO_ERR_BAD_SHAPE, "emo_audio_windows: T=%d D=%d m=%d n=%d", T_, D, m, n);
+  EMO_CHECK(emo_dtype_ok(dtype), EMO_ERR_BAD_DTYPE, "emo_audio_windows: dtype %d", dtype);
+  const int64_t total = (int64_t)T_ * (m + n + 1) * D;
+  EMO_DISPATCH(dtype, "emo_audio_windows", (audio_windows_kernel<T><<<fgrid(total, 256), 256, 0, as_stream(stream)>>>((const T*)feats, (T*)out, T_, D, m, n)));
+  EMO_LAUNCH_CHECK();
+  return EMO_OK;
+}
+
+// rows ((b f) h w, ld >= C) -> (B, C, F, H, W) f32, y = clamp(x * mul + add, lo, hi)
+template <typename T>
+__global__ __launch_bounds__(256) void rows_to_video_kernel(const T* __restrict__ x, int64_t ld, float* __restrict__ y, int B, int C, int F,
+                                                            int HW, float mul, float add, float lo, float hi) {
+  const int64_t total = (int64_t)B * C * F * HW;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW);
+    int64_t r = i / HW;
+    const int f = (int)(r % F); r /= F;
+    const int c = (int)(r % C);
+    const int b = (int)(r / C);
+    const float v = TT<T>::ld(x + ((int64_t)(b * F + f) * HW + p) * ld + c) * mul + add;
+    y[i] = fminf(fmaxf(v, lo), hi);
+  }
+}
+
+extern "C" int emo_rows_to_video(const void* x, int64_t ld, float* y, int B, int C, int F, int HW, float mul, float add, float lo, float hi,
+                                 int dtype, void* stream) {
+  EMO_CHECK(x && y, EMO_ERR_NULL, "emo_rows_to_video: null pointer");
+  EMO_CHECK(B > 0 && C > 0 && F > 0 && HW > 0 && ld >= C, EMO_ERR_BAD_SHAPE, "emo_rows_to_video: bad shape");
+  EMO_CHECK(emo_dtype_ok(dtype), EMO_ERR_BAD_DTYPE, "emo_rows_to_video: dtype %d", dtype);
+  const int64_t total = (int64_t)B * C * F * HW;
+  EMO_DISPATCH(dtype, "emo_rows_to_video", (rows_to_video_kernel<T><<<fgrid(total, 256), 256, 0, as_stream(stream)>>>((const T*)x, ld, y, B, C, F, HW, mul, add, lo, hi)));
+  EMO_LAUNCH_CHECK();
+  return EMO_OK;
+}

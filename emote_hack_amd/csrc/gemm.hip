@@ -37,21 +37,22 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
     EMO_CHECK(p.H > 0 && p.W_ > 0 && p.Ho > 0 && p.Wo > 0 && (p.stride == 1 || p.stride == 2), EMO_ERR_BAD_SHAPE, "emo_gemm: conv geometry");
     EMO_CHECK(p.M % ((int64_t)p.Ho * p.Wo) == 0, EMO_ERR_BAD_SHAPE, "emo_gemm: conv M not a multiple of Ho*Wo");
     const int He = p.upsample2x ? 2 * p.H : p.H, We = p.upsample2x ? 2 * p.W_ : p.W_;
-    EMO_CHECK(p.Ho == (He + 2 - 3) / p.stride + 1 && p.Wo == (We + 2 - 3) / p.stride + 1, EMO_ERR_BAD_SHAPE, "emo_gemm: conv output size");
+    const int pad_tot = p.conv_asym ? 1 : 2;
+    EMO_CHECK(p.Ho == (He + pad_tot - 3) / p.stride + 1 && p.Wo == (We + pad_tot - 3) / p.stride + 1, EMO_ERR_BAD_SHAPE, "emo_gemm: conv output size");
   }
   if (!p.transpose_out) {
     EMO_CHECK(((uintptr_t)p.C % 16) == 0 && (!p.residual || ((uintptr_t)p.residual % 8) == 0), EMO_ERR_BAD_SHAPE, "emo_gemm: C/residual alignment");
   }
   const int S = p.split_k > 1 ? p.split_k : 1;
-  if (p.ln_colsum) {
-    EMO_CHECK(!conv && S == 1 && p.ln_eps > 0.f, EMO_ERR_UNSUPPORTED,
-              "emo_gemm: the LayerNorm fold needs a dense, single-pass GEMM (conv=%d split_k=%d)", (int)conv, S);
-    EMO_CHECK(p.N % 4 == 0 && ((uintptr_t)p.ln_colsum % 16) == 0 && (!p.bias || ((uintptr_t)p.bias % 16) == 0), EMO_ERR_BAD_SHAPE,
-              "emo_gemm: the LayerNorm fold needs N %% 4 == 0 and 16-byte aligned colsum / bias");
+  if (p.ln_colsum || p.ln_stats) {
+    EMO_CHECK(p.ln_colsum && p.ln_stats, EMO_ERR_NULL, "emo_gemm: the LayerNorm fold needs both ln_colsum and ln_stats");
+    EMO_CHECK(!conv && S == 1, EMO_ERR_UNSUPPORTED, "emo_gemm: the LayerNorm fold needs a dense, single-pass GEMM (conv=%d split_k=%d)", (int)conv, S);
+    EMO_CHECK(p.N % 4 == 0 && ((uintptr_t)p.ln_colsum % 16) == 0 && ((uintptr_t)p.ln_stats % 8) == 0 && (!p.bias || ((uintptr_t)p.bias % 16) == 0),
+              EMO_ERR_BAD_SHAPE, "emo_gemm: the LayerNorm fold needs N %% 4 == 0 and aligned colsum / stats / bias");
   }
   {
     const int bk = KBYTES / (p.dtype == EMO_F32 ? 4 : 2);
-    if (conv && p.stride == 1 && !p.upsample2x && !p.transpose_out && !p.geglu && S == 1 && p.Cin % bk == 0 &&
+    if (conv && p.stride == 1 && !p.conv_asym && !p.upsample2x && !p.transpose_out && !p.geglu && S == 1 && p.Cin % bk == 0 &&
         p.H % 8 == 0 && p.W_ % HaloGeom::PW == 0 && (p.N & 3) == 0 &&
         (!p.rowbias || (p.rows_per_batch % (p.H * p.W_) == 0 && (p.ld_rowbias & 3) == 0))) {
       const int64_t nt = (p.N + HaloGeom::BN - 1) / HaloGeom::BN;

@@ -55,18 +55,14 @@ static GemmPlan plan_gemm(int64_t M, int N, int K, int dtype, int geglu, int tra
   const int64_t blocks128 = ((M + 127) / 128) * ((N + (nt5 ? 159 : 127)) / (nt5 ? 160 : 128));
   const bool small = !big && !geglu && nk <= 24 && (blocks128 < 256 || transpose_out);
   pl.tile = big ? EMO_TILE_256x256 : (small ? EMO_TILE_64x64 : (nt5 ? EMO_TILE_128x160 : EMO_TILE_128x128));
-  // 256-row tiles for N = 320 / 640 / 960 / 1920 ... when M is large: the 128-row tiles move 14-15.6 KB through the
-  // direct-to-LDS path per MFLOP and sit on that path's ~9 TB/s (measured 540-640 TFLOP/s on every such shape); 256x160
-  // moves 10.2, 256x320 7.0 (and reads the A panel once instead of once per 160-column tile)
-  if (!big && !small && !transpose_out && !geglu && dtype != EMO_F32 && N % 160 == 0) {
-    const int64_t t320 = ((M + 255) / 256) * ((N + 319) / 320), t160 = ((M + 255) / 256) * (N / 160);
-    if (N % 320 == 0 && t320 >= 192) pl.tile = EMO_TILE_256x320;
-    else if (t160 >= 192) pl.tile = EMO_TILE_256x160;
-  }
+  // (256x160 / 256x320 tiles exist behind the hint: on the UNet's shapes they measured SLOWER than the 128-row tiles - 342 /
+  // 250 vs 351 TFLOP/s at M=98304 N=K=320, 576 / 732 vs 696-725 at M=24576 N=640 K=2560 - one block per CU leaves the
+  // epilogue uncovered, which costs more than the lighter LDS-DMA stream saves; the planner does not pick them)
   if (hint > 0) {
     pl.tile = hint;
     if ((hint == EMO_TILE_256x160 || hint == EMO_TILE_256x320) && (transpose_out || (hint == EMO_TILE_256x320 && dtype == EMO_F32))) pl.tile = EMO_TILE_128x160;
-    if (geglu && (hint == EMO_TILE_64x64 || hint == EMO_TILE_128x160 || hint == EMO_TILE_256x160)) pl.tile = EMO_TILE_128x128;   // GEGLU pairs tiles: even WTN
+    // GEGLU pairs a value tile with its gate tile inside one wave: only the even-WTN shapes (128x128, 256x256) serve it
+    if (geglu && pl.tile != EMO_TILE_128x128 && pl.tile != EMO_TILE_256x256) pl.tile = EMO_TILE_128x128;
   }
   int bm, bn;
   tile_dims(pl.tile, bm, bn);

@@ -42,9 +42,12 @@
 // Epilogue fused: bias, per-batch row bias (temb), GEGLU, residual, scale, row-major or V^T store.
 // Split-K (small M): f32 partial slabs + a fixed-order reduce/epilogue kernel (deterministic).
 // conv3x3_halo_kernel (below): the stride-1 3x3 convs with input-halo reuse instead of the im2col loader.
-// LayerNorm fold (template LN): the LayerNorms of the transformer blocks all feed a Linear; with ln_colsum set the kernel
-// multiplies the RAW rows and applies rstd_m * (acc - mean_m * colsum[n]) in the epilogue, the row statistics coming from
-// v_dot2 sums over the A fragments the MFMA loop reads anyway - the LayerNorm launches and their HBM round trip disappear.
+// LayerNorm fold (template LN): the LayerNorms of the transformer blocks all feed a Linear; with ln_colsum / ln_stats set the
+// kernel multiplies the RAW rows: out = rstd_m * (acc0 + x . W'^T), acc0 = b'[n] / rstd_m - mean_m * colsum[n] - the whole
+// correction rides in the accumulator init and the epilogue pays one multiply.  (mean, rstd) come from a read-only statistics
+// pass (emo_layernorm_stats: one read of x instead of LayerNorm's read + write + the GEMM's re-read).  A first version summed
+// the statistics from the A fragments inside the MFMA loop and applied colsum / bias in the epilogue: no extra pass, but two
+// float4 loads per output quad with nothing to hide them - 20-30 % slower GEMMs at N >= 960, a net loss on the GEGLU shapes.
 // emo_gemm_params.tile pins a tile shape (0 = planned); the planner's thresholds are the measured ones of DESIGN.md 7.
 #pragma once
 #include "gemm_api.h"
@@ -88,12 +91,11 @@ __device__ __forceinline__ uint4 lds_read16(unsigned addr) {
 
 // Row-major fused epilogue of one 32-row MFMA tile row (lane <-> output row m; register quad g of tile j <-> columns
 // j*32 + 8*g + 4*half + {0..3}): bias, per-batch row bias, GEGLU, residual, scale, 8-byte (bf16) / 16-byte (f32) stores.
-// ln_s != nullptr: LayerNorm folded into the GEMM - the accumulator holds A.W^T of the RAW rows and becomes
-// rstd_m * (acc - mean_m * colsum[n]) before the bias (see emo_gemm_params.ln_colsum).
+// ln: LayerNorm folded into the GEMM - the accumulator started at bias / rstd_m - mean_m * colsum[n] and holds that plus A.W^T
+// of the RAW rows; one multiply by rstd_m finishes it (see emo_gemm_params.ln_colsum).
 template <typename T, int WTN>
 __device__ __forceinline__ void epilogue_row(const f32x16 (&acc)[WTN], const emo_gemm_params& p, int64_t m, bool m_ok, int wn0, int half,
-                                             T* __restrict__ C, const T* __restrict__ R, const float* __restrict__ ln_s = nullptr,
-                                             float ln_mean = 0.f, float ln_rstd = 1.f) {
+                                             T* __restrict__ C, const T* __restrict__ R, bool ln = false, float ln_rstd = 1.f) {
   const float* rbias = (p.rowbias && m_ok) ? p.rowbias + (m / p.rows_per_batch) * p.ld_rowbias : nullptr;
   const int n_out = p.geglu ? p.N / 2 : p.N;
   const bool vec_ok = (p.N & 3) == 0 && ((p.ldc | (R ? p.ldr : 0)) & 3) == 0 && (!p.rowbias || (p.ld_rowbias & 3) == 0);
@@ -107,23 +109,13 @@ __device__ __forceinline__ void epilogue_row(const f32x16 (&acc)[WTN], const emo
       if (nw0 >= p.N) continue;
       float o[4] = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
       if (vec_ok) {   // the whole quad is in range (N % 4 == 0)
-        if (ln_s) {
-          const float4 s4 = *(const float4*)(ln_s + nw0);
-          const float nm = -ln_mean;
-          o[0] = ln_rstd * fmaf(nm, s4.x, o[0]); o[1] = ln_rstd * fmaf(nm, s4.y, o[1]);
-          o[2] = ln_rstd * fmaf(nm, s4.z, o[2]); o[3] = ln_rstd * fmaf(nm, s4.w, o[3]);
-        }
+        if (ln) { o[0] *= ln_rstd; o[1] *= ln_rstd; o[2] *= ln_rstd; o[3] *= ln_rstd; }
         if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
         if (rbias) { const float4 b4 = *(const float4*)(rbias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
         if (p.geglu) {
           float gt[4] = {acc[(j + 1) % WTN][4 * g], acc[(j + 1) % WTN][4 * g + 1], acc[(j + 1) % WTN][4 * g + 2],
                          acc[(j + 1) % WTN][4 * g + 3]};
-          if (ln_s) {
-            const float4 s4 = *(const float4*)(ln_s + nw0 + 32);
-            const float nm = -ln_mean;
-            gt[0] = ln_rstd * fmaf(nm, s4.x, gt[0]); gt[1] = ln_rstd * fmaf(nm, s4.y, gt[1]);
-            gt[2] = ln_rstd * fmaf(nm, s4.z, gt[2]); gt[3] = ln_rstd * fmaf(nm, s4.w, gt[3]);
-          }
+          if (ln) { gt[0] *= ln_rstd; gt[1] *= ln_rstd; gt[2] *= ln_rstd; gt[3] *= ln_rstd; }
           if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0 + 32); gt[0] += b4.x; gt[1] += b4.y; gt[2] += b4.z; gt[3] += b4.w; }
           if constexpr (sizeof(T) == 2) {
             float g0, g1, g2, g3;
@@ -156,12 +148,12 @@ __device__ __forceinline__ void epilogue_row(const f32x16 (&acc)[WTN], const emo
           const int nw = nw0 + e;
           if (nw >= p.N || !m_ok) continue;
           float v = o[e];
-          if (ln_s) v = ln_rstd * (v - ln_mean * ln_s[nw]);
+          if (ln) v *= ln_rstd;
           if (p.bias) v += p.bias[nw];
           if (rbias) v += rbias[nw];
           if (p.geglu) {
             float gt = acc[(j + 1) % WTN][4 * g + e];
-            if (ln_s) gt = ln_rstd * (gt - ln_mean * ln_s[nw + 32]);
+            if (ln) gt *= ln_rstd;
             if (p.bias) gt += p.bias[nw + 32];
             v *= gelu_for<T>(gt);
           }
@@ -189,8 +181,7 @@ __device__ __forceinline__ void lds_write8(unsigned addr, unsigned lo, unsigned 
 // m_of(i, row) -> global output row of row `row` (0..31) of this wave's MFMA tile row i, or -1 if it does not exist
 template <typename T, int WTM, int WTN, int NW, int XBYTES, bool GEGLU, typename MF>
 __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], const emo_gemm_params& p, MF m_of, int wn0, int wave, int lane,
-                                             unsigned xbase, T* __restrict__ C, const T* __restrict__ R,
-                                             const float* __restrict__ ln_s, const float (&ln_mean)[WTM], const float (&ln_rstd)[WTM]) {
+                                             unsigned xbase, T* __restrict__ C, const T* __restrict__ R, bool ln, const float (&ln_rstd)[WTM]) {
   static_assert(sizeof(T) == 2, "the staged epilogue is for the 2-byte element types");
   constexpr int OTW = GEGLU ? WTN / 2 : WTN;                  // 32-column output tiles per wave row
   constexpr int JMAX = (XBYTES / (NW * 32) - 16) / 64;        // tiles per pass that fit this wave's share of the slot
@@ -234,20 +225,12 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], cons
           const int nw0 = wn0 + jv * 32 + 8 * g + 4 * half;    // column in W-row space
           float o[4] = {acc[i][jv][4 * g], acc[i][jv][4 * g + 1], acc[i][jv][4 * g + 2], acc[i][jv][4 * g + 3]};
           if (nw0 < p.N) {
-            if (ln_s) {   // LayerNorm folded into the GEMM: rstd_m * (acc - mean_m * colsum[n])
-              const float4 s4 = *(const float4*)(ln_s + nw0);
-              const float nm = -ln_mean[i], rs = ln_rstd[i];
-              o[0] = rs * fmaf(nm, s4.x, o[0]); o[1] = rs * fmaf(nm, s4.y, o[1]); o[2] = rs * fmaf(nm, s4.z, o[2]); o[3] = rs * fmaf(nm, s4.w, o[3]);
-            }
+            if (ln) { const float rs = ln_rstd[i]; o[0] *= rs; o[1] *= rs; o[2] *= rs; o[3] *= rs; }   // LayerNorm fold: finish with rstd_m
             if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
             if (rbias) { const float4 b4 = *(const float4*)(rbias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
             if constexpr (GEGLU) {
               float gt[4] = {acc[i][jv + 1][4 * g], acc[i][jv + 1][4 * g + 1], acc[i][jv + 1][4 * g + 2], acc[i][jv + 1][4 * g + 3]};
-              if (ln_s) {
-                const float4 s4 = *(const float4*)(ln_s + nw0 + 32);
-                const float nm = -ln_mean[i], rs = ln_rstd[i];
-                gt[0] = rs * fmaf(nm, s4.x, gt[0]); gt[1] = rs * fmaf(nm, s4.y, gt[1]); gt[2] = rs * fmaf(nm, s4.z, gt[2]); gt[3] = rs * fmaf(nm, s4.w, gt[3]);
-              }
+              if (ln) { const float rs = ln_rstd[i]; gt[0] *= rs; gt[1] *= rs; gt[2] *= rs; gt[3] *= rs; }
               if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0 + 32); gt[0] += b4.x; gt[1] += b4.y; gt[2] += b4.z; gt[3] += b4.w; }
               float g0, g1, g2, g3;
               gelu_erf_poly2(gt[0], gt[1], g0, g1);
@@ -309,6 +292,57 @@ __device__ __forceinline__ void init_acc_bias(f32x16 (&acc)[WTM][WTN], const flo
 #pragma unroll
       for (int i = 0; i < WTM; i++) { acc[i][j][4 * g] = b4.x; acc[i][j][4 * g + 1] = b4.y; acc[i][j][4 * g + 2] = b4.z; acc[i][j][4 * g + 3] = b4.w; }
     }
+}
+
+// LayerNorm fold: out = rstd_m * (x . W'^T - mean_m * colsum[n]) + b'[n] = rstd_m * (acc0 + x . W'^T) with
+// acc0 = b'[n] / rstd_m - mean_m * colsum[n]: the whole correction enters through the accumulator init (its loads hide behind
+// the tile's first stage like the bias init) and the epilogue is one multiply per element.
+template <int WTM, int WTN>
+__device__ __forceinline__ void init_acc_ln(f32x16 (&acc)[WTM][WTN], const float* __restrict__ bias, const float* __restrict__ colsum,
+                                            const float (&mean)[WTM], const float (&rstd)[WTM], int wn0, int half, int N) {
+  float stdv[WTM];
+#pragma unroll
+  for (int i = 0; i < WTM; i++) stdv[i] = 1.0f / rstd[i];
+#pragma unroll
+  for (int j = 0; j < WTN; j++)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int n0 = wn0 + j * 32 + 8 * g + 4 * half;
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n0 < N) {   // N % 4 == 0 checked by the caller
+        s4 = *(const float4*)(colsum + n0);
+        if (bias) b4 = *(const float4*)(bias + n0);
+      }
+#pragma unroll
+      for (int i = 0; i < WTM; i++) {
+        acc[i][j][4 * g] = fmaf(-mean[i], s4.x, b4.x * stdv[i]); acc[i][j][4 * g + 1] = fmaf(-mean[i], s4.y, b4.y * stdv[i]);
+        acc[i][j][4 * g + 2] = fmaf(-mean[i], s4.z, b4.z * stdv[i]); acc[i][j][4 * g + 3] = fmaf(-mean[i], s4.w, b4.w * stdv[i]);
+      }
+    }
+}
+// V^T layout: lane <-> column n = wn0 + j*32 + l31, register 4g + e <-> row 8g + 4half + e (statistics of row r live in lane r)
+template <int WTM, int WTN>
+__device__ __forceinline__ void init_acc_ln_trans(f32x16 (&acc)[WTM][WTN], const float* __restrict__ bias, const float* __restrict__ colsum,
+                                                  const float (&mean)[WTM], const float (&rstd)[WTM], int wn0, int l31, int half, int N) {
+  float sn[WTN], bnv[WTN];
+#pragma unroll
+  for (int j = 0; j < WTN; j++) {
+    const int n = wn0 + j * 32 + l31;
+    sn[j] = n < N ? colsum[n] : 0.f;
+    bnv[j] = (bias && n < N) ? bias[n] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < WTM; i++) {
+    const float stdv = 1.0f / rstd[i];
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float rm = __shfl(mean[i], 8 * g + 4 * half + e, 64), rs = __shfl(stdv, 8 * g + 4 * half + e, 64);
+#pragma unroll
+        for (int j = 0; j < WTN; j++) acc[i][j][4 * g + e] = fmaf(-rm, sn[j], bnv[j] * rs);
+      }
+  }
 }
 
 struct ConvRow { int img, iy0, ix0; };
@@ -378,7 +412,8 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
         const int64_t mm = a_ok[i] ? m : 0;
         const int img = (int)(mm / hw), rem = (int)(mm % hw);
         const int oy = rem / p.Wo, ox = rem % p.Wo;
-        a_cr[i].img = img; a_cr[i].iy0 = oy * p.stride - 1; a_cr[i].ix0 = ox * p.stride - 1;
+        const int pad_tl = p.conv_asym ? 0 : 1;   // (0, 1, 0, 1) padding: nothing above / left of the image
+        a_cr[i].img = img; a_cr[i].iy0 = oy * p.stride - pad_tl; a_cr[i].ix0 = ox * p.stride - pad_tl;
       } else {
         const int64_t mc = m < p.M ? m : p.M - 1;
         a_ptr[i] = A + mc * p.lda + klog * V + (int64_t)kt0 * BK;
@@ -460,7 +495,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
   // row-major single-pass outputs start their accumulators at the bias; the epilogues then see bias == nullptr
   const bool bias_in_acc = !LN && !TRANS && nsplit == 1 && p.bias != nullptr && (p.N & 3) == 0;
   emo_gemm_params pe = p;
-  if (bias_in_acc) pe.bias = nullptr;
+  if (bias_in_acc || LN) pe.bias = nullptr;   // (LN: the folded bias enters the accumulator init scaled by 1 / rstd)
   // coalesced LDS-staged epilogue (bf16, row-major, single pass): needs whole 16-byte chunks everywhere
   const int n_out_all = p.geglu ? p.N / 2 : p.N;
   const bool use_lds_epi = !TRANS && sizeof(T) == 2 && nsplit == 1 && nk > 0 && (n_out_all & 7) == 0 && (p.N & 3) == 0 &&
@@ -487,7 +522,21 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
   const int tiles_left = (tiles_all - 1 - c_iter) / G;   // tiles of this block after this one
 
   f32x16 acc[WTM][WTN];
-  if (bias_in_acc) {
+  // LayerNorm fold: (mean, rstd) of this lane's A rows (lane <-> row l31 of MFMA tile row i) from the statistics pass
+  float ln_mean[WTM], ln_rstd[WTM];
+#pragma unroll
+  for (int i = 0; i < WTM; i++) { ln_mean[i] = 0.f; ln_rstd[i] = 1.f; }
+  if constexpr (LN) {
+#pragma unroll
+    for (int i = 0; i < WTM; i++) {
+      int64_t m = bm + wvm * 32 * WTM + i * 32 + l31;
+      if (m >= p.M) m = p.M - 1;
+      const float2 st2 = *(const float2*)(p.ln_stats + 2 * m);
+      ln_mean[i] = st2.x; ln_rstd[i] = st2.y;
+    }
+    if constexpr (!TRANS) init_acc_ln<WTM, WTN>(acc, p.bias, p.ln_colsum, ln_mean, ln_rstd, bn + wvn * 32 * WTN, half, p.N);
+    else init_acc_ln_trans<WTM, WTN>(acc, p.bias, p.ln_colsum, ln_mean, ln_rstd, bn + wvn * 32 * WTN, l31, half, p.N);
+  } else if (bias_in_acc) {
     init_acc_bias<WTM, WTN>(acc, p.bias, bn + wvn * 32 * WTN, half, p.N);
   } else {
 #pragma unroll
@@ -497,11 +546,6 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
   }
-  // LayerNorm fold: per-lane partial (sum, sum of squares) of the A rows this lane reads as MFMA fragments; lanes l and
-  // l + 32 hold the two halves of every row's chunks
-  float ln_sum[WTM], ln_sq[WTM];
-#pragma unroll
-  for (int i = 0; i < WTM; i++) { ln_sum[i] = 0.f; ln_sq[i] = 0.f; }
 
   for (int kt = 0; kt < nk; kt++, gs++) {
     // stage gs must have landed; up to NS-2 younger stages may still be in flight - fewer at the end of the stream, and none
@@ -548,10 +592,6 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
         if constexpr (TRANS) acc[i][j] = mma16<T>(fa[cur][i], fb[cur][j], acc[i][j]);   // rows = m, lane = n
         else acc[i][j] = mma16<T>(fb[cur][j], fa[cur][i], acc[i][j]);                   // rows = n, lane = m
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (LN && (q % WTN) == 0) {   // row statistics of fragment row i, on the VALU beside the MFMAs that consume it
-          ln_sum[i] = dot16<T>(fa[cur][i], ones16<T>(), ln_sum[i]);
-          ln_sq[i] = dot16<T>(fa[cur][i], fa[cur][i], ln_sq[i]);
-        }
         static_for<n_side>([&](auto O) {
           constexpr int o = decltype(O)::value;
           if constexpr ((o * NMMA) / n_side == q) {
@@ -568,22 +608,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
   const int64_t wm0 = bm + wvm * 32 * WTM;
   const int wn0 = bn + wvn * 32 * WTN;
 
-  float ln_mean[WTM], ln_rstd[WTM];
-  const float* ln_s = LN ? p.ln_colsum : nullptr;
-  if constexpr (LN) {
-    const float invK = 1.0f / (float)p.K;
-#pragma unroll
-    for (int i = 0; i < WTM; i++) {
-      const float su = ln_sum[i] + __shfl_xor(ln_sum[i], 32, 64), sq = ln_sq[i] + __shfl_xor(ln_sq[i], 32, 64);
-      const float mean = su * invK;
-      ln_mean[i] = mean;
-      ln_rstd[i] = rsqrtf(fmaxf(sq * invK - mean * mean, 0.f) + p.ln_eps);
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < WTM; i++) { ln_mean[i] = 0.f; ln_rstd[i] = 1.f; }
-  }
-
+  const bool ln_on = LN;
   bool lds_epilogue = false;
   if constexpr (!TRANS && sizeof(T) == 2) {
     lds_epilogue = use_lds_epi;
@@ -594,9 +619,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
       const unsigned xbase = lds_base + ((gs + NS - 1) % NS) * Tile::STAGE_BYTES;
       auto m_of = [&](int i, int row) -> int64_t { const int64_t m = wm0 + i * 32 + row; return m < p.M ? m : -1; };
       if (p.geglu) {
-        if constexpr (WTN % 2 == 0) epilogue_lds<T, WTM, WTN, NW, Tile::STAGE_BYTES, true>(acc, pe, m_of, wn0, wave, lane, xbase, C, R, ln_s, ln_mean, ln_rstd);
+        if constexpr (WTN % 2 == 0) epilogue_lds<T, WTM, WTN, NW, Tile::STAGE_BYTES, true>(acc, pe, m_of, wn0, wave, lane, xbase, C, R, ln_on, ln_rstd);
       } else {
-        epilogue_lds<T, WTM, WTN, NW, Tile::STAGE_BYTES, false>(acc, pe, m_of, wn0, wave, lane, xbase, C, R, ln_s, ln_mean, ln_rstd);
+        epilogue_lds<T, WTM, WTN, NW, Tile::STAGE_BYTES, false>(acc, pe, m_of, wn0, wave, lane, xbase, C, R, ln_on, ln_rstd);
       }
     }
   }
@@ -619,7 +644,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
           }
         continue;
       }
-      epilogue_row<T, WTN>(acc[i], pe, m, m_ok, wn0, half, C, R, ln_s, ln_mean[i], ln_rstd[i]);
+      epilogue_row<T, WTN>(acc[i], pe, m, m_ok, wn0, half, C, R, ln_on, ln_rstd[i]);
     }
   } else {
     // TRANS: lane <-> column n; register quad g <-> rows 8*g + 4*half + {0..3} (4 CONSECUTIVE rows), which are 4
@@ -631,18 +656,15 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
       for (int j = 0; j < WTN; j++) {
         const int n = wn0 + j * 32 + l31;
         if (n >= p.N) continue;
-        const float bias_v = p.bias ? p.bias[n] : 0.f;
-        const float ln_sn = LN ? p.ln_colsum[n] : 0.f;
+        const float bias_v = (p.bias && !LN) ? p.bias[n] : 0.f;   // (LN: folded into the accumulator init)
 #pragma unroll
         for (int g = 0; g < 4; g++) {
           const int64_t m0 = wm0 + i * 32 + 8 * g + 4 * half;
-          float rmean[4], rrstd[4];   // LayerNorm fold: statistics of rows 8g + 4half + e live in lane (row) of this wave
+          float rrstd[4];   // LayerNorm fold: the statistics of rows 8g + 4half + e live in lane (row) of this wave
 #pragma unroll
           for (int e = 0; e < 4; e++) {
-            if constexpr (LN) {
-              rmean[e] = __shfl(ln_mean[i], 8 * g + 4 * half + e, 64);
-              rrstd[e] = __shfl(ln_rstd[i], 8 * g + 4 * half + e, 64);
-            } else { rmean[e] = 0.f; rrstd[e] = 1.f; }
+            if constexpr (LN) rrstd[e] = __shfl(ln_rstd[i], 8 * g + 4 * half + e, 64);
+            else rrstd[e] = 1.f;
           }
           if (m0 >= p.M) continue;
           if (nsplit > 1) {
@@ -655,7 +677,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
 #pragma unroll
           for (int e = 0; e < 4; e++) {
             float v = acc[i][j][4 * g + e];
-            if constexpr (LN) v = rrstd[e] * (v - rmean[e] * ln_sn);
+            if constexpr (LN) v *= rrstd[e];
             v += bias_v;
             if (p.rowbias && m0 + e < p.M) v += p.rowbias[((m0 + e) / p.rows_per_batch) * p.ld_rowbias + n];
             o[e] = v * p.out_scale;
@@ -930,9 +952,9 @@ __global__ __launch_bounds__(32 * PH_, 2) void conv3x3_halo_kernel(const emo_gem
         auto m_of = [&](int i, int row) -> int64_t {
           return ((int64_t)img * p.H + y0 + (wvm * WTM + i) * 2 + (row >> 4)) * p.W_ + x0 + (row & 15);
         };
-        const float no_ln[WTM] = {0.f, 0.f};
+        const float no_ln[WTM] = {1.f, 1.f};
         epilogue_lds<T, WTM, WTN, NW, Halo::HALO_BYTES, false>(acc, pe, m_of, wn0, wave, lane, lds_base + ((gc + 1) & 1) * Halo::HALO_BYTES, C, R,
-                                                               nullptr, no_ln, no_ln);
+                                                               false, no_ln);
         staged = true;
       }
     }

@@ -391,6 +391,76 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
   }
 }
 
+// Statistics half of the LayerNorm for the GEMM fold: stats[m] = (mean, rstd), same two-pass arithmetic and lane mapping.
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void layernorm_stats_kernel(const T* __restrict__ x, int ldx, float* __restrict__ stats, int64_t M, int C,
+                                                              float eps) {
+  constexpr int V = TT<T>::VEC;
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, rsel = lane / LPR;
+  const int CV = C / V;
+  const float invC = 1.0f / (float)C;
+  for (int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * RPW; m0 < M; m0 += (int64_t)gridDim.x * 4 * RPW) {
+    const int64_t m = m0 + rsel;
+    const bool ok = m < M;
+    float f[LN_MAXV][V];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; j++) {
+      const int cv = sub + LPR * j;
+      if (ok && cv < CV) {
+        unpack16<T>(*(const uint4*)(x + m * ldx + cv * V), f[j]);
+#pragma unroll
+        for (int e = 0; e < V; e++) s += f[j][e];
+      }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; j++) {
+      const int cv = sub + LPR * j;
+      if (ok && cv < CV) {
+#pragma unroll
+        for (int e = 0; e < V; e++) { float d = f[j][e] - mean; q += d * d; }
+      }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    if (ok && sub == 0) *(float2*)(stats + 2 * m) = make_float2(mean, rsqrtf(q * invC + eps));
+  }
+}
+
+extern "C" int emo_layernorm_stats(const void* x, int ldx, float* stats, int64_t M, int C, float eps, int dtype, void* stream) {
+  EMO_CHECK(x && stats, EMO_ERR_NULL, "emo_layernorm_stats: null pointer");
+  EMO_CHECK(emo_dtype_ok(dtype), EMO_ERR_BAD_DTYPE, "emo_layernorm_stats: dtype %d", dtype);
+  const int V = emo_dtype_vec(dtype);
+  EMO_CHECK(M > 0 && C > 0 && C % V == 0 && ldx % V == 0 && ldx >= C, EMO_ERR_BAD_SHAPE, "emo_layernorm_stats: M=%lld C=%d ldx=%d", (long long)M, C, ldx);
+  EMO_CHECK(C / V <= 64 * LN_MAXV, EMO_ERR_UNSUPPORTED, "emo_layernorm_stats: C=%d too wide", C);
+  EMO_CHECK(((uintptr_t)stats % 8) == 0, EMO_ERR_BAD_SHAPE, "emo_layernorm_stats: stats alignment");
+  hipStream_t st = as_stream(stream);
+  const int CV = C / V;
+  int lpr = 1;
+  while (lpr * LN_MAXV < CV) lpr *= 2;
+  const int rpw = 64 / lpr;
+  int64_t g = (M + 4 * rpw - 1) / (4 * rpw); if (g > 256 * 16) g = 256 * 16;
+#define EMO_LNS(L) EMO_DISPATCH(dtype, "emo_layernorm_stats", (layernorm_stats_kernel<T, L><<<(int)g, 256, 0, st>>>((const T*)x, ldx, stats, M, C, eps)))
+  switch (lpr) {
+    case 1: EMO_LNS(1); break;
+    case 2: EMO_LNS(2); break;
+    case 4: EMO_LNS(4); break;
+    case 8: EMO_LNS(8); break;
+    case 16: EMO_LNS(16); break;
+    case 32: EMO_LNS(32); break;
+    default: EMO_LNS(64); break;
+  }
+#undef EMO_LNS
+  EMO_LAUNCH_CHECK();
+  return EMO_OK;
+}
+
 template <typename T>
 static void launch_layernorm(const T* x, int ldx, const float* gamma, const float* beta, T* y, int ldy, int64_t M, int C, float eps,
                              const float* pe, int rpf, int frames, hipStream_t st) {

@@ -199,6 +199,17 @@ def layer_norm(x: torch.Tensor, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0
     return y
 
 
+def layer_norm_stats(x: torch.Tensor, eps=1e-5) -> torch.Tensor:
+    """(mean, rstd) per row, f32 (M, 2): the statistics pass of a LayerNorm folded into the consumer GEMM (gemm(ln=...))."""
+    _need_cuda(x)
+    M, Cc = x.shape
+    px, ldx = _rows(x)
+    st = torch.empty(M, 2, device=x.device, dtype=torch.float32)
+    _launch("layernorm_stats", 0.0, x.element_size() * 1.0 * M * Cc,
+            lambda: check(_lib.load().emo_layernorm_stats(px, ldx, _ptr(st), M, Cc, float(eps), dt(x), _stream()), "emo_layernorm_stats"))
+    return st
+
+
 # ----------------------------------------------------------------------------- GEMM / conv
 GEMM_TILE = 0   # tuning hook for tools/bench: pins emo_gemm_params.tile of every dense GEMM that does not pass tile=
 
@@ -206,8 +217,8 @@ GEMM_TILE = 0   # tuning hook for tools/bench: pins emo_gemm_params.tile of ever
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, geglu=False,
          out_scale=1.0, out=None, transpose_rows=0, transpose_ld=0, conv=None, split_k=None, ln=None, tile=None) -> torch.Tensor:
     """out = epilogue(a @ w.T).  a (M, K) rows view; w (N, K) contiguous in the compute dtype.
-    ln = (colsum f32 (N,), eps): LayerNorm over K folded into the GEMM - a holds the RAW rows, w / bias carry the folded
-    affine (emo_hip.h emo_gemm_params.ln_colsum).
+    ln = (colsum f32 (N,), stats f32 (M, 2) from layer_norm_stats(a)): LayerNorm over K folded into the GEMM - a holds the RAW
+    rows, w / bias carry the folded affine (emo_hip.h emo_gemm_params.ln_colsum).
     conv = dict(H, W, Cin, stride, upsample2x, Ho, Wo) selects the implicit 3x3 conv loader (then a is
     the (B*F*H*W, >=Cin) NHWC input and M = B*F*Ho*Wo).
     transpose_rows=L stores V^T per batch of L rows: out (M/L, N, transpose_ld)."""
@@ -246,13 +257,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
     if conv is not None:
         p.conv_taps, p.H, p.W_, p.Cin = 9, conv["H"], conv["W"], conv["Cin"]
         p.stride, p.upsample2x, p.Ho, p.Wo = conv["stride"], int(conv["upsample2x"]), conv["Ho"], conv["Wo"]
+        p.conv_asym = int(conv.get("asym", 0))
     p.dtype = dt(a)
     p.tile = int(tile if tile is not None else (GEMM_TILE if conv is None else 0))
     if ln is not None:
-        colsum, eps = ln
+        colsum, stats = ln
         assert conv is None and colsum.dtype == torch.float32 and colsum.numel() == N
-        p.ln_colsum, p.ln_eps = colsum.data_ptr(), float(eps)
-        split_k = 1   # the row statistics are accumulated over the whole K by one block
+        assert stats.dtype == torch.float32 and stats.shape == (M, 2) and stats.is_contiguous()
+        p.ln_colsum, p.ln_stats = colsum.data_ptr(), stats.data_ptr()
+        split_k = 1   # the correction rides in the accumulator init of ONE pass over K
     lib = _lib.load()
     sk = lib.emo_gemm_suggest_split_k(M, N, K, p.dtype, int(bool(geglu)), int(bool(transpose_rows))) if split_k is None else split_k
     ws = None
@@ -269,14 +282,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
     return out
 
 
-def conv3x3(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, H: int, W: int, *, stride=1, upsample2x=False, **kw):
+def conv3x3(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, H: int, W: int, *, stride=1, upsample2x=False, pad=1, **kw):
     """Per-frame 3x3 conv, pad 1 (resnet.py:30-38), as an implicit GEMM over NHWC rows.
-    w is the re-laid (Cout, 9*Cin_pad) weight."""
+    w is the re-laid (Cout, 9*Cin_pad) weight.  pad=0 means the asymmetric (0, 1, 0, 1) padding of the VAE encoder's downsampler."""
     cin = w.shape[1] // 9
     He, We = (2 * H, 2 * W) if upsample2x else (H, W)
-    Ho, Wo = (He + 2 - 3) // stride + 1, (We + 2 - 3) // stride + 1
-    assert x.shape[0] == n_img * H * W
-    return gemm(x, w, bias, conv=dict(H=H, W=W, Cin=cin, stride=stride, upsample2x=upsample2x, Ho=Ho, Wo=Wo), **kw), Ho, Wo
+    tot = 2 if pad == 1 else 1
+    Ho, Wo = (He + tot - 3) // stride + 1, (We + tot - 3) // stride + 1
+    assert x.shape[0] == n_img * H * W and pad in (0, 1)
+    return gemm(x, w, bias, conv=dict(H=H, W=W, Cin=cin, stride=stride, upsample2x=upsample2x, Ho=Ho, Wo=Wo, asym=int(pad == 0)), **kw), Ho, Wo
 
 
 # ----------------------------------------------------------------------------- attention
@@ -374,4 +388,35 @@ def add_rowbias(x: torch.Tensor, rb: torch.Tensor, rows_per_batch: int) -> torch
     y = torch.empty(x.shape[0], x.shape[1], device=x.device, dtype=x.dtype)
     check(_lib.load().emo_add_rowbias(px, ldx, pr, ldr, _ptr(y), y.stride(0), x.shape[0], x.shape[1], rows_per_batch, dt(x), _stream()),
           "emo_add_rowbias")
+    return y
+
+
+# ----------------------------------------------------------------------------- either side of the loop (VAE, audio front-end)
+def softmax_rows(x: torch.Tensor, scale: float, out=None) -> torch.Tensor:
+    """softmax(scale * x) over the columns of a rows view (M, N)."""
+    _need_cuda(x)
+    px, ldx = _rows(x)
+    y = torch.empty(x.shape[0], x.shape[1], device=x.device, dtype=x.dtype) if out is None else out
+    py, ldy = _rows(y)
+    check(_lib.load().emo_softmax_rows(px, ldx, py, ldy, x.shape[0], x.shape[1], float(scale), dt(x), _stream()), "emo_softmax_rows")
+    return y
+
+
+def audio_windows(feats: torch.Tensor, m: int = 2, n: int = 2) -> torch.Tensor:
+    """(T, D) -> (T, m+n+1, D): features of frames [t-m, t+n], zero-padded at the ends (Net.py:649-667)."""
+    _need_cuda(feats)
+    feats = feats.contiguous()
+    T_, D = feats.shape
+    out = torch.empty(T_, m + n + 1, D, device=feats.device, dtype=feats.dtype)
+    check(_lib.load().emo_audio_windows(_ptr(feats), _ptr(out), T_, D, m, n, dt(feats), _stream()), "emo_audio_windows")
+    return out
+
+
+def rows_to_video(x: torch.Tensor, B, Cc, F, H, W, mul=0.5, add=0.5, lo=0.0, hi=1.0) -> torch.Tensor:
+    """rows ((b f) h w, >= C) -> (B, C, F, H, W) f32 = clamp(x*mul + add, lo, hi) (EMOAnimationPipeline.py:303-306)."""
+    _need_cuda(x)
+    px, ld = _rows(x)
+    y = torch.empty(B, Cc, F, H, W, device=x.device, dtype=torch.float32)
+    check(_lib.load().emo_rows_to_video(px, ld, _ptr(y), B, Cc, F, H * W, float(mul), float(add), float(lo), float(hi), dt(x), _stream()),
+          "emo_rows_to_video")
     return y

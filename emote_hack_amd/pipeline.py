@@ -75,10 +75,12 @@ class EMOAnimationPipeline:
                         context_batch_size=1, context_schedule="uniform", audio_features=None, speed_embeddings=None, seed=0,
                         fusion_blocks="midup", dist=False, rank=0, world_size=1, return_eps=False, use_graphs=False,
                         controlnet=None, controlnet_cond=None, controlnet_conditioning_scale=1.0, reference_group=10,
-                        reference_lookahead=True):
+                        reference_lookahead=True, motion_latents=None):
         """Set up the loop state (EMOAnimationPipeline.py:628-696).  latents f32 (1,4,F_tot,h,w);
         ref_image_latents (1,4,h,w); text_embeddings (2,L,D) = [uncond, cond].
-        reference_group = T: ReferenceNet timesteps computed per batched pass (1 = the reference's per-step order)."""
+        reference_group = T: ReferenceNet timesteps computed per batched pass (1 = the reference's per-step order).
+        motion_latents (n_m, 4, h, w): latents of the previous clip's last frames - they go through the ReferenceNet next to the
+        reference image and their LN1 features join the banks as extra tokens (see denoise_chained)."""
         unet, sch = self.unet, self.scheduler
         dev = unet.device
         if not guidance_scale > 1.0:
@@ -102,6 +104,14 @@ class EMOAnimationPipeline:
         st.timesteps = sch.set_timesteps(num_inference_steps)
         n_steps = len(st.timesteps)
         st.ref_lat = ref_image_latents.to(dev).float().reshape(1, st.C4, st.h, st.w)
+        if motion_latents is not None:   # (Net.py:56-72 intent; junk/EMo-write-up.txt:104-110): ReferenceNet images = [reference, motion frames]
+            ml = motion_latents.to(dev).float()
+            if ml.dim() == 5:
+                ml = ml[0].permute(1, 0, 2, 3)
+            if tuple(ml.shape[1:]) != (st.C4, st.h, st.w):
+                raise ValueError(f"motion_latents must be (n, {st.C4}, {st.h}, {st.w}), got {tuple(ml.shape)}")
+            st.ref_lat = torch.cat([st.ref_lat, ml]).contiguous()
+        st.n_ref_images = st.ref_lat.shape[0]
         scheduler_fn = get_context_scheduler(context_schedule)
         # the reference recomputes the (step-independent: step arg is always 0) window list every step (:748-755)
         st.windows = [list(map(int, c)) for c in scheduler_fn(0, num_inference_steps, st.f_tot, context_frames, context_stride, context_overlap)]
@@ -224,12 +234,16 @@ class EMOAnimationPipeline:
         uc attention, mutual_self_attention.py:243-256) and the ReferenceNet is batch-independent.  Banks are rounded through
         fp16 like reader.update() does (:588) and packed for the exchange."""
         t = st.ref_t[:Tg] if st.world_size == 1 else st.ref_t.index_select(0, self._ref_sel(st, Tg))
-        n = t.numel()
+        n, k = t.numel(), st.n_ref_images
         st.writer.clear()
-        st.appearance_encoder(st.ref_lat.expand(n, -1, -1, -1), t, encoder_hidden_states=st.text_c, return_dict=False,
-                              _ctx_kv=st.ref_ctx_kv)
+        # batch rows timestep-major: (t0: reference image, motion frames...), (t1: ...) - the k images of one timestep are
+        # consecutive, so their LN1 rows (k, L, C) read as ONE bank of k*L tokens (the reference concatenates several bank
+        # entries along tokens the same way, mutual_self_attention.py:239)
+        imgs = st.ref_lat.expand(n, -1, -1, -1) if k == 1 else st.ref_lat.repeat(n, 1, 1, 1)
+        tt = t if k == 1 else t.repeat_interleave(k)
+        st.appearance_encoder(imgs, tt, encoder_hidden_states=st.text_c, return_dict=False, _ctx_kv=st.ref_ctx_kv)
         tgt = self.unet.dtype
-        st.bank_L = [st.writer.bank[p][0].shape[1] for p in st.writer.order]
+        st.bank_L = [k * st.writer.bank[p][0].shape[1] for p in st.writer.order]
         banks = [ops.convert(st.writer.bank[p][0], tgt, fp16_round=True).reshape(n, -1) for p in st.writer.order]
         st.writer.clear()                                                                      # :823
         st.bank_pack = banks if st.world_size == 1 else torch.cat(banks, dim=1)                # (n, total) plumbing copy
@@ -403,6 +417,27 @@ class EMOAnimationPipeline:
             if callback is not None and si % callback_steps == 0:
                 callback(si, t, st.latents)
         return (st.latents, st.eps_trace) if st.return_eps else st.latents
+
+    @torch.no_grad()
+    def denoise_chained(self, clips, ref_image_latents, text_embeddings, *, n_motion_frames=4, **kw):
+        """Long-video generation by clip chaining (intent of Net.py:56-72 `pre_extract_motion_features` and
+        junk/EMo-write-up.txt:104-110 - the reference never wires it): clip k+1 is denoised with the LAST n_motion_frames
+        latent frames of the denoised clip k as motion frames; the first clip gets zero maps.  The motion frames pass through
+        the ReferenceNet together with the reference image at every timestep and their LN1 features are appended to the
+        reference banks as extra tokens, i.e. every spatial self-attention of the Backbone's mid / up path also attends to
+        the previous clip's tail (same bank mechanism, Lk1 = (1 + n_motion_frames) * L).  `clips`: list of noisy latents
+        (1, 4, F, h, w).  Returns the list of denoised latents.  Design choice - no reference behaviour to match."""
+        out, prev = [], None
+        for lat in clips:
+            if n_motion_frames > 0:
+                _, c4, f, h, w = lat.shape
+                motion = torch.zeros(n_motion_frames, c4, h, w) if prev is None else prev[0, :, -n_motion_frames:].permute(1, 0, 2, 3)
+            else:
+                motion = None
+            res = self.denoise(lat, ref_image_latents, text_embeddings, motion_latents=motion, **kw)
+            prev = res[0] if isinstance(res, tuple) else res
+            out.append(prev)
+        return out
 
     # ------------------------------------------------------------------ reference-compatible entry point
     @torch.no_grad()

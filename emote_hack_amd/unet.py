@@ -42,8 +42,8 @@ def _round_up(x, m):
 
 
 # Every LayerNorm of the transformer / motion blocks feeds a Linear (attention.py:279-316, motion_module.py:216-224,282-303):
-# the affine is folded into the Linear's operands at load and the normalisation into the GEMM (emo_gemm_params.ln_colsum) -
-# the LayerNorm launches and the HBM round trip of the normalised tokens disappear.  The one exception is the LN1 of a block
+# the affine is folded into the Linear's operands at load and the normalisation into the GEMM (emo_gemm_params.ln_colsum /
+# ln_stats): a read-only statistics pass replaces LayerNorm's read + write and the GEMM reads the raw tokens.  The one exception is the LN1 of a block
 # whose output is WRITTEN to a reference bank (mutual_self_attention.py:230): that tensor has to exist.
 FOLD_LAYERNORM = True
 
@@ -396,10 +396,11 @@ class UNet3DConditionModel:
         fold = self._fold_ln and not a.gutted and not (c.bank_mode == "write" and p in c.active)
         LN_EPS = 1e-5   # nn.LayerNorm default (attention.py:240-252)
         if fold:        # LN1 folded into the q|k and V^T projections
+            st = ops.layer_norm_stats(h, LN_EPS)
             wq, cs, bq = w[tb + ".attn1.qk_ln"]
-            qk = ops.gemm(h, wq, bq, ln=(cs, LN_EPS))
+            qk = ops.gemm(h, wq, bq, ln=(cs, st))
             wv, cs, bv = w[tb + ".attn1.v_ln"]
-            vt = ops.gemm(h, wv, bv, ln=(cs, LN_EPS), transpose_rows=HW, transpose_ld=_round_up(HW, 8))
+            vt = ops.gemm(h, wv, bv, ln=(cs, st), transpose_rows=HW, transpose_ld=_round_up(HW, 8))
         else:
             n1 = ops.layer_norm(h, w[tb + ".norm1.g"], w[tb + ".norm1.b"])
             if c.bank_mode == "write" and p in c.active:
@@ -425,7 +426,7 @@ class UNet3DConditionModel:
         # --- cross attention to the text / audio context
         if self._fold_ln:
             wq, cs, bq = w[tb + ".attn2.q_ln"]
-            q2 = ops.gemm(h, wq, bq, ln=(cs, LN_EPS))
+            q2 = ops.gemm(h, wq, bq, ln=(cs, ops.layer_norm_stats(h, LN_EPS)))
         else:
             n2 = ops.layer_norm(h, w[tb + ".norm2.g"], w[tb + ".norm2.b"])
             q2 = ops.gemm(n2, w[tb + ".attn2.q"])
@@ -438,7 +439,7 @@ class UNet3DConditionModel:
         # --- GEGLU feed-forward
         if self._fold_ln:
             wf, cs, bf = w[tb + ".ff1_ln"]
-            g = ops.gemm(h, wf, bf, geglu=True, ln=(cs, LN_EPS))
+            g = ops.gemm(h, wf, bf, geglu=True, ln=(cs, ops.layer_norm_stats(h, LN_EPS)))
         else:
             n3 = ops.layer_norm(h, w[tb + ".norm3.g"], w[tb + ".norm3.b"])
             g = ops.gemm(n3, w[tb + ".ff1.w"], w[tb + ".ff1.b"], geglu=True)
@@ -467,7 +468,7 @@ class UNet3DConditionModel:
                     if key not in self._pe_rows:
                         self._pe_rows[key] = w[ab + ".pe_w"][:c.F].repeat(c.B, 1).contiguous()
                     kw = dict(rowbias=self._pe_rows[key], rows_per_batch=HW)
-                qkv = ops.gemm(h, wq, bq, ln=(cs, 1e-5), **kw)
+                qkv = ops.gemm(h, wq, bq, ln=(cs, ops.layer_norm_stats(h, 1e-5)), **kw)
             else:
                 n = ops.layer_norm(h, w[f"{tb}.norms.{k}.g"], w[f"{tb}.norms.{k}.b"], pe=w.get(ab + ".pe"), rows_per_frame=HW, frames=c.F)
                 qkv = ops.gemm(n, w[ab + ".qkv"])
@@ -475,7 +476,7 @@ class UNet3DConditionModel:
             h = ops.gemm(att, w[ab + ".o.w"], w[ab + ".o.b"], residual=h)
         if self._fold_ln:
             wf, cs, bf = w[tb + ".ff1_ln"]
-            g = ops.gemm(h, wf, bf, geglu=True, ln=(cs, 1e-5))
+            g = ops.gemm(h, wf, bf, geglu=True, ln=(cs, ops.layer_norm_stats(h, 1e-5)))
         else:
             n = ops.layer_norm(h, w[tb + ".ff_norm.g"], w[tb + ".ff_norm.b"])
             g = ops.gemm(n, w[tb + ".ff1.w"], w[tb + ".ff1.b"], geglu=True)

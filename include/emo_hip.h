@@ -92,6 +92,9 @@ int emo_groupnorm_apply(const void* x, int ldx, const void* partials, const floa
  * y[row] += pe[frame(row)] with frame(row) = (row / rows_per_frame) % frames, pe f32 [max_len][C]. */
 int emo_layernorm(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, int64_t M,
                   int C, float eps, const float* pe, int rows_per_frame, int frames, int dtype, void* stream);
+/* the statistics half of it: stats[m] = (mean, 1 / sqrt(var + eps)) of row m (two-pass, f32) for the LayerNorm fold of
+ * emo_gemm (emo_gemm_params.ln_stats) - a read-only pass over x. */
+int emo_layernorm_stats(const void* x, int ldx, float* stats, int64_t M, int C, float eps, int dtype, void* stream);
 
 /* ---- GEMM / convolution (MFMA) ----------------------------------------------------------------
  * C[M,N] = epilogue( A[M,K] . W[N,K]^T ).  Replaces F.linear / 1x1 conv (orig_attention.py:566-575,
@@ -124,14 +127,16 @@ typedef struct {
    * and applies the epilogue.  split_k <= 1: single pass, workspace unused. */
   int split_k; void* workspace;
   /* LayerNorm folded into the GEMM (attention.py:279-316, motion_module.py:216-224: every LayerNorm of the transformer
-   * blocks feeds a Linear).  With ln_colsum != NULL the kernel computes
-   *     C = epilogue( ((A - mean_m) * rstd_m) . W^T ),   mean_m / rstd_m = LayerNorm statistics of row m of A over K (eps ln_eps)
-   * as rstd_m * (A.W^T - mean_m * ln_colsum[n]) with ln_colsum[n] = sum_k W[n][k]; the row statistics are accumulated from
-   * the A fragments the MFMA loop reads anyway (no extra pass over A, no normalised copy of A in HBM).  The caller folds
-   * the LayerNorm affine into the operands once at load: W <- W * gamma[k], bias <- bias + W . beta.  Dense, split_k <= 1. */
-  const float* ln_colsum; float ln_eps;
+   * blocks feeds a Linear).  With ln_colsum / ln_stats != NULL the kernel computes
+   *     C = epilogue( ((A - mean_m) * rstd_m) . W^T + bias ),   ln_stats[m] = (mean_m, rstd_m) from emo_layernorm_stats
+   * as rstd_m * (bias[n] / rstd_m - mean_m * ln_colsum[n] + A.W^T) with ln_colsum[n] = sum_k W[n][k]: the correction enters
+   * through the accumulator init, the epilogue pays one multiply, and no normalised copy of A ever exists in HBM.  The caller
+   * folds the LayerNorm affine into the operands once at load: W <- W * gamma[k], bias <- bias + W . beta.  Dense, split_k <= 1. */
+  const float* ln_colsum; const float* ln_stats;
   int tile;   /* 0 = planned from the shape; 1..6 pin a tile (64x64, 128x128, 128x160, 256x256, 256x160, 256x320) - tuning hook
                  in the spirit of a BLAS algorithm id; combinations a tile cannot serve fall back to the nearest one that can */
+  int conv_asym;   /* conv only: 1 = padding (0, 1, 0, 1) instead of 1 all round - the `F.pad(x, (0,1,0,1))` + stride-2
+                      conv of the VAE encoder's Downsample2D (diffusers AutoencoderKL; Ho = (H + 1 - 3) / stride + 1) */
 } emo_gemm_params;
 int emo_gemm(const emo_gemm_params* p, void* stream);
 /* heuristic split factor for (M, N, K) and the workspace it needs */
@@ -205,6 +210,18 @@ int emo_speed_bucket(const float* v, const float* centers, int32_t* idx, int B, 
 int emo_gather_rows(const void* table, const int32_t* idx, void* out, int B, int D, int rows, int dtype, void* stream);
 int emo_add_rowbias(const void* x, int ldx, const void* rb, int ldr, void* y, int ldy, int64_t M, int C, int rows_per_batch,
                     int dtype, void* stream);
+
+/* ---- either side of the loop ----------------------------------------------------
+ * emo_softmax_rows: y[m, :] = softmax(scale * x[m, :]) over N columns - the VAE mid-block attention (one head of 512
+ *   channels; diffusers AutoencoderKL behind EMOAnimationPipeline.py:291-307,402-414) as Q.K^T GEMM -> this -> P.V GEMM.
+ * emo_audio_windows: Wav2VecFeatureExtractor.extract_features_from_wav (Net.py:649-667): out[t][j][:] = feats[t-m+j][:],
+ *   zero where t-m+j falls outside [0, T); out is [T][m+n+1][D].  Bit-exact (a copy).
+ * emo_rows_to_video: rows ((b f) h w, ld) -> (B, C, F, H, W) f32 with y = clamp(x*mul + add, lo, hi): the
+ *   `(video / 2 + 0.5).clamp(0, 1)` of decode_latents (EMOAnimationPipeline.py:303-306). */
+int emo_softmax_rows(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t M, int N, float scale, int dtype, void* stream);
+int emo_audio_windows(const void* feats, void* out, int T, int D, int m, int n, int dtype, void* stream);
+int emo_rows_to_video(const void* x, int64_t ld, float* y, int B, int C, int F, int HW, float mul, float add, float lo, float hi,
+                      int dtype, void* stream);
 
 #ifdef __cplusplus
 }

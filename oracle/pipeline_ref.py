@@ -19,7 +19,7 @@ def denoise_loop(unet_sd, unet_cfg, ref_sd, ref_cfg, latents, ref_latents, text_
                  scheduler: SchedulerRef, num_inference_steps=50, guidance_scale=7.5,
                  context_frames=16, context_stride=1, context_overlap=4, context_batch_size=1,
                  fusion_blocks="midup", seed=0, audio_features=None, speed_embeddings=None,
-                 rank=0, world_size=1, return_eps=False, controlnet=None):
+                 rank=0, world_size=1, return_eps=False, controlnet=None, motion_latents=None):
     """latents (1,4,F_tot,h,w); ref_latents (1,4,h,w); text_embeddings (2,L,D) = [uncond, cond].
 
     Per step (EMOAnimationPipeline.py:698-823):
@@ -42,8 +42,16 @@ def denoise_loop(unet_sd, unet_cfg, ref_sd, ref_cfg, latents, ref_latents, text_
     for si, t in enumerate(timesteps):
         noise_pred = torch.zeros(2, *latents.shape[1:])
         counter = torch.zeros(1, 1, f_tot, 1, 1)
-        ref_in = ref_latents.repeat(2 * cbs, 1, 1, 1).unsqueeze(2)  # F=1 instance
-        _, written = unet_forward(ref_sd, ref_cfg, ref_in, t, text, bank_mode="write", fusion_blocks=fusion_blocks)
+        if motion_latents is None:
+            ref_in = ref_latents.repeat(2 * cbs, 1, 1, 1).unsqueeze(2)  # F=1 instance
+            _, written = unet_forward(ref_sd, ref_cfg, ref_in, t, text, bank_mode="write", fusion_blocks=fusion_blocks)
+        else:
+            # motion-frame conditioning (design, no reference behaviour): [reference image, motion frames] through
+            # the ReferenceNet with the cond text; their LN1 rows concatenated along tokens form ONE bank row, shared by every copy
+            imgs = torch.cat([ref_latents.reshape(1, *ref_latents.shape[-3:]), motion_latents]).unsqueeze(2)
+            _, w1 = unet_forward(ref_sd, ref_cfg, imgs, t, text_embeddings[1:].expand(imgs.shape[0], -1, -1), bank_mode="write",
+                                 fusion_blocks=fusion_blocks)
+            written = {p_: v.reshape(1, -1, v.shape[-1]).repeat(2 * cbs, 1, 1) for p_, v in w1.items()}
         banks = round_banks_fp16(written)
         windows = uniform_windows(0, num_inference_steps, f_tot, context_frames, context_stride, context_overlap)
         nb = math.ceil(len(windows) / cbs)

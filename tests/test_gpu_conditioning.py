@@ -92,3 +92,21 @@ def test_unet_accepts_audio_and_speed_kwargs():
     m.to(DEV, torch.float32)
     y = m(x.to(DEV), 500, ctx.to(DEV), audio_features=audio.to(DEV), speed_embeddings=speed.to(DEV)).sample
     torch.testing.assert_close(y.cpu(), ref, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_audio_windows_vs_reference_loop(dtype):
+    """Net.py:649-667 (the per-frame windowing loop of Wav2VecFeatureExtractor, run by tools/oracle/gen_golden.py on synthetic
+    hidden states): bit-exact - the kernel is a gather with zero padding."""
+    from safetensors.torch import load_file
+    from emote_hack_amd.conditioning import audio_context_tokens, audio_windows
+    g = load_file(os.path.join(cases.GOLDEN_DIR, "audio_windows.safetensors"))
+    for name, (m, n) in {"t9_m2n2": (2, 2), "t3_m2n2": (2, 2), "t7_m1n3": (1, 3), "t5_m0n0": (0, 0)}.items():
+        x = g[f"{name}/in"].to(dtype)
+        got = audio_windows(x.to(DEV).unsqueeze(0), m, n)
+        want = x.float()
+        ref = g[f"{name}/out"].to(dtype)
+        assert torch.equal(got.cpu(), ref), name
+        assert want.shape[0] == got.shape[0]
+    tok = audio_context_tokens(audio_windows(g["t9_m2n2/in"].to(DEV), 2, 2), 4, feature_dim=16)
+    assert tok.shape == (4, 5, 16) and torch.equal(tok[0, 2].cpu(), g["t9_m2n2/in"][0])

@@ -262,8 +262,8 @@ def test_gemm_layernorm_fold(dtype, tile, M, N, K, mode):
     out = LN(x) W^T + b, with a mean offset 2x the spread to exercise the colsum subtraction - plain / GEGLU / V^T epilogues, the
     temporal PE as a per-frame row bias, every tile shape."""
     o = ops()
-    if mode == "geglu" and tile in (1, 3, 5):
-        pytest.skip("GEGLU pairs 32-column tiles: planner falls back")
+    if mode == "geglu" and tile in (1, 3, 5, 6):
+        pytest.skip("GEGLU pairs 32-column tiles (even tiles per wave): the planner falls back to 128x128")
     x = q(seeded_randn((M, K), 120) * 1.5 + 3.0 * seeded_randn((M, 1), 121), dtype)
     wt = seeded_randn((N, K), 122) / math.sqrt(K)
     bias = 0.1 * seeded_randn((N,), 123) if mode != "trans" else None
@@ -287,12 +287,15 @@ def test_gemm_layernorm_fold(dtype, tile, M, N, K, mode):
         il = lambda t: torch.cat([t[:N // 2].reshape(N // 64, 32, *t.shape[1:]), t[N // 2:].reshape(N // 64, 32, *t.shape[1:])], 1).reshape(t.shape)
         wp, cs, bp = il(wp), il(cs), il(bp)
     a = x.to(DEV).to(dtype)
+    st = o.layer_norm_stats(a, 1e-5)
+    mu, var = x.mean(1), x.var(1, unbiased=False)
+    torch.testing.assert_close(st.cpu(), torch.stack([mu, (var + 1e-5).rsqrt()], 1), rtol=1e-4, atol=1e-5)
     if mode == "trans":
         L = M // 3
-        got = o.gemm(a, wp.to(DEV).contiguous(), bp.to(DEV), ln=(cs.to(DEV).contiguous(), 1e-5), transpose_rows=L, transpose_ld=L, tile=tile)
+        got = o.gemm(a, wp.to(DEV).contiguous(), bp.to(DEV), ln=(cs.to(DEV).contiguous(), st), transpose_rows=L, transpose_ld=L, tile=tile)
         got = got.float().cpu().permute(0, 2, 1).reshape(M, N)
     else:
-        got = o.gemm(a, wp.to(DEV).contiguous(), bp.to(DEV).contiguous(), ln=(cs.to(DEV).contiguous(), 1e-5), geglu=(mode == "geglu"),
+        got = o.gemm(a, wp.to(DEV).contiguous(), bp.to(DEV).contiguous(), ln=(cs.to(DEV).contiguous(), st), geglu=(mode == "geglu"),
                      tile=tile, **kw)
     # the fold rounds W * gamma (not LN(x)) to the compute dtype: same error scale as the unfused pair
     tol = TOL[dtype]

@@ -253,3 +253,38 @@ def test_unet_vs_oracle_medium_size_properties():
     check(y, ref, torch.float32)
     y0 = m(x[:1].to(DEV), 321, ctx[:1].to(DEV)).sample
     torch.testing.assert_close(y0.cpu(), y[:1].cpu(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_motion_frame_conditioning_vs_oracle(graphs):
+    """the previous clip's last frames go through the ReferenceNet next to the reference image and their LN1
+    features join the reference banks as extra tokens (Lk1 = 3 * L here).  HIP f32 loop vs the oracle loop with the same
+    motion latents; and the motion frames are live (the result differs from the run without them)."""
+    from oracle.pipeline_ref import denoise_loop
+    from oracle.scheduler_ref import SchedulerRef
+    from emote_hack_amd import DDIMScheduler
+    from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
+    from emote_hack_amd.pipeline import EMOAnimationPipeline
+    from emote_hack_amd.spec import build_spec, param_shapes
+    ref = build(cases.TINY, torch.float32, cases.REF_PREFIX, cls=AppearanceEncoderModel, has_out=False)
+    unet = build(cases.TINY_MOTION, torch.float32)
+    usd = synth_state_dict(param_shapes(build_spec(cases.TINY_MOTION)))
+    rsd = synth_state_dict(param_shapes(ref.spec), prefix=cases.REF_PREFIX)
+    lat, refl, text = seeded_randn((1, 4, 4, 16, 16), 5), seeded_randn((1, 4, 16, 16), 3), seeded_randn((2, 5, 32), 2)
+    motion = 0.5 * seeded_randn((2, 4, 16, 16), 6)
+    kw = dict(num_inference_steps=2, guidance_scale=7.5, context_frames=4, context_stride=1, context_overlap=0, seed=0)
+    want = denoise_loop(usd, cases.TINY_MOTION, rsd, cases.TINY, lat, refl, text, scheduler=SchedulerRef("ddim"), motion_latents=motion, **kw)
+    base = denoise_loop(usd, cases.TINY_MOTION, rsd, cases.TINY, lat, refl, text, scheduler=SchedulerRef("ddim"), **kw)
+    pipe = EMOAnimationPipeline(unet=unet, scheduler=DDIMScheduler())
+    got = pipe.denoise(lat.to(DEV), refl, text, appearance_encoder=ref, use_graphs=graphs, motion_latents=motion, **kw)
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-3, atol=2e-4)
+    assert float((want - base).abs().max()) > 1e-3
+    if not graphs:   # clip chaining: the second clip sees the first one's tail, the first one zero maps
+        clips = pipe.denoise_chained([lat.to(DEV), seeded_randn((1, 4, 4, 16, 16), 8).to(DEV)], refl, text, n_motion_frames=2,
+                                     appearance_encoder=ref, **kw)
+        z = denoise_loop(usd, cases.TINY_MOTION, rsd, cases.TINY, lat, refl, text, scheduler=SchedulerRef("ddim"),
+                         motion_latents=torch.zeros(2, 4, 16, 16), **kw)
+        torch.testing.assert_close(clips[0].cpu(), z, rtol=2e-3, atol=2e-4)
+        nxt = denoise_loop(usd, cases.TINY_MOTION, rsd, cases.TINY, seeded_randn((1, 4, 4, 16, 16), 8), refl, text, scheduler=SchedulerRef("ddim"),
+                           motion_latents=z[0, :, -2:].permute(1, 0, 2, 3), **kw)
+        torch.testing.assert_close(clips[1].cpu(), nxt, rtol=4e-3, atol=4e-4)

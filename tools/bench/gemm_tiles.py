@@ -46,11 +46,12 @@ def dense(M, N, K, tiles, res=False, geglu=False, ln=False):
     r = [torch.randn(M, no, device=dev, dtype=dt) for _ in range(NROT)] if res else None
     out = [torch.empty(M, no, device=dev, dtype=dt) for _ in range(NROT)]
     cs = w.float().sum(1).contiguous()
+    st = [o.layer_norm_stats(x_) for x_ in a] if ln else None
     row = f"M={M:6d} N={N:5d} K={K:5d} {'geglu' if geglu else '     '} {'res' if res else '   '} {'ln' if ln else '  '} |"
     for t in tiles:
         try:
             us = timeit(lambda i: o.gemm(a[i % NROT], w, b, geglu=geglu, residual=r[i % NROT] if res else None, out=out[i % NROT],
-                                         tile=t, split_k=1, ln=(cs, 1e-5) if ln else None))
+                                         tile=t, split_k=1, ln=(cs, st[i % NROT]) if ln else None))
             row += f" t{t}: {us:7.1f}us {2.0 * M * N * K / us / 1e6:6.0f}TF |"
         except Exception as ex:   # a tile the planner cannot serve
             row += f" t{t}: {type(ex).__name__} |"
@@ -70,8 +71,22 @@ def conv(n, H, W, Cin, N):
     print(row, flush=True)
 
 
+def norms():
+    for M, C in ((98304, 320), (24576, 640), (6144, 1280)):
+        xs = [torch.randn(M, C, device=dev, dtype=dt) for _ in range(NROT)]
+        g, b = torch.randn(C, device=dev), torch.randn(C, device=dev)
+        us_ln = timeit(lambda i: o.layer_norm(xs[i % NROT], g, b))
+        us_st = timeit(lambda i: o.layer_norm_stats(xs[i % NROT]))
+        us_gn5 = timeit(lambda i: o.group_norm(xs[i % NROT], g, b, 2, 32, 1e-5, True))
+        us_gn4 = timeit(lambda i: o.group_norm(xs[i % NROT], g, b, 24, 32, 1e-6, False))
+        mb = M * C * 2 / 1e6
+        print(f"norms M={M:6d} C={C:5d} ({mb:5.1f} MB): layernorm {us_ln:6.1f}us ({2 * mb / us_ln:5.2f} TB/s r+w) | ln_stats {us_st:6.1f}us "
+              f"({mb / us_st:5.2f} TB/s r) | GN 5-D+SiLU {us_gn5:6.1f}us ({3 * mb / us_gn5:5.2f} TB/s 2r+w) | GN per-frame {us_gn4:6.1f}us", flush=True)
+
+
 if __name__ == "__main__":
-    T = (0, 2, 3, 5, 6, 4)
+    norms()
+    T = (0, 2, 3, 4)
     dense(98304, 320, 320, T, res=True)
     dense(98304, 960, 320, T)
     dense(98304, 960, 320, T, ln=True)
@@ -79,16 +94,14 @@ if __name__ == "__main__":
     dense(98304, 320, 1280, T, res=True)
     dense(24576, 640, 640, T, res=True)
     dense(24576, 1920, 640, T, ln=True)
-    dense(24576, 1280, 640, T, ln=True)
     dense(24576, 640, 2560, T, res=True)
     dense(6144, 1280, 1280, T, res=True)
     dense(6144, 3840, 1280, T, ln=True)
-    dense(6144, 2560, 1280, T, ln=True)
     dense(6144, 1280, 5120, T, res=True)
-    dense(1536, 1280, 1280, (0, 1, 2, 3), res=True)
-    G = (0, 4, 6, 2)
+    G = (0, 4, 2)
     dense(98304, 2560, 320, G, geglu=True)
     dense(98304, 2560, 320, G, geglu=True, ln=True)
+    dense(24576, 5120, 640, G, geglu=True)
     dense(24576, 5120, 640, G, geglu=True, ln=True)
     dense(6144, 10240, 1280, G, geglu=True, ln=True)
     dense(8192, 8192, 8192, (4, 6, 2))

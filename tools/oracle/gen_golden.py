@@ -361,6 +361,32 @@ def gen_conditioning():
     print("conditioning.safetensors", list(T))
 
 
+# =============================================================================== audio windows
+def gen_audio_windows():
+    """Net.py:649-667: the per-frame windowing loop of Wav2VecFeatureExtractor.extract_features_from_wav, run on synthetic
+    `hidden_states` (the class itself needs transformers checkpoints + soundfile / librosa).  The statements from
+    `num_frames = hidden_states.shape[1]` to `all_features = torch.stack(...)` are taken from the method body by AST and
+    executed as they stand; only tensors are stored."""
+    import ast
+    from types import SimpleNamespace
+    tree = ast.parse(open("/root/reference/Net.py").read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "Wav2VecFeatureExtractor")
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "extract_features_from_wav")
+    start = next(i for i, st in enumerate(fn.body) if isinstance(st, ast.Assign) and getattr(st.targets[0], "id", "") == "num_frames")
+    stop = next(i for i, st in enumerate(fn.body) if isinstance(st, ast.Assign) and getattr(st.targets[0], "id", "") == "all_features"
+                and isinstance(st.value, ast.Call) and getattr(st.value.func, "attr", "") == "stack")
+    code = compile(ast.Module(body=fn.body[start:stop + 1], type_ignores=[]), "Net.py", "exec")
+    T = {}
+    for name, (Tn, D, m, n) in {"t9_m2n2": (9, 16, 2, 2), "t3_m2n2": (3, 16, 2, 2), "t7_m1n3": (7, 8, 1, 3), "t5_m0n0": (5, 8, 0, 0)}.items():
+        hs = seeded_randn((1, Tn, D), 300 + Tn)
+        ns = dict(torch=torch, hidden_states=hs, m=m, n=n, self=SimpleNamespace(device="cpu"))
+        exec(code, ns)
+        T[f"{name}/in"] = hs[0].contiguous()
+        T[f"{name}/out"] = ns["all_features"].contiguous()
+    save_file(T, os.path.join(GOLD, "audio_windows.safetensors"))
+    print("audio_windows.safetensors", {k: tuple(v.shape) for k, v in T.items()})
+
+
 # =============================================================================== ControlNet (SURVEY 8f rank 1)
 def gen_controlnet():
     """The in-tree arithmetic of magicanimate/models/controlnet.py that does not need diffusers: the
@@ -402,7 +428,7 @@ if __name__ == "__main__":
     ap.add_argument("--skip-cfg1", action="store_true")
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    todo = a.only.split(",") if a.only else ["ints", "modules", "unet", "cond", "controlnet", "cfg1"]
+    todo = a.only.split(",") if a.only else ["ints", "modules", "unet", "cond", "controlnet", "audio", "cfg1"]
     if "ints" in todo:
         gen_ints()
     if "modules" in todo:
@@ -414,5 +440,7 @@ if __name__ == "__main__":
         gen_conditioning()
     if "controlnet" in todo:
         gen_controlnet()
+    if "audio" in todo:
+        gen_audio_windows()
     if "cfg1" in todo and not a.skip_cfg1:
         gen_cfg1()
