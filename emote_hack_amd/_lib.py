@@ -36,6 +36,7 @@ class GemmParams(C.Structure):
         ("ln_colsum", C.c_void_p), ("ln_stats", C.c_void_p),
         ("tile", C.c_int),
         ("conv_asym", C.c_int),
+        ("up_h", C.c_int), ("up_w", C.c_int),
     ]
 
 

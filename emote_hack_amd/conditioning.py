@@ -293,6 +293,85 @@ def stage3_combine(unet_fn, noisy_latents, face_features, speed_embed):
     return ops.rows_to_ncfhw(o, B, out.shape[1], 1, H, W).squeeze(2)
 
 
+# ----------------------------------------------------------------------------- VideoNet attention modules
+class SpatialAttentionModule(_HipModule):
+    """models/videonet.py:15-77 - the alternative reference attention: the reference feature map is concatenated to x ALONG THE
+    WIDTH, GroupNorm(32, eps 1e-6) + 1x1 conv over the concatenation, q from the RAW x tokens, k / v from the concatenated
+    tokens, `num_heads` heads (xformers.memory_efficient_attention = softmax(q k^T d^-0.5) v), LN(attn + x), Linear, LN(. + .),
+    1x1 conv, + x.  The residual `attn_out + reshaped_x` needs embed_dim == num_inp_channels (the reference's default 40 only
+    runs for 40-channel inputs).  x, reference_tensor: (b*t, C, h, w) -> (b*t, C, h, w) f32."""
+
+    def __init__(self, num_inp_channels: int, embed_dim: int = 40, num_heads: int = 8):
+        super().__init__()
+        if embed_dim != num_inp_channels:
+            raise ValueError("SpatialAttentionModule: attn_out + reshaped_x (videonet.py:66) needs embed_dim == num_inp_channels")
+        C, E = num_inp_channels, embed_dim
+        self.C, self.E, self.num_heads = C, E, num_heads
+        self._shapes = {"norm_in.weight": (C,), "norm_in.bias": (C,), "proj_in.weight": (C, C, 1, 1), "proj_in.bias": (C,),
+                        "to_q.weight": (E, C), "to_q.bias": (E,), "to_k.weight": (E, C), "to_k.bias": (E,),
+                        "to_v.weight": (E, C), "to_v.bias": (E,), "norm1.weight": (E,), "norm1.bias": (E,),
+                        "ffn.weight": (E, E), "ffn.bias": (E,), "norm2.weight": (E,), "norm2.bias": (E,),
+                        "proj_out.weight": (C, C, 1, 1), "proj_out.bias": (C,)}
+
+    def _pack(self):
+        if self._sd is None or self.device.type != "cuda":
+            return
+        self._w = {k: (v.reshape(v.shape[0], -1).to(self.device, self.dtype) if v.dim() >= 2 else v.to(self.device).float()).contiguous()
+                   for k, v in self._sd.items()}
+
+    def _tail(self, att, xr, n_rows_shape):
+        """LN(attn + x) -> Linear -> LN(. + .) -> 1x1 conv -> + x   (videonet.py:66-77)"""
+        w = self._w
+        n1 = ops.layer_norm(ops.add(att, xr), w["norm1.weight"], w["norm1.bias"])
+        f = ops.gemm(n1, w["ffn.weight"], w["ffn.bias"])
+        n2 = ops.layer_norm(ops.add(n1, f), w["norm2.weight"], w["norm2.bias"])
+        return ops.gemm(n2, w["proj_out.weight"], w["proj_out.bias"], residual=xr)
+
+    def forward(self, x, reference_tensor):
+        self._need()
+        bt, C, h, wd = x.shape
+        w, dtp = self._w, self.dtype
+        xr = ops.ncfhw_to_rows(x.to(self.device).float().unsqueeze(2), dtp)                        # (bt*h*w, C)
+        rr = ops.ncfhw_to_rows(reference_tensor.to(self.device).float().unsqueeze(2), dtp)
+        cat = torch.cat([xr.view(bt, h, wd, C), rr.view(bt, h, wd, C)], dim=2).reshape(bt * h * 2 * wd, C)   # concat along w (:42)
+        g = ops.group_norm(cat, w["norm_in.weight"], w["norm_in.bias"], bt, 32, 1e-6, False)
+        pj = ops.gemm(g, w["proj_in.weight"], w["proj_in.bias"])
+        Lk = h * 2 * wd
+        q = ops.gemm(xr, w["to_q.weight"], w["to_q.bias"])
+        k = ops.gemm(pj, w["to_k.weight"], w["to_k.bias"])
+        vt = ops.gemm(pj, w["to_v.weight"], w["to_v.bias"], transpose_rows=Lk, transpose_ld=(Lk + 7) // 8 * 8)
+        d = self.E // self.num_heads
+        att = ops.attention(q, k, vt, Lk, B=bt, Lq=h * wd, heads=self.num_heads, d=d, scale=d ** -0.5)
+        out = self._tail(att, xr, None)
+        return ops.rows_to_ncfhw(out, bt, C, 1, h, wd)[:, :, 0]
+
+
+class TemporalAttentionModule(SpatialAttentionModule):
+    """models/videonet.py:81-128: per pixel, ONE head of embed_dim over the `num_frames` frames; q / k / v from the RAW tokens
+    (the module computes norm_in / proj_in and never uses the result, :110-118 - neither do we), then the same
+    LN / Linear / LN / 1x1-conv tail, + x.  x: ((b t), C, h, w)."""
+
+    def __init__(self, num_inp_channels: int, num_frames: int, embed_dim: int = 40, num_heads: int = 8):
+        super().__init__(num_inp_channels, embed_dim, num_heads)
+        self.num_frames = num_frames
+
+    def _pack(self):
+        super()._pack()
+        if self._w is not None:
+            self._w["qkv.weight"] = torch.cat([self._w["to_q.weight"], self._w["to_k.weight"], self._w["to_v.weight"]]).contiguous()
+            self._w["qkv.bias"] = torch.cat([self._w["to_q.bias"], self._w["to_k.bias"], self._w["to_v.bias"]]).contiguous()
+
+    def forward(self, x):
+        self._need()
+        bt, C, h, wd = x.shape
+        T = self.num_frames
+        xr = ops.ncfhw_to_rows(x.to(self.device).float().reshape(bt // T, T, C, h, wd).permute(0, 2, 1, 3, 4), self.dtype)   # ((b t) h w, C)
+        qkv = ops.gemm(xr, self._w["qkv.weight"], self._w["qkv.bias"])
+        att = ops.temporal_attention(qkv, bt // T, T, h * wd, 1, self.E, self.E ** -0.5)          # 3-D xformers call: one head
+        out = self._tail(att, xr, None)
+        return ops.rows_to_ncfhw(out, bt // T, C, T, h, wd).permute(0, 2, 1, 3, 4).reshape(bt, C, h, wd)
+
+
 # ----------------------------------------------------------------------------- audio front-end (SURVEY 8f row 4)
 def audio_windows(hidden_states: torch.Tensor, m: int = 2, n: int = 2) -> torch.Tensor:
     """Wav2VecFeatureExtractor.extract_features_from_wav, the windowing half (Net.py:649-667): for every audio frame f the

@@ -36,7 +36,8 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
               "emo_gemm: conv needs Cin %% %d == 0 and K == 9*Cin (Cin=%d K=%d)", V, p.Cin, p.K);
     EMO_CHECK(p.H > 0 && p.W_ > 0 && p.Ho > 0 && p.Wo > 0 && (p.stride == 1 || p.stride == 2), EMO_ERR_BAD_SHAPE, "emo_gemm: conv geometry");
     EMO_CHECK(p.M % ((int64_t)p.Ho * p.Wo) == 0, EMO_ERR_BAD_SHAPE, "emo_gemm: conv M not a multiple of Ho*Wo");
-    const int He = p.upsample2x ? 2 * p.H : p.H, We = p.upsample2x ? 2 * p.W_ : p.W_;
+    EMO_CHECK((p.up_h == 0) == (p.up_w == 0) && p.up_h >= 0 && !(p.up_h && p.upsample2x), EMO_ERR_BAD_SHAPE, "emo_gemm: up_h / up_w");
+    const int He = p.up_h ? p.up_h : (p.upsample2x ? 2 * p.H : p.H), We = p.up_h ? p.up_w : (p.upsample2x ? 2 * p.W_ : p.W_);
     const int pad_tot = p.conv_asym ? 1 : 2;
     EMO_CHECK(p.Ho == (He + pad_tot - 3) / p.stride + 1 && p.Wo == (We + pad_tot - 3) / p.stride + 1, EMO_ERR_BAD_SHAPE, "emo_gemm: conv output size");
   }
@@ -52,7 +53,7 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
   }
   {
     const int bk = KBYTES / (p.dtype == EMO_F32 ? 4 : 2);
-    if (conv && p.stride == 1 && !p.conv_asym && !p.upsample2x && !p.transpose_out && !p.geglu && S == 1 && p.Cin % bk == 0 &&
+    if (conv && p.stride == 1 && !p.conv_asym && !p.upsample2x && !p.up_h && !p.transpose_out && !p.geglu && S == 1 && p.Cin % bk == 0 &&
         p.H % 8 == 0 && p.W_ % HaloGeom::PW == 0 && (p.N & 3) == 0 &&
         (!p.rowbias || (p.rows_per_batch % (p.H * p.W_) == 0 && (p.ld_rowbias & 3) == 0))) {
       const int64_t nt = (p.N + HaloGeom::BN - 1) / HaloGeom::BN;

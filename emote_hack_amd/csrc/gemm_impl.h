@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
       EMO_GLDS16(src, sa + (i * NW + wave) * 1024);
       a_ptr[i] += BK;
     } else {
-      const int Hin = p.upsample2x ? 2 * p.H : p.H, Win = p.upsample2x ? 2 * p.W_ : p.W_;
+      const int Hin = p.up_h ? p.up_h : (p.upsample2x ? 2 * p.H : p.H), Win = p.up_h ? p.up_w : (p.upsample2x ? 2 * p.W_ : p.W_);
       const int k0 = kt * BK + klog * V;
       int tap, ci;
       if (cin_aligned) { tap = (kt * BK) / p.Cin; ci = kt * BK - tap * p.Cin + klog * V; }   // tap is wave-uniform (SALU)
@@ -450,6 +450,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
       const T* src = zero;
       if (a_ok[i] && k0 < p.K && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
         if (p.upsample2x) { iy >>= 1; ix >>= 1; }
+        else if (p.up_h) { iy = iy * p.H / p.up_h; ix = ix * p.W_ / p.up_w; }   // nearest to an explicit size (rare path)
         src = A + (((int64_t)a_cr[i].img * p.H + iy) * p.W_ + ix) * p.lda + ci;
       }
       EMO_GLDS16(src, sa + (i * NW + wave) * 1024);
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
 
   const bool ln_on = LN;
   bool lds_epilogue = false;
-  if constexpr (!TRANS && sizeof(T) == 2) {
+  if constexpr (!TRANS && sizeof(T) == 2 && Tile::STAGE_BYTES >= 80 * 32 * NW) {   // (a ring slot must hold a wave's 32 x 32 staging tile)
     lds_epilogue = use_lds_epi;
     if (lds_epilogue) {
       // the slot the last stage was read from is free once every wave has finished that stage (the other slot holds the
@@ -1066,12 +1067,17 @@ static int launch_gemm(const emo_gemm_params& p, int S, hipStream_t st) {
 //   EMO_TILE_256x160  8x1 waves of 32x160  10.2 KB / MFLOP for N = 320 / 640 / 960 / 1920 ... with M large
 //   EMO_TILE_256x320  4x2 waves of 64x160   7.0 KB / MFLOP, A panel read once for N = 320
 // (4-wave 128x256 / 256x128, 192x128, 128x192, 128x320 tiles were measured 15-35 % slower than these at equal LDS traffic per MFMA)
+#ifndef EMO_GEMM_NS
+#define EMO_GEMM_NS 2   // LDS ring depth (tools/bench/build_variant.sh builds deeper-ring / shorter-stage variants for A/B runs)
+#endif
 template <typename T, bool CONV, bool TRANS, bool LN>
 static int dispatch_tile(const emo_gemm_params& p, const GemmPlan& pl, int S, hipStream_t st) {
+  constexpr int NS = EMO_GEMM_NS;
+  constexpr int NS_BIG = (NS * 512 * KBYTES <= 160 * 1024) ? NS : 2;   // a 256x256 stage holds 512 rows of KBYTES
   switch (pl.tile) {
-    case EMO_TILE_256x256: return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, 2, LN>(p, S, st);
-    case EMO_TILE_64x64: return launch_gemm<T, CONV, TRANS, 1, 1, 2, 2, 2, LN>(p, S, st);
-    case EMO_TILE_128x160: return launch_gemm<T, CONV, TRANS, 1, 5, 4, 1, 2, LN>(p, S, st);
+    case EMO_TILE_256x256: return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, NS_BIG, LN>(p, S, st);
+    case EMO_TILE_64x64: return launch_gemm<T, CONV, TRANS, 1, 1, 2, 2, NS, LN>(p, S, st);
+    case EMO_TILE_128x160: return launch_gemm<T, CONV, TRANS, 1, 5, 4, 1, NS, LN>(p, S, st);
     case EMO_TILE_256x160:
       if constexpr (!CONV && !TRANS) return launch_gemm<T, CONV, TRANS, 1, 5, 8, 1, 2, LN>(p, S, st);
       break;
@@ -1080,7 +1086,7 @@ static int dispatch_tile(const emo_gemm_params& p, const GemmPlan& pl, int S, hi
       break;
     default: break;
   }
-  return launch_gemm<T, CONV, TRANS, 2, 2, 2, 2, 2, LN>(p, S, st);
+  return launch_gemm<T, CONV, TRANS, 2, 2, 2, 2, NS, LN>(p, S, st);
 }
 
 template <typename T>

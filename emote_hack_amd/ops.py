@@ -258,6 +258,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
         p.conv_taps, p.H, p.W_, p.Cin = 9, conv["H"], conv["W"], conv["Cin"]
         p.stride, p.upsample2x, p.Ho, p.Wo = conv["stride"], int(conv["upsample2x"]), conv["Ho"], conv["Wo"]
         p.conv_asym = int(conv.get("asym", 0))
+        p.up_h, p.up_w = conv.get("up", (0, 0))
     p.dtype = dt(a)
     p.tile = int(tile if tile is not None else (GEMM_TILE if conv is None else 0))
     if ln is not None:
@@ -282,15 +283,18 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
     return out
 
 
-def conv3x3(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, H: int, W: int, *, stride=1, upsample2x=False, pad=1, **kw):
+def conv3x3(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, H: int, W: int, *, stride=1, upsample2x=False, pad=1, upsample_to=None, **kw):
     """Per-frame 3x3 conv, pad 1 (resnet.py:30-38), as an implicit GEMM over NHWC rows.
     w is the re-laid (Cout, 9*Cin_pad) weight.  pad=0 means the asymmetric (0, 1, 0, 1) padding of the VAE encoder's downsampler."""
     cin = w.shape[1] // 9
-    He, We = (2 * H, 2 * W) if upsample2x else (H, W)
+    if upsample_to is not None and tuple(upsample_to) == (2 * H, 2 * W):
+        upsample2x, upsample_to = True, None        # the x2 fast path (a shift instead of a division per tap)
+    He, We = (2 * H, 2 * W) if upsample2x else (tuple(upsample_to) if upsample_to is not None else (H, W))
     tot = 2 if pad == 1 else 1
     Ho, Wo = (He + tot - 3) // stride + 1, (We + tot - 3) // stride + 1
     assert x.shape[0] == n_img * H * W and pad in (0, 1)
-    return gemm(x, w, bias, conv=dict(H=H, W=W, Cin=cin, stride=stride, upsample2x=upsample2x, Ho=Ho, Wo=Wo, asym=int(pad == 0)), **kw), Ho, Wo
+    return gemm(x, w, bias, conv=dict(H=H, W=W, Cin=cin, stride=stride, upsample2x=upsample2x, Ho=Ho, Wo=Wo, asym=int(pad == 0),
+                                      up=(He, We) if upsample_to is not None else (0, 0)), **kw), Ho, Wo
 
 
 # ----------------------------------------------------------------------------- attention

@@ -499,14 +499,15 @@ class UNet3DConditionModel:
         if Cin != cfg["in_channels"]:
             raise ValueError(f"sample has {Cin} channels, expected {cfg['in_channels']}")
         up = 2 ** self.num_upsamplers
-        if H % up or W % up:
-            raise NotImplementedError("sample H/W must be multiples of 2**num_upsamplers (upsample_size forwarding is not built)")
+        # unet_controlnet.py:357-365: inputs that are not a multiple of 2^num_upsamplers forward the skip's size to the upsamplers
+        forward_upsample_size = bool(H % up or W % up)
         if cfg["center_input_sample"]:
             raise NotImplementedError("center_input_sample=True is outside the hot path (False in every shipped config)")
         dev = self.device
         s = _State()
         s.c = _Ctx(B, F, H, W)
         s.B, s.F, s.H, s.W = B, F, H, W
+        s.forward_upsample_size, s.skip_hw = forward_upsample_size, []
         sample = sample.to(dev)
         # time (unet_controlnet.py:376-398)
         if not torch.is_tensor(timestep):
@@ -545,7 +546,7 @@ class UNet3DConditionModel:
         s.x, _, _ = ops.conv3x3(x, w["conv_in.w"], w["conv_in.b"], B * F, H, W, out=self._skip_slot(s, B * F * H * W, self.spec.down[0].resnets[0].cin))
         if add_after_conv_in is not None:   # ControlNet: sample += controlnet_cond_embedding(cond) (controlnet.py:523-525)
             s.x = ops.add(s.x, add_after_conv_in)
-        self._push_skip(s, s.x)
+        self._push_skip(s, s.x, (H, W))
         s.h, s.w = H, W
         return s
 
@@ -563,8 +564,9 @@ class UNet3DConditionModel:
         s.pending = torch.empty(rows, c1 + c2, device=self.device, dtype=self.dtype)
         return s.pending[:, c1:]
 
-    def _push_skip(self, s, x):
+    def _push_skip(self, s, x, hw=None):
         s.skips.append(s.pending if s.zero_copy else x)
+        s.skip_hw.append(hw)
         s.n_pushed += 1
 
     @staticmethod
@@ -586,11 +588,12 @@ class UNet3DConditionModel:
                     x = self._transformer(a, x, s.ctx_rows, s.ctx_len, s.ctx_div, c, h_, w_, out=slot if mo is None else None, ctx_kv=s.ctx_kv)
                 if mo is not None:
                     x = self._motion(mo, x, c, h_, w_, out=slot)
-                self._push_skip(s, x)
+                self._push_skip(s, x, (h_, w_))
             if blk.sampler:
-                slot = self._skip_slot(s, x.shape[0] // 4, x.shape[1])
+                ho, wo = (h_ - 1) // 2 + 1, (w_ - 1) // 2 + 1          # 3x3, stride 2, padding 1
+                slot = self._skip_slot(s, s.B * s.F * ho * wo, x.shape[1])
                 x, h_, w_ = ops.conv3x3(x, w[blk.sampler + ".w"], w[blk.sampler + ".b"], s.B * s.F, h_, w_, stride=2, out=slot)
-                self._push_skip(s, x)
+                self._push_skip(s, x, (h_, w_))
         down_res, mid_res = s.ctrl
         if down_res is not None and mid_res is not None:
             s.skips = [ops.add(sk, ops.ncfhw_to_rows(r.to(dev), dtp)) for sk, r in zip(s.skips, down_res)]  # unet_controlnet.py:430-439
@@ -635,7 +638,10 @@ class UNet3DConditionModel:
             if x is _STOP:
                 break
             if blk.sampler:
-                x, h_, w_ = ops.conv3x3(x, w[blk.sampler + ".w"], w[blk.sampler + ".b"], B * F, h_, w_, upsample2x=True,
+                # unet_controlnet.py:456-459 / resnet.py:74-82: with forward_upsample_size the interpolation targets the size of
+                # the next skip tensor instead of x2
+                tgt = s.skip_hw[len(skips) - 1] if (s.forward_upsample_size and skips) else (2 * h_, 2 * w_)
+                x, h_, w_ = ops.conv3x3(x, w[blk.sampler + ".w"], w[blk.sampler + ".b"], B * F, h_, w_, upsample_to=tgt,
                                         out=None if not s.zero_copy or not skips else self._hidden_slot(s, skips, x.shape[1]))
         rc = self._reference_control
         if rc is not None:

@@ -137,6 +137,9 @@ typedef struct {
                  in the spirit of a BLAS algorithm id; combinations a tile cannot serve fall back to the nearest one that can */
   int conv_asym;   /* conv only: 1 = padding (0, 1, 0, 1) instead of 1 all round - the `F.pad(x, (0,1,0,1))` + stride-2
                       conv of the VAE encoder's Downsample2D (diffusers AutoencoderKL; Ho = (H + 1 - 3) / stride + 1) */
+  int up_h; int up_w;  /* conv only: nearest upsampling to an EXPLICIT size folded into the loader (F.interpolate(size=...),
+                      resnet.py:74-82 with `output_size`: inputs that are not a multiple of 2^num_upsamplers,
+                      unet_controlnet.py:357-365,456-459); source pixel = floor(dst * H / up_h).  0 = off (upsample2x covers x2) */
 } emo_gemm_params;
 int emo_gemm(const emo_gemm_params* p, void* stream);
 /* heuristic split factor for (M, N, K) and the workspace it needs */

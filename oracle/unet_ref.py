@@ -202,9 +202,13 @@ def motion_module(sd, p, x, heads, groups=32, n_attn=2):
     return h.reshape(b, f, c, hh, ww).permute(0, 2, 1, 3, 4)
 
 
-def upsample(sd, p, x):
-    """resnet.py:56-84 (Upsample3D): nearest x(1,2,2) then conv3x3."""
-    x = F.interpolate(x, scale_factor=[1.0, 2.0, 2.0], mode="nearest")
+def upsample(sd, p, x, output_size=None):
+    """resnet.py:56-84 (Upsample3D): nearest x(1,2,2) - or to an explicit `output_size` (f, h, w) when the UNet forwards the
+    skip's size (unet_controlnet.py:357-365,456-459) - then conv3x3."""
+    if output_size is None:
+        x = F.interpolate(x, scale_factor=[1.0, 2.0, 2.0], mode="nearest")
+    else:
+        x = F.interpolate(x, size=tuple(output_size), mode="nearest")
     return _conv_per_frame(sd, p + ".conv", x)
 
 
@@ -318,6 +322,7 @@ def unet_forward(sd, cfg, sample, timestep, encoder_hidden_states, *, bank_mode=
         x = x + mid_block_additional_residual
 
     rhd = list(reversed(hd))
+    forward_upsample_size = any(s_ % (2 ** (len(boc) - 1)) != 0 for s_ in sample.shape[-2:])   # unet_controlnet.py:357-365
     try:
         for i, t in enumerate(cfg["up_block_types"]):
             p = f"up_blocks.{i}"
@@ -328,7 +333,7 @@ def unet_forward(sd, cfg, sample, timestep, encoder_hidden_states, *, bank_mode=
                     x = tf(f"{p}.attentions.{j}", x, rhd[i])
                 x = mm(f"{p}.motion_modules.{j}", x)
             if (p + ".upsamplers.0.conv.weight") in sd:
-                x = upsample(sd, p + ".upsamplers.0", x)
+                x = upsample(sd, p + ".upsamplers.0", x, tuple(skips[-1].shape[2:]) if (forward_upsample_size and skips) else None)
     except GuttedBlock:
         if bank_mode != "write":
             raise

@@ -110,3 +110,21 @@ def test_audio_windows_vs_reference_loop(dtype):
         assert want.shape[0] == got.shape[0]
     tok = audio_context_tokens(audio_windows(g["t9_m2n2/in"].to(DEV), 2, 2), 4, feature_dim=16)
     assert tok.shape == (4, 5, 16) and torch.equal(tok[0, 2].cpu(), g["t9_m2n2/in"][0])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_videonet_attention_modules_vs_reference(dtype):
+    """SURVEY A19 (models/videonet.py:15-128): the width-concat reference attention and the per-pixel temporal attention vs
+    goldens produced by the reference's own classes (AST-extracted; xformers' memory_efficient_attention stood in by its
+    published softmax(q k^T K^-0.5) v semantics)."""
+    from emote_hack_amd.conditioning import SpatialAttentionModule, TemporalAttentionModule
+    g = load_file(os.path.join(cases.GOLDEN_DIR, "videonet.safetensors"))
+    tol = dict(rtol=1e-3, atol=1e-4) if dtype == torch.float32 else dict(rtol=5e-2, atol=5e-2)
+    sp = mk(SpatialAttentionModule, "videonet_spatial.", 64, 64, 8).to(DEV, dtype)
+    y = sp(seeded_randn((3, 64, 4, 8), 80).to(DEV), seeded_randn((3, 64, 4, 8), 81).to(DEV))
+    torch.testing.assert_close(y.float().cpu(), g["spatial/out"], **tol)
+    tm = mk(TemporalAttentionModule, "videonet_temporal.", 64, 4, 64, 8).to(DEV, dtype)
+    y = tm(seeded_randn((2 * 4, 64, 4, 4), 82).to(DEV))
+    torch.testing.assert_close(y.float().cpu(), g["temporal/out"], **tol)
+    with pytest.raises(ValueError):
+        SpatialAttentionModule(64)          # the reference default embed_dim=40 cannot add attn_out to 64-channel tokens

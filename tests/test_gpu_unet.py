@@ -288,3 +288,13 @@ def test_motion_frame_conditioning_vs_oracle(graphs):
         nxt = denoise_loop(usd, cases.TINY_MOTION, rsd, cases.TINY, seeded_randn((1, 4, 4, 16, 16), 8), refl, text, scheduler=SchedulerRef("ddim"),
                            motion_latents=z[0, :, -2:].permute(1, 0, 2, 3), **kw)
         torch.testing.assert_close(clips[1].cpu(), nxt, rtol=4e-3, atol=4e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_unet_non_multiple_of_8_input(tiny, dtype):
+    """unet_controlnet.py:357-365,456-459: a 20x12 latent (not a multiple of 2^3) - stride-2 convs give 10x6, 5x3, 3x2 and the
+    upsamplers interpolate (nearest) to the skip's size instead of x2 (emo_gemm_params.up_h / up_w).  Golden from the
+    reference's own UNet."""
+    m = build(cases.TINY_MOTION, dtype)
+    y = m(seeded_randn((1, 4, 2, 20, 12), 1).to(DEV), 500, seeded_randn((1, 5, 32), 2).to(DEV)).sample
+    check(y, tiny["motion/out_20x12"], dtype)

@@ -333,3 +333,10 @@ def test_controlnet_state_dict_keys_follow_the_reference_module_tree():
     assert d["controlnet_mid_block.weight"] == (1280, 1280, 1, 1)
     assert not any(k.startswith(("up_blocks.", "conv_out.", "conv_norm_out.")) for k in d)
     assert "mid_block.attentions.0.transformer_blocks.0.attn1.to_q.weight" in d
+
+
+def test_unet_non_multiple_of_8_input(tiny):
+    """unet_controlnet.py:357-365,456-459: H / W not a multiple of 2^num_upsamplers -> the upsamplers interpolate to the skip
+    tensor's size (20x12 -> 10x6 -> 5x3 -> 3x2 and back).  Golden from the reference's own UNet."""
+    y = U.unet_forward(tiny_sd(cases.TINY_MOTION), cases.TINY_MOTION, seeded_randn((1, 4, 2, 20, 12), 1), 500, seeded_randn((1, 5, 32), 2))
+    close(y, tiny["motion/out_20x12"])

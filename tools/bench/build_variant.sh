@@ -1,13 +1,19 @@
 #!/bin/bash
-# usage: build_variant.sh NAME SRC "-DFLAG ..."   -> emote_hack_amd/lib/variants/NAME.so (SRC.hip rebuilt with the flags, other objects from lib/)
+# usage: build_variant.sh NAME "-DFLAG ..."   -> emote_hack_amd/lib/variants/NAME.so
+# Rebuilds the GEMM translation units that see the flags (gemm.hip: planning, gemm_bf16.hip: kernels) and links them with the
+# other objects of the product build.  BENCH ONLY: the f32 / f16 kernels keep the product's geometry - load the variant with
+# EMO_HIP_LIB=... and run bf16 microbenchmarks (tools/bench/gemm_tiles.py).
 set -e
-cd "$(dirname "$0")/.."
-N=$1; SRC=$2; shift; shift
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-variable -Wno-pass-failed $@ -c emote_hack_amd/csrc/$SRC.hip -o /tmp/emo_variant_$N.o
+cd "$(dirname "$0")/../.."
+N=$1; shift
+FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-variable -Wno-pass-failed"
+/opt/rocm/bin/hipcc $FL $@ -c emote_hack_amd/csrc/gemm.hip -o /tmp/emo_variant_${N}_gemm.o &
+/opt/rocm/bin/hipcc $FL $@ -c emote_hack_amd/csrc/gemm_bf16.hip -o /tmp/emo_variant_${N}_gemm_bf16.o &
+wait
 L=emote_hack_amd/lib
 OBJS=""
-for o in elementwise norm gemm gemm_f32 gemm_bf16 gemm_f16 attention temporal conditioning; do
-  if [ "$o" == "$SRC" ]; then OBJS="$OBJS /tmp/emo_variant_$N.o"; else OBJS="$OBJS $L/$o.o"; fi
+for o in elementwise norm gemm gemm_f32 gemm_bf16 gemm_f16 attention temporal conditioning frontend; do
+  if [ "$o" == "gemm" ] || [ "$o" == "gemm_bf16" ]; then OBJS="$OBJS /tmp/emo_variant_${N}_$o.o"; else OBJS="$OBJS $L/$o.o"; fi
 done
 mkdir -p $L/variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $L/variants/$N.so

@@ -272,6 +272,8 @@ def gen_unet_tiny():
     for i, b in enumerate(banks):
         T[f"banks/{i}"] = b
     T["read/out"] = run_reader(u1, x, 961, ctx, banks)
+    # (b4) H / W not a multiple of 2^num_upsamplers: the upsamplers interpolate to the skip's size (unet_controlnet.py:357-365,456-459)
+    T["motion/out_20x12"] = u1(seeded_randn((1, 4, 2, 20, 12), 1), 500, seeded_randn((1, 5, 32), 2)).sample
     # (d) the reference's OWN low-precision forwards of the same models / inputs: the yard-stick for the bf16 / fp16 HIP
     # modes (their error against the fp32 goldens is compared with the error of these tensors against the fp32 goldens)
     import copy
@@ -361,6 +363,32 @@ def gen_conditioning():
     print("conditioning.safetensors", list(T))
 
 
+# =============================================================================== VideoNet attention modules
+def gen_videonet():
+    """models/videonet.py:15-128: SpatialAttentionModule (reference features concatenated along the width) and
+    TemporalAttentionModule, AST-extracted (the file imports xformers / diffusers at module level).  The one third-party op,
+    xformers.ops.memory_efficient_attention, is stood in by its published semantics softmax(q k^T K^-0.5) v for [B, M, H, K] /
+    [B, M, K] inputs (no bias, p = 0) - everything else executed is the reference's own code."""
+    from einops import rearrange
+
+    def mea(q, k, v):
+        if q.dim() == 4:
+            q, k, v = (t.transpose(1, 2) for t in (q, k, v))
+            return (torch.softmax(q @ k.transpose(-1, -2) * q.shape[-1] ** -0.5, -1) @ v).transpose(1, 2)
+        return torch.softmax(q @ k.transpose(-1, -2) * q.shape[-1] ** -0.5, -1) @ v
+
+    V = shim.extract_classes("/root/reference/models/videonet.py", ["SpatialAttentionModule", "TemporalAttentionModule"],
+                             extra_ns={"rearrange": rearrange, "memory_efficient_attention": mea})
+    T = {}
+    sp = load_synth(V["SpatialAttentionModule"](64, embed_dim=64, num_heads=8), "videonet_spatial.")
+    x, r = seeded_randn((3, 64, 4, 8), 80), seeded_randn((3, 64, 4, 8), 81)
+    T["spatial/out"] = sp(x, r)
+    tm = load_synth(V["TemporalAttentionModule"](64, 4, embed_dim=64, num_heads=8), "videonet_temporal.")
+    T["temporal/out"] = tm(seeded_randn((2 * 4, 64, 4, 4), 82))
+    save_file({k: v.contiguous() for k, v in T.items()}, os.path.join(GOLD, "videonet.safetensors"))
+    print("videonet.safetensors", {k: tuple(v.shape) for k, v in T.items()})
+
+
 # =============================================================================== audio windows (SURVEY 8f rank 4)
 def gen_audio_windows():
     """Net.py:649-667: the per-frame windowing loop of Wav2VecFeatureExtractor.extract_features_from_wav, run on synthetic
@@ -428,7 +456,7 @@ if __name__ == "__main__":
     ap.add_argument("--skip-cfg1", action="store_true")
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    todo = a.only.split(",") if a.only else ["ints", "modules", "unet", "cond", "controlnet", "audio", "cfg1"]
+    todo = a.only.split(",") if a.only else ["ints", "modules", "unet", "cond", "controlnet", "audio", "videonet", "cfg1"]
     if "ints" in todo:
         gen_ints()
     if "modules" in todo:
@@ -442,5 +470,7 @@ if __name__ == "__main__":
         gen_controlnet()
     if "audio" in todo:
         gen_audio_windows()
+    if "videonet" in todo:
+        gen_videonet()
     if "cfg1" in todo and not a.skip_cfg1:
         gen_cfg1()

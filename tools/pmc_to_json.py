@@ -11,7 +11,7 @@ import re
 import sqlite3
 import sys
 
-FAMILY = [("conv3x3_halo_kernel", "gemm_conv3x3"), (r"gemm_kernel<[^>]*?(unsigned short|float), true", "gemm_conv3x3"),
+FAMILY = [("layernorm_stats_kernel", "layernorm_stats"), ("softmax_rows_kernel", "softmax_rows"), ("conv3x3_halo_kernel", "gemm_conv3x3"), (r"gemm_kernel<[^>]*?(unsigned short|float), true", "gemm_conv3x3"),
           ("gemm_kernel", "gemm_dense"), ("gemm_splitk_epilogue", "gemm_splitk_epilogue"), ("temporal_attention_kernel", "temporal_attention"),
           ("attention_kernel", "attention"), ("layernorm_kernel", "layernorm"), ("gn_stats_kernel", "groupnorm"), ("gn_apply_kernel", "groupnorm")]
 
@@ -41,7 +41,38 @@ def load(path, counter):
     return agg
 
 
+def mfma(path):
+    """MFMA utilisation (half of BASELINE.json's metric) from one pass with --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES
+    GRBM_GUI_ACTIVE: SQ_VALU_MFMA_BUSY_CYCLES counts SIMD cycles with the matrix pipe busy (32 per v_mfma_f32_32x32x16_bf16,
+    MI355X_MICROARCH.md constants table), summed over the chip's 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE = shader-clock cycles the
+    dispatch was in flight.  util = MFMA_BUSY / (GUI_ACTIVE * 1024)."""
+    db = sqlite3.connect(path)
+    rows = db.execute("select name, counter_name, counter_value, dispatch_id from pmc_events").fetchall() \
+        if "dispatch_id" in [r[1] for r in db.execute("pragma table_info(pmc_events)")] else \
+        [(n, c, v, i) for i, (n, c, v) in enumerate(db.execute("select name, counter_name, counter_value from pmc_events"))]
+    per = {}
+    for name, cn, v, _ in rows:
+        f = family(name) or "other"
+        d = per.setdefault(f, {})
+        d[cn] = d.get(cn, 0.0) + float(v)
+        d["_n_" + cn] = d.get("_n_" + cn, 0) + 1
+    out = {"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE over `bench.py --steps 1 --warmup 1 "
+                   "--no-graphs --no-profile --no-cpu-baseline`; util = MFMA_BUSY / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs)", "per_kernel_family": {}}
+    tot_b = tot_a = 0.0
+    for f, d in sorted(per.items()):
+        b, a = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), d.get("GRBM_GUI_ACTIVE", 0.0)
+        out["per_kernel_family"][f] = {"launches": d.get("_n_GRBM_GUI_ACTIVE", 0), "mfma_busy_cycles": b, "gui_active_cycles": a,
+                                       "sq_busy_cu_cycles": d.get("SQ_BUSY_CU_CYCLES", 0.0), "mfma_busy_frac": b / (a * 1024.0) if a else None}
+        tot_b += b
+        tot_a += a
+    out["mfma_busy_frac"] = tot_b / (tot_a * 1024.0) if tot_a else None
+    out["mfma_busy_frac_note"] = "over every dispatch of the run (GEMM + conv + attention + the HBM-bound kernels), weighted by time in flight"
+    print(json.dumps(out, indent=1))
+
+
 def main():
+    if sys.argv[1] == "--mfma":
+        return mfma(sys.argv[2])
     fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
     out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1 --no-graphs "
                    "--no-profile --no-cpu-baseline` (2 loop iterations), gfx950 correction FETCH x2 (MI355X_MICROARCH.md HBM section); "
