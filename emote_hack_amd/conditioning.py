@@ -372,6 +372,52 @@ class TemporalAttentionModule(SpatialAttentionModule):
         return ops.rows_to_ncfhw(out, bt // T, C, T, h, wd).permute(0, 2, 1, 3, 4).reshape(bt, C, h, wd)
 
 
+# ----------------------------------------------------------------------------- FaceLocator
+class FaceLocator(_HipModule):
+    """Net.py:819-855: conv3x3(3->16) ReLU pool, conv3x3(16->32) ReLU pool, conv3x3(32->64) ReLU pool, 1x1 conv (64->1),
+    bilinear upsampling of the logits to the input size (align_corners=False).  images (B, 3, H, W) f32 -> logits (B, 1, H, W);
+    H, W multiples of 8.  The reference asserts float32 4-D input (:832-835); so does this."""
+
+    def __init__(self):
+        super().__init__()
+        self._shapes = {"conv1.weight": (16, 3, 3, 3), "conv1.bias": (16,), "conv2.weight": (32, 16, 3, 3), "conv2.bias": (32,),
+                        "conv3.weight": (64, 32, 3, 3), "conv3.bias": (64,), "final_conv.weight": (1, 64, 1, 1), "final_conv.bias": (1,)}
+
+    def _pack(self):
+        if self._sd is None or self.device.type != "cuda":
+            return
+        w = {}
+        for k, t in self._sd.items():
+            if k.endswith(".bias"):
+                w[k] = t.to(self.device).float().contiguous()
+            elif t.shape[-1] == 3:
+                co, ci = t.shape[0], t.shape[1]
+                cip = (ci + 7) // 8 * 8
+                o = torch.zeros(co, 3, 3, cip)
+                o[..., :ci] = t.permute(0, 2, 3, 1)
+                w[k] = o.reshape(co, 9 * cip).to(self.device, self.dtype).contiguous()
+            else:
+                w[k] = t.reshape(t.shape[0], -1).to(self.device, self.dtype).contiguous()
+        self._w = w
+
+    def forward(self, images):
+        self._need()
+        assert images.dtype == torch.float32, "Images must be of type torch.float32"
+        assert images.ndim == 4, "Images must have 4 dimensions [B, C, H, W]"
+        B, _, H, W = images.shape
+        if H % 8 or W % 8:
+            raise ValueError("FaceLocator: H and W must be multiples of 8 (three 2x2 poolings)")
+        w = self._w
+        x = ops.ncfhw_to_rows(images.to(self.device).permute(1, 0, 2, 3).unsqueeze(0), self.dtype, cpad=8)
+        h_, w_ = H, W
+        for name in ("conv1", "conv2", "conv3"):
+            x, _, _ = ops.conv3x3(x, w[name + ".weight"], w[name + ".bias"], B, h_, w_)
+            x = ops.maxpool2x2(ops.act(x, "relu"), B, h_, w_)
+            h_, w_ = h_ // 2, w_ // 2
+        logits = ops.gemm(x, w["final_conv.weight"], w["final_conv.bias"])
+        return ops.bilinear_to_nchw(logits, B, 1, h_, w_, H, W)
+
+
 # ----------------------------------------------------------------------------- audio front-end (SURVEY 8f row 4)
 def audio_windows(hidden_states: torch.Tensor, m: int = 2, n: int = 2) -> torch.Tensor:
     """Wav2VecFeatureExtractor.extract_features_from_wav, the windowing half (Net.py:649-667): for every audio frame f the

@@ -128,3 +128,65 @@ extern "C" int emo_rows_to_video(const void* x, int64_t ld, float* y, int B, int
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
+
+// ---- FaceLocator pieces (Net.py:819-855): 2x2 max pooling over NHWC rows, bilinear upsampling of the logits map
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2x2_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, int n_img, int H,
+                                                         int W, int C) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)n_img * Ho * Wo * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int xo = (int)(r % Wo); r /= Wo;
+    const int yo = (int)(r % Ho);
+    const int img = (int)(r / Ho);
+    const T* p = x + (((int64_t)img * H + 2 * yo) * W + 2 * xo) * ldx + c;
+    const float v = fmaxf(fmaxf(TT<T>::ld(p), TT<T>::ld(p + ldx)), fmaxf(TT<T>::ld(p + (int64_t)W * ldx), TT<T>::ld(p + (int64_t)(W + 1) * ldx)));
+    TT<T>::st(y + (((int64_t)img * Ho + yo) * Wo + xo) * ldy + c, v);
+  }
+}
+
+extern "C" int emo_maxpool2x2(const void* x, int64_t ldx, void* y, int64_t ldy, int n_img, int H, int W, int C, int dtype, void* stream) {
+  EMO_CHECK(x && y, EMO_ERR_NULL, "emo_maxpool2x2: null pointer");
+  EMO_CHECK(n_img > 0 && H >= 2 && W >= 2 && C > 0 && ldx >= C && ldy >= C, EMO_ERR_BAD_SHAPE, "emo_maxpool2x2: bad shape");
+  EMO_CHECK(emo_dtype_ok(dtype), EMO_ERR_BAD_DTYPE, "emo_maxpool2x2: dtype %d", dtype);
+  const int64_t total = (int64_t)n_img * (H / 2) * (W / 2) * C;
+  EMO_DISPATCH(dtype, "emo_maxpool2x2", (maxpool2x2_kernel<T><<<fgrid(total, 256), 256, 0, as_stream(stream)>>>((const T*)x, ldx, (T*)y, ldy, n_img, H, W, C)));
+  EMO_LAUNCH_CHECK();
+  return EMO_OK;
+}
+
+// F.interpolate(mode='bilinear', align_corners=False) of rows ((n) h w, ld >= C) to (n, C, Ho, Wo) f32:
+// src = (dst + 0.5) * in / out - 0.5 clamped at 0, neighbours i0 = floor(src), i1 = min(i0 + 1, in - 1)
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_kernel(const T* __restrict__ x, int64_t ld, float* __restrict__ y, int n_img, int C, int h, int w,
+                                                       int Ho, int Wo) {
+  const int64_t total = (int64_t)n_img * C * Ho * Wo;
+  const float sy = (float)h / (float)Ho, sx = (float)w / (float)Wo;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int xo = (int)(i % Wo);
+    int64_t r = i / Wo;
+    const int yo = (int)(r % Ho); r /= Ho;
+    const int c = (int)(r % C);
+    const int img = (int)(r / C);
+    const float fy = fmaxf(((float)yo + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf(((float)xo + 0.5f) * sx - 0.5f, 0.f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + 1 < h ? y0 + 1 : h - 1, x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const T* b = x + (int64_t)img * h * w * ld + c;
+    const float v00 = TT<T>::ld(b + ((int64_t)y0 * w + x0) * ld), v01 = TT<T>::ld(b + ((int64_t)y0 * w + x1) * ld);
+    const float v10 = TT<T>::ld(b + ((int64_t)y1 * w + x0) * ld), v11 = TT<T>::ld(b + ((int64_t)y1 * w + x1) * ld);
+    y[i] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+  }
+}
+
+extern "C" int emo_bilinear_to_nchw(const void* x, int64_t ld, float* y, int n_img, int C, int h, int w, int Ho, int Wo, int dtype, void* stream) {
+  EMO_CHECK(x && y, EMO_ERR_NULL, "emo_bilinear_to_nchw: null pointer");
+  EMO_CHECK(n_img > 0 && C > 0 && h > 0 && w > 0 && Ho > 0 && Wo > 0 && ld >= C, EMO_ERR_BAD_SHAPE, "emo_bilinear_to_nchw: bad shape");
+  EMO_CHECK(emo_dtype_ok(dtype), EMO_ERR_BAD_DTYPE, "emo_bilinear_to_nchw: dtype %d", dtype);
+  const int64_t total = (int64_t)n_img * C * Ho * Wo;
+  EMO_DISPATCH(dtype, "emo_bilinear_to_nchw", (bilinear_kernel<T><<<fgrid(total, 256), 256, 0, as_stream(stream)>>>((const T*)x, ld, y, n_img, C, h, w, Ho, Wo)));
+  EMO_LAUNCH_CHECK();
+  return EMO_OK;
+}

@@ -424,3 +424,21 @@ def rows_to_video(x: torch.Tensor, B, Cc, F, H, W, mul=0.5, add=0.5, lo=0.0, hi=
     check(_lib.load().emo_rows_to_video(px, ld, _ptr(y), B, Cc, F, H * W, float(mul), float(add), float(lo), float(hi), dt(x), _stream()),
           "emo_rows_to_video")
     return y
+
+
+def maxpool2x2(x: torch.Tensor, n_img: int, H: int, W: int) -> torch.Tensor:
+    """nn.MaxPool2d(2, 2) over NHWC rows (Net.py:828)."""
+    _need_cuda(x)
+    px, ldx = _rows(x)
+    y = torch.empty(n_img * (H // 2) * (W // 2), x.shape[1], device=x.device, dtype=x.dtype)
+    check(_lib.load().emo_maxpool2x2(px, ldx, _ptr(y), y.stride(0), n_img, H, W, x.shape[1], dt(x), _stream()), "emo_maxpool2x2")
+    return y
+
+
+def bilinear_to_nchw(x: torch.Tensor, n_img: int, Cc: int, h: int, w: int, Ho: int, Wo: int) -> torch.Tensor:
+    """F.interpolate(size=(Ho, Wo), mode='bilinear', align_corners=False) of NHWC rows into (n, C, Ho, Wo) f32 (Net.py:851)."""
+    _need_cuda(x)
+    px, ld = _rows(x)
+    y = torch.empty(n_img, Cc, Ho, Wo, device=x.device, dtype=torch.float32)
+    check(_lib.load().emo_bilinear_to_nchw(px, ld, _ptr(y), n_img, Cc, h, w, Ho, Wo, dt(x), _stream()), "emo_bilinear_to_nchw")
+    return y

@@ -225,6 +225,10 @@ int emo_softmax_rows(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t M
 int emo_audio_windows(const void* feats, void* out, int T, int D, int m, int n, int dtype, void* stream);
 int emo_rows_to_video(const void* x, int64_t ld, float* y, int B, int C, int F, int HW, float mul, float add, float lo, float hi,
                       int dtype, void* stream);
+/* FaceLocator (Net.py:819-855): nn.MaxPool2d(2, 2) over NHWC rows (H, W -> H/2, W/2), and
+ * F.interpolate(logits, size=(Ho, Wo), mode='bilinear', align_corners=False) of rows ((n) h w, ld) into (n, C, Ho, Wo) f32. */
+int emo_maxpool2x2(const void* x, int64_t ldx, void* y, int64_t ldy, int n_img, int H, int W, int C, int dtype, void* stream);
+int emo_bilinear_to_nchw(const void* x, int64_t ld, float* y, int n_img, int C, int h, int w, int Ho, int Wo, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -141,6 +141,19 @@ def test_load_state_dict_merges_partial_loads():
     assert set(missing2) == set(base) and m._absent_keys() == []
 
 
+def test_vae_key_listing_is_the_published_sd_vae():
+    """(f)2: the AutoencoderKL of SD-1.x has 248 tensors / 83,653,863 parameters (the published `vae/` checkpoint of
+    runwayml/stable-diffusion-v1-5 and stabilityai/sd-vae-ft-*); the product's key walk reproduces both and the encoder /
+    decoder / quant split.  (Parity of the arithmetic is unpinned: diffusers is absent.)"""
+    import math
+    from emote_hack_amd.vae import VAE_DEFAULTS, vae_param_shapes
+    d = vae_param_shapes(VAE_DEFAULTS)
+    assert len(d) == 248 and sum(math.prod(s) for s in d.values()) == 83653863
+    assert d["decoder.mid_block.attentions.0.to_q.weight"] == (512, 512) and d["encoder.conv_out.weight"] == (8, 512, 3, 3)
+    assert d["quant_conv.weight"] == (8, 8, 1, 1) and d["post_quant_conv.weight"] == (4, 4, 1, 1)
+    assert "decoder.up_blocks.2.resnets.0.conv_shortcut.weight" in d and "decoder.up_blocks.3.upsamplers.0.conv.weight" not in d
+
+
 def test_bank_pairing_order(ints):
     from emote_hack_amd.spec import build_spec, reference_block_order
     strip = lambda names: [n.replace(".transformer_blocks.0", "") for n in names]

@@ -128,3 +128,17 @@ def test_videonet_attention_modules_vs_reference(dtype):
     torch.testing.assert_close(y.float().cpu(), g["temporal/out"], **tol)
     with pytest.raises(ValueError):
         SpatialAttentionModule(64)          # the reference default embed_dim=40 cannot add attn_out to 64-channel tokens
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_face_locator_vs_reference(g, dtype):
+    """SURVEY 8f row 4, Net.py:819-855: three conv3x3 + ReLU + 2x2 max-pool stages, a 1x1 conv and the bilinear upsampling of the
+    logits (align_corners=False) - vs the golden of the reference's own class."""
+    from emote_hack_amd.conditioning import FaceLocator
+    fl = mk(FaceLocator, "face_locator.").to(DEV, dtype)
+    y = fl(seeded_randn((2, 3, 32, 48), 68).to(DEV))
+    assert y.shape == (2, 1, 32, 48)
+    tol = dict(rtol=1e-3, atol=1e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(y.cpu(), g["face_locator/out"], **tol)
+    with pytest.raises(AssertionError):
+        fl(seeded_randn((2, 3, 32, 48), 68).to(DEV).half())

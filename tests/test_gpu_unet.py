@@ -298,3 +298,28 @@ def test_unet_non_multiple_of_8_input(tiny, dtype):
     m = build(cases.TINY_MOTION, dtype)
     y = m(seeded_randn((1, 4, 2, 20, 12), 1).to(DEV), 500, seeded_randn((1, 5, 32), 2).to(DEV)).sample
     check(y, tiny["motion/out_20x12"], dtype)
+
+
+def test_denoise_loop_wrapped_window_with_repeated_frames():
+    """uniform(20 frames, context 16, stride 2) emits a wrapped window that lists frames 0..10 twice
+    (context.py:20-42).  The reference's `noise_pred[:, :, c] = noise_pred[:, :, c] + pred` is an index assignment: ONE
+    occurrence per frame counts (the last), and the counter grows by one.  The accumulate kernel used to `+=` every occurrence
+    non-atomically (a race); the host now marks the earlier duplicates.  HIP f32 loop vs the oracle loop (torch semantics)."""
+    from oracle.pipeline_ref import denoise_loop
+    from oracle.scheduler_ref import SchedulerRef
+    from emote_hack_amd import DDIMScheduler
+    from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
+    from emote_hack_amd.pipeline import EMOAnimationPipeline
+    from emote_hack_amd.spec import build_spec, param_shapes
+    ref = build(cases.TINY, torch.float32, cases.REF_PREFIX, cls=AppearanceEncoderModel, has_out=False)
+    unet = build(cases.TINY_MOTION, torch.float32)
+    usd = synth_state_dict(param_shapes(build_spec(cases.TINY_MOTION)))
+    rsd = synth_state_dict(param_shapes(ref.spec), prefix=cases.REF_PREFIX)
+    lat, refl, text = seeded_randn((1, 4, 20, 16, 16), 5), seeded_randn((1, 4, 16, 16), 3), seeded_randn((2, 5, 32), 2)
+    kw = dict(num_inference_steps=2, guidance_scale=7.5, context_frames=16, context_stride=2, context_overlap=4, seed=0)
+    want = denoise_loop(usd, cases.TINY_MOTION, rsd, cases.TINY, lat, refl, text, scheduler=SchedulerRef("ddim"), **kw)
+    pipe = EMOAnimationPipeline(unet=unet, scheduler=DDIMScheduler())
+    st = pipe.prepare_denoise(lat.to(DEV), refl, text, appearance_encoder=ref, **kw)
+    assert any(int((fi < 0).sum()) > 0 for fi in st.frame_idx), "the wrapped window must carry dropped duplicates"
+    got = pipe.denoise(lat.to(DEV), refl, text, appearance_encoder=ref, **kw)
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-3, atol=2e-4)

@@ -341,6 +341,7 @@ def gen_conditioning():
     T = {}
     N = shim.extract_classes("/root/reference/Net.py",
                              ["SpeedEncoder", "CrossAttentionLayer", "AudioAttentionLayers", "ReferenceAttentionLayer"])
+    N2 = shim.extract_classes("/root/reference/Net.py", ["FaceLocator"])
     S2 = shim.extract_classes("/root/reference/train_stage_2_temporal_audio.py", ["TemporalAttention", "AudioAttention"])
     S3 = shim.extract_classes("/root/reference/train_stage_3_speedlayers.py", ["SpeedController", "FaceRegionController"])
     speeds = torch.tensor(cases.SPEEDS, dtype=torch.float32)
@@ -359,6 +360,8 @@ def gen_conditioning():
     T["stage2_audio/out"] = aa(seeded_randn((2, 12, 64), 65), seeded_randn((2, 5, 768), 66))
     ta = load_synth(S2["TemporalAttention"](64, 8), "stage2_temporal.")
     T["stage2_temporal/out"] = ta(seeded_randn((2, 12, 64), 67))
+    fl = load_synth(N2["FaceLocator"](), "face_locator.")
+    T["face_locator/out"] = fl(seeded_randn((2, 3, 32, 48), 68))
     save_file({k: v.contiguous() for k, v in T.items()}, os.path.join(GOLD, "conditioning.safetensors"))
     print("conditioning.safetensors", list(T))
 

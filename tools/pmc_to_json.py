@@ -43,30 +43,34 @@ def load(path, counter):
 
 def mfma(path):
     """MFMA utilisation (half of BASELINE.json's metric) from one pass with --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES
-    GRBM_GUI_ACTIVE: SQ_VALU_MFMA_BUSY_CYCLES counts SIMD cycles with the matrix pipe busy (32 per v_mfma_f32_32x32x16_bf16,
-    MI355X_MICROARCH.md constants table), summed over the chip's 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE = shader-clock cycles the
-    dispatch was in flight.  util = MFMA_BUSY / (GUI_ACTIVE * 1024)."""
+    GRBM_GUI_ACTIVE.  SQ_VALU_MFMA_BUSY_CYCLES counts SIMD cycles with the matrix pipe busy (32 per v_mfma_f32_32x32x16_bf16,
+    MI355X_MICROARCH.md constants table; checked against the conv FLOPs of the run).  rocprofv3 on gfx950 reports every counter
+    once PER XCD and dispatch (8 rows per launch: 8 x 1050 dense launches = 8400 rows), each GRBM_GUI_ACTIVE row holding the
+    dispatch's full duration in shader cycles, so
+        util = sum(MFMA_BUSY rows) / (sum(GUI_ACTIVE rows) / XCDS * 256 CUs * 4 SIMDs) = sum(busy) / (sum(gui) * 128)."""
+    XCDS, SIMDS = 8, 1024
     db = sqlite3.connect(path)
-    rows = db.execute("select name, counter_name, counter_value, dispatch_id from pmc_events").fetchall() \
-        if "dispatch_id" in [r[1] for r in db.execute("pragma table_info(pmc_events)")] else \
-        [(n, c, v, i) for i, (n, c, v) in enumerate(db.execute("select name, counter_name, counter_value from pmc_events"))]
     per = {}
-    for name, cn, v, _ in rows:
+    for name, cn, v in db.execute("select name, counter_name, counter_value from pmc_events"):
         f = family(name) or "other"
         d = per.setdefault(f, {})
         d[cn] = d.get(cn, 0.0) + float(v)
         d["_n_" + cn] = d.get("_n_" + cn, 0) + 1
     out = {"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE over `bench.py --steps 1 --warmup 1 "
-                   "--no-graphs --no-profile --no-cpu-baseline`; util = MFMA_BUSY / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs)", "per_kernel_family": {}}
+                   "--no-graphs --no-profile --no-cpu-baseline` (eager: the ReferenceNet group pass weighs more than in a 50-step run); "
+                   "counters arrive once per XCD and dispatch; util = sum(MFMA_BUSY) / (sum(GRBM_GUI_ACTIVE) / 8 * 1024 SIMDs)",
+           "per_kernel_family": {}}
     tot_b = tot_a = 0.0
     for f, d in sorted(per.items()):
         b, a = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), d.get("GRBM_GUI_ACTIVE", 0.0)
-        out["per_kernel_family"][f] = {"launches": d.get("_n_GRBM_GUI_ACTIVE", 0), "mfma_busy_cycles": b, "gui_active_cycles": a,
-                                       "sq_busy_cu_cycles": d.get("SQ_BUSY_CU_CYCLES", 0.0), "mfma_busy_frac": b / (a * 1024.0) if a else None}
-        tot_b += b
-        tot_a += a
-    out["mfma_busy_frac"] = tot_b / (tot_a * 1024.0) if tot_a else None
-    out["mfma_busy_frac_note"] = "over every dispatch of the run (GEMM + conv + attention + the HBM-bound kernels), weighted by time in flight"
+        out["per_kernel_family"][f] = {"launches": d.get("_n_GRBM_GUI_ACTIVE", 0) // XCDS, "mfma_busy_cycles": b,
+                                       "dispatch_cycles": a / XCDS, "sq_busy_cu_cycles": d.get("SQ_BUSY_CU_CYCLES", 0.0),
+                                       "mfma_busy_frac": b / (a / XCDS * SIMDS) if a else None}
+        if f != "other":   # torch's own kernels (weight synthesis, packing) are not the path
+            tot_b += b
+            tot_a += a
+    out["mfma_busy_frac"] = tot_b / (tot_a / XCDS * SIMDS) if tot_a else None
+    out["mfma_busy_frac_note"] = "over every dispatch of the path's kernel families (GEMM, conv, attention AND the HBM-bound kernels), weighted by time in flight"
     print(json.dumps(out, indent=1))
 
 
