@@ -85,6 +85,14 @@ def norms():
 
 
 if __name__ == "__main__":
+    import os
+    if os.environ.get("GEMM_TILES_QUICK"):   # the planned tile only, the shapes that dominate the step
+        for args, kw in (((98304, 320, 320), dict(res=True)), ((98304, 960, 320), dict(ln=True)), ((98304, 320, 1280), dict(res=True)),
+                         ((24576, 640, 640), dict(res=True)), ((24576, 640, 2560), dict(res=True)), ((6144, 1280, 1280), dict(res=True)),
+                         ((6144, 1280, 5120), dict(res=True)), ((98304, 2560, 320), dict(geglu=True, ln=True)),
+                         ((24576, 5120, 640), dict(geglu=True, ln=True)), ((6144, 10240, 1280), dict(geglu=True, ln=True))):
+            dense(*args, (0,), **kw)
+        raise SystemExit(0)
     norms()
     T = (0, 2, 3, 4)
     dense(98304, 320, 320, T, res=True)
