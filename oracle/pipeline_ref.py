@@ -94,8 +94,15 @@ def denoise_loop(unet_sd, unet_cfg, ref_sd, ref_cfg, latents, ref_latents, text_
                 pred_uc, pred_c = pred.chunk(2)
                 pred = torch.stack([pred_uc, pred_c])
                 for j, c in enumerate(context):
-                    noise_pred[:, :, c] = noise_pred[:, :, c] + pred[:, j]
-                    counter[:, :, c] = counter[:, :, c] + 1
+                    # reference (:792-794): noise_pred[:, :, c] = noise_pred[:, :, c] + pred[:, j]; counter likewise.  A wrapped
+                    # window at context_stride > 1 lists a frame twice; torch leaves WHICH of the two writes of an index
+                    # assignment survives undefined (serial CPU: the last one; parallel CPU / CUDA index_put: a race), so
+                    # the restatement pins the serial outcome explicitly - one occurrence per frame, the last
+                    last = {k: i for i, k in enumerate(c)}
+                    keep = [i for i, k in enumerate(c) if last[k] == i]
+                    frames = [c[i] for i in keep]
+                    noise_pred[:, :, frames] = noise_pred[:, :, frames] + pred[:, j][:, :, keep]
+                    counter[:, :, frames] = counter[:, :, frames] + 1
         uc, cc = (noise_pred / counter).chunk(2)
         eps = uc + guidance_scale * (cc - uc)
         if return_eps:

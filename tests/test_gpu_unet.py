@@ -141,8 +141,8 @@ def test_denoise_loop_vs_golden(kind, graphs, ref_group):
                             context_stride=1, context_overlap=2, seed=0, return_eps=True, use_graphs=graphs,
                             reference_group=ref_group)
     for i in range(3):
-        torch.testing.assert_close(eps[i].cpu(), g[f"{kind}/eps{i}"], rtol=2e-3, atol=2e-4)
-    torch.testing.assert_close(lat.cpu(), g[f"{kind}/latents"], rtol=2e-3, atol=2e-4)
+        torch.testing.assert_close(eps[i].cpu(), g[f"{kind}/eps{i}"], rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(lat.cpu(), g[f"{kind}/latents"], rtol=1e-3, atol=1e-4)
 
 
 @pytest.mark.parametrize("graphs", [False, True])
@@ -170,7 +170,7 @@ def test_denoise_loop_multi_gpu_code_path_single_rank(graphs):
                                 appearance_encoder=ref, num_inference_steps=3, guidance_scale=7.5, context_frames=4,
                                 context_stride=1, context_overlap=2, seed=0, return_eps=True, use_graphs=graphs,
                                 dist=True, rank=0, world_size=1)
-        torch.testing.assert_close(lat.cpu(), g["ddpm/latents"], rtol=2e-3, atol=2e-4)
+        torch.testing.assert_close(lat.cpu(), g["ddpm/latents"], rtol=1e-3, atol=1e-4)
     finally:
         td.destroy_process_group()
 
@@ -277,17 +277,17 @@ def test_motion_frame_conditioning_vs_oracle(graphs):
     base = denoise_loop(usd, cases.TINY_MOTION, rsd, cases.TINY, lat, refl, text, scheduler=SchedulerRef("ddim"), **kw)
     pipe = EMOAnimationPipeline(unet=unet, scheduler=DDIMScheduler())
     got = pipe.denoise(lat.to(DEV), refl, text, appearance_encoder=ref, use_graphs=graphs, motion_latents=motion, **kw)
-    torch.testing.assert_close(got.cpu(), want, rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-3, atol=1e-4)
     assert float((want - base).abs().max()) > 1e-3
     if not graphs:   # clip chaining: the second clip sees the first one's tail, the first one zero maps
         clips = pipe.denoise_chained([lat.to(DEV), seeded_randn((1, 4, 4, 16, 16), 8).to(DEV)], refl, text, n_motion_frames=2,
                                      appearance_encoder=ref, **kw)
         z = denoise_loop(usd, cases.TINY_MOTION, rsd, cases.TINY, lat, refl, text, scheduler=SchedulerRef("ddim"),
                          motion_latents=torch.zeros(2, 4, 16, 16), **kw)
-        torch.testing.assert_close(clips[0].cpu(), z, rtol=2e-3, atol=2e-4)
+        torch.testing.assert_close(clips[0].cpu(), z, rtol=1e-3, atol=1e-4)
         nxt = denoise_loop(usd, cases.TINY_MOTION, rsd, cases.TINY, seeded_randn((1, 4, 4, 16, 16), 8), refl, text, scheduler=SchedulerRef("ddim"),
                            motion_latents=z[0, :, -2:].permute(1, 0, 2, 3), **kw)
-        torch.testing.assert_close(clips[1].cpu(), nxt, rtol=4e-3, atol=4e-4)
+        torch.testing.assert_close(clips[1].cpu(), nxt, rtol=2e-3, atol=2e-4)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -303,8 +303,10 @@ def test_unet_non_multiple_of_8_input(tiny, dtype):
 def test_denoise_loop_wrapped_window_with_repeated_frames():
     """uniform(20 frames, context 16, stride 2) emits a wrapped window that lists frames 0..10 twice
     (context.py:20-42).  The reference's `noise_pred[:, :, c] = noise_pred[:, :, c] + pred` is an index assignment: ONE
-    occurrence per frame counts (the last), and the counter grows by one.  The accumulate kernel used to `+=` every occurrence
-    non-atomically (a race); the host now marks the earlier duplicates.  HIP f32 loop vs the oracle loop (torch semantics)."""
+    occurrence per frame counts and the counter grows by one; WHICH occurrence is undefined in torch (a race in CUDA and in
+    multi-threaded CPU index_put - this test was flaky while the oracle used the bare index assignment), so product and oracle
+    pin the serial outcome: the last.  The accumulate kernel used to `+=` every occurrence non-atomically (a race); the host
+    now marks the earlier duplicates.  HIP f32 loop vs the oracle loop."""
     from oracle.pipeline_ref import denoise_loop
     from oracle.scheduler_ref import SchedulerRef
     from emote_hack_amd import DDIMScheduler
@@ -322,4 +324,4 @@ def test_denoise_loop_wrapped_window_with_repeated_frames():
     st = pipe.prepare_denoise(lat.to(DEV), refl, text, appearance_encoder=ref, **kw)
     assert any(int((fi < 0).sum()) > 0 for fi in st.frame_idx), "the wrapped window must carry dropped duplicates"
     got = pipe.denoise(lat.to(DEV), refl, text, appearance_encoder=ref, **kw)
-    torch.testing.assert_close(got.cpu(), want, rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-3, atol=1e-4)
