@@ -67,7 +67,7 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
       return rc_h;
     }
   }
-  GemmPlan pl = plan_gemm(p.M, p.N, p.K, p.dtype, p.geglu, p.transpose_out, p.tile, p.ln_colsum != nullptr);
+  GemmPlan pl = plan_gemm(p.M, p.N, p.K, p.dtype, p.geglu, p.transpose_out, p.tile & 15, p.ln_colsum != nullptr);   // (tile >> 4: tile-order override, gemm_impl.h)
   if (S > 1) {
     EMO_CHECK(p.workspace != nullptr && S <= 65535, EMO_ERR_NULL, "emo_gemm: split_k=%d needs a workspace", S);
     EMO_CHECK(p.N % 4 == 0, EMO_ERR_BAD_SHAPE, "emo_gemm: split-K needs N %% 4 == 0");

@@ -15,6 +15,8 @@ struct HaloGeom { static constexpr int PW = 16, BN = 128; };   // patch height: 
 
 enum { EMO_TILE_AUTO = 0, EMO_TILE_64x64 = 1, EMO_TILE_128x128 = 2, EMO_TILE_128x160 = 3, EMO_TILE_256x256 = 4,
        EMO_TILE_256x160 = 5, EMO_TILE_256x320 = 6 };
+// (measured and dropped: 4 waves of 128x128 with 512 registers - 880-900 TFLOP/s at 8192^3 against 1100 and 2-3x slower on short
+// K, hipcc spills ~220 VGPRs around the epilogue; a register-staged loader - tools/bench/patches/gemm_staged_loader.patch)
 struct GemmPlan { int tile, split_k; };
 
 static inline void tile_dims(int tile, int& bm, int& bn) {
@@ -64,6 +66,7 @@ static GemmPlan plan_gemm(int64_t M, int N, int K, int dtype, int geglu, int tra
     pl.tile = hint;
     if ((hint == EMO_TILE_256x160 || hint == EMO_TILE_256x320) && (transpose_out || (hint == EMO_TILE_256x320 && dtype == EMO_F32))) pl.tile = EMO_TILE_128x160;
     // GEGLU pairs a value tile with its gate tile inside one wave: only the even-WTN shapes (128x128, 256x256) serve it
+    if (hint > EMO_TILE_256x320) pl.tile = EMO_TILE_128x128;
     if (geglu && pl.tile != EMO_TILE_128x128 && pl.tile != EMO_TILE_256x256) pl.tile = EMO_TILE_128x128;
   }
   int bm, bn;

@@ -88,6 +88,7 @@ __device__ __forceinline__ uint4 lds_read16(unsigned addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
   return v;
 }
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 // Row-major fused epilogue of one 32-row MFMA tile row (lane <-> output row m; register quad g of tile j <-> columns
 // j*32 + 8*g + 4*half + {0..3}): bias, per-batch row bias, GEGLU, residual, scale, 8-byte (bf16) / 16-byte (f32) stores.
@@ -178,104 +179,137 @@ __device__ __forceinline__ void lds_write8(unsigned addr, unsigned lo, unsigned 
   const unsigned long long v = ((unsigned long long)hi << 32) | lo;
   asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
-// m_of(i, row) -> global output row of row `row` (0..31) of this wave's MFMA tile row i, or -1 if it does not exist
-template <typename T, int WTM, int WTN, int NW, int XBYTES, bool GEGLU, typename MF>
-__device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], const emo_gemm_params& p, MF m_of, int wn0, int wave, int lane,
-                                             unsigned xbase, T* __restrict__ C, const T* __restrict__ R, bool ln, const float (&ln_rstd)[WTM]) {
+// Addressing and order follow one observation: on gfx950 stores and loads share the in-order vmcnt, so a load issued after a
+// pass's stores (the next pass's residual chunks, a row-bias quad, a spilled 64-bit row address coming back from scratch) cannot
+// be waited for without waiting for those stores to be acknowledged by L2.  The first version (64-bit row addresses per chunk,
+// run-time branches for bias / row bias / residual) paid that round trip in every pass: hipcc had a vmcnt(0) in front of nearly
+// every LDS write.  In the instrumented build (tools/bench/gemm_timing.py) the epilogue of a 256x256 tile took 14-18 k cycles
+// whether 20 or 256 CUs were storing; now 6 k (plain) / 13 k (GEGLU).  Here
+//   * output and residual go through buffer resources anchored at the wave's first element, with ONE per-lane byte offset per
+//     operand and pass; what moves (tile row, chunk round) is a wave-uniform addend - no 64-bit row addresses to keep alive or
+//     spill; rows past M and masked columns fall outside the resource's range (stores dropped, loads zero): no branches.
+//     The whole offset goes into the VECTOR offset field (the hardware's range check does not see the scalar offset), and
+//     keeping the scalar field the literal 0 matters for a second reason, see the store below;
+//   * the residual chunks of pass s+1 are requested BEFORE the stores of pass s (two register sets);
+//   * LN / residual-or-scale / row bias are TEMPLATE flags: with them as run-time branches hipcc's waitcnt insertion fell back
+//     to vmcnt(0) at every join (and spilled row addresses around them) - the very round trips this function removes.
+//   * ROWW = 0: row r of the wave's tile is output row wm0 + r.  ROWW = 16 (halo conv): the tile is a stack of 16-pixel patch
+//     rows, row r is output row wm0 + (r / 16) * row_pitch + r % 16 (a chunk round never straddles a patch row).
+template <typename T, int WTM, int WTN, int NW, int XBYTES, bool GEGLU, bool LN, bool RES, bool ROWB, int ROWW = 0>
+__device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], const emo_gemm_params& p, int64_t wm0, int wn0, int wave, int lane,
+                                                    unsigned xbase, T* __restrict__ C, const T* __restrict__ R, const float (&ln_rstd)[WTM],
+                                                    int row_pitch = 0) {
+  auto roff = [&](int r0) -> unsigned { return ROWW == 0 ? (unsigned)r0 : (unsigned)((r0 / (ROWW ? ROWW : 1)) * row_pitch + r0 % (ROWW ? ROWW : 1)); };
   static_assert(sizeof(T) == 2, "the staged epilogue is for the 2-byte element types");
   constexpr int OTW = GEGLU ? WTN / 2 : WTN;                  // 32-column output tiles per wave row
   constexpr int JMAX = (XBYTES / (NW * 32) - 16) / 64;        // tiles per pass that fit this wave's share of the slot
-  constexpr int JG = JMAX < OTW ? JMAX : OTW;
-  static_assert(JG >= 1, "transpose slot too small");
+  constexpr int JFIT = JMAX < OTW ? JMAX : OTW;
+  constexpr int JG = JFIT >= 4 ? 4 : (JFIT >= 2 ? 2 : 1);     // power of two: a chunk round then covers whole rows
+  static_assert(JFIT >= 1, "transpose slot too small");
+  constexpr int NPO = (OTW + JG - 1) / JG, NPASS = WTM * NPO; // passes per tile row, passes in all
   constexpr int PITCH = JG * 64 + 16;                          // bytes per staged row (+16: rows on different banks)
+  constexpr int NIT = 2 * JG;                                  // 16-byte chunks per lane per pass: 32 rows * 4*nt chunks / 64 lanes
   const int half = lane >> 5, l31 = lane & 31;
   const unsigned xw = xbase + wave * (32 * PITCH);
   const int n_out = GEGLU ? p.N / 2 : p.N;
   const int oc0 = GEGLU ? (wn0 >> 1) : wn0;                    // first output column of this wave
-  const bool plain = R == nullptr && p.out_scale == 1.0f;
+  const int64_t rows_left = p.M - wm0;
+  auto span = [&](int64_t ld) -> int {                         // bytes from the wave's first element to the end of its last valid row
+    const int64_t b = (rows_left > 0 && n_out > oc0) ? ((rows_left - 1) * ld + (n_out - oc0)) * 2 : 0;
+    return (int)(b > 0x7fffffff ? 0x7fffffff : b);
+  };
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)(C + wm0 * p.ldc + oc0), 0, span(p.ldc), 0x00020000);
+  const bool has_r = RES && R != nullptr;
+  const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)(has_r ? R + wm0 * p.ldr + oc0 : C), 0, has_r ? span(p.ldr) : 0, 0x00020000);
+  const unsigned ldc2 = (unsigned)p.ldc * 2u, ldr2 = (unsigned)p.ldr * 2u;
+  // row bias (f32, one row per batch of rows_per_batch output rows): the whole table as one resource, rows past M clamp to the last
+  const int64_t rb_rows = ROWB ? (p.M + p.rows_per_batch - 1) / p.rows_per_batch : 0;
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(ROWB ? (const void*)p.rowbias : (const void*)C), 0,
+                                                                           ROWB ? (int)(((rb_rows - 1) * p.ld_rowbias + p.N) * 4) : 0, 0x00020000);
+  u32x4_t rv[2][RES ? NIT : 1];
+  // pass s -> (tile row i, first output tile ot0, tiles nt); chunk idx = it*64 + lane -> row = it*(64/cw) + lane/cw, c = lane%cw
+  auto lane_off = [&](int cw, int ot0, unsigned ld2) -> unsigned {
+    const int lrow = lane / cw, lc = lane - lrow * cw;
+    return (oc0 + ot0 * 32 + lc * 8 < n_out) ? (unsigned)lrow * ld2 + (unsigned)lc * 16u : 0x80000000u;   // masked column: out of range (num_records < 2^31)
+  };
+  auto load_res = [&](auto S) {
+    constexpr int s_ = decltype(S)::value, i = s_ / NPO, ot0 = (s_ % NPO) * JG, nt = (OTW - ot0) < JG ? (OTW - ot0) : JG, cw = nt * 4;
+    static_assert((cw & (cw - 1)) == 0, "chunks per staged row must be a power of two");
+    if constexpr (RES) {
+      const unsigned vo = lane_off(cw, ot0, ldr2);
 #pragma unroll
-  for (int i = 0; i < WTM; i++) {
-    const int64_t m_lane = m_of(i, l31);
-    const float* rbias = (p.rowbias && m_lane >= 0) ? p.rowbias + (m_lane / p.rows_per_batch) * p.ld_rowbias : nullptr;
-#pragma unroll
-    for (int ot0 = 0; ot0 < OTW; ot0 += JG) {
-      constexpr int dummy = 0; (void)dummy;
-      constexpr int NIT = 2 * JG;                              // 16-byte chunks per lane per pass: 32 rows * 4*nt chunks / 64 lanes
-      const int nt = (OTW - ot0) < JG ? (OTW - ot0) : JG;     // tiles in this pass (compile-time after unrolling)
-      const int cw = nt * 4;                                   // 16-byte chunks per staged row
-      // ---- residual loads of the whole pass first (coalesced 16-byte chunks; chunk idx -> (row, c)): their latency hides
-      // under phase 1
-      uint4 rv[NIT];
-#pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        rv[it] = make_uint4(0, 0, 0, 0);
-        const int idx = it * 64 + lane;
-        const int row = idx / cw, c = idx - row * cw;
-        const int64_t m = it < 2 * nt ? m_of(i, row) : -1;
-        const int col = oc0 + ot0 * 32 + c * 8;
-        if (R && m >= 0 && col < n_out) rv[it] = *(const uint4*)(R + m * p.ldr + col);
-      }
-      // ---- phase 1: lane <-> row, quads of 4 columns -> LDS
-#pragma unroll
-      for (int t = 0; t < JG; t++) {
-        if (ot0 + t >= OTW) break;
-        const int jv = GEGLU ? 2 * (ot0 + t) : (ot0 + t);
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const int nw0 = wn0 + jv * 32 + 8 * g + 4 * half;    // column in W-row space
-          float o[4] = {acc[i][jv][4 * g], acc[i][jv][4 * g + 1], acc[i][jv][4 * g + 2], acc[i][jv][4 * g + 3]};
-          if (nw0 < p.N) {
-            if (ln) { const float rs = ln_rstd[i]; o[0] *= rs; o[1] *= rs; o[2] *= rs; o[3] *= rs; }   // LayerNorm fold: finish with rstd_m
-            if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
-            if (rbias) { const float4 b4 = *(const float4*)(rbias + nw0); o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w; }
-            if constexpr (GEGLU) {
-              float gt[4] = {acc[i][jv + 1][4 * g], acc[i][jv + 1][4 * g + 1], acc[i][jv + 1][4 * g + 2], acc[i][jv + 1][4 * g + 3]};
-              if (ln) { const float rs = ln_rstd[i]; gt[0] *= rs; gt[1] *= rs; gt[2] *= rs; gt[3] *= rs; }
-              if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0 + 32); gt[0] += b4.x; gt[1] += b4.y; gt[2] += b4.z; gt[3] += b4.w; }
-              float g0, g1, g2, g3;
-              gelu_erf_poly2(gt[0], gt[1], g0, g1);
-              gelu_erf_poly2(gt[2], gt[3], g2, g3);
-              o[0] *= g0; o[1] *= g1; o[2] *= g2; o[3] *= g3;
-            }
-          }
-          lds_write8(xw + l31 * PITCH + t * 64 + (8 * g + 4 * half) * 2, pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
-        }
-      }
-      wait_lgkmcnt<0>();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- phase 2: read back row-major, add the residual, store full lines
-      uint4 xv[NIT];
-#pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        const int idx = it * 64 + lane;
-        const int row = idx / cw, c = idx - row * cw;
-        if (it < 2 * nt) xv[it] = lds_read16(xw + row * PITCH + c * 16);
-      }
-      wait_lgkmcnt<0>();
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        const int idx = it * 64 + lane;
-        const int row = idx / cw, c = idx - row * cw;
-        const int64_t m = it < 2 * nt ? m_of(i, row) : -1;
-        const int col = oc0 + ot0 * 32 + c * 8;
-        if (m >= 0 && col < n_out) {
-          if (plain) {   // no residual, no scale: the staged bf16 chunk is the result
-            *(uint4*)(C + m * p.ldc + col) = xv[it];
-          } else {
-            float x[8], r[8];
-            unpack16<T>(xv[it], x);
-            unpack16<T>(rv[it], r);
-#pragma unroll
-            for (int e = 0; e < 8; e++) x[e] = (x[e] + r[e]) * p.out_scale;
-            *(uint4*)(C + m * p.ldc + col) = pack16<T>(x);
-          }
-        }
-      }
-      wait_lgkmcnt<0>();   // (all reads retired before the next pass overwrites the region)
-      __builtin_amdgcn_sched_barrier(0);
+      for (int it = 0; it < 2 * nt; it++)
+        rv[s_ & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, vo + roff(i * 32 + it * (64 / cw)) * ldr2 + (unsigned)(ot0 * 64), 0, 0);   // (the range check sees the vector offset only)
     }
-  }
+  };
+  load_res(std::integral_constant<int, 0>{});
+  static_for<NPASS>([&](auto S) {
+    constexpr int s_ = decltype(S)::value, i = s_ / NPO, ot0 = (s_ % NPO) * JG, nt = (OTW - ot0) < JG ? (OTW - ot0) : JG, cw = nt * 4;
+    // (the bias is in the accumulators - init_acc_bias / the LayerNorm fold; the per-batch row bias is not)
+    unsigned rb_off = 0;
+    if constexpr (ROWB) {
+      int64_t m_lane = ROWW ? wm0 : wm0 + i * 32 + l31;   // (a patch lies inside one frame: one bias row)
+      if (m_lane >= p.M) m_lane = p.M - 1;
+      rb_off = (unsigned)((m_lane / p.rows_per_batch) * p.ld_rowbias) * 4u;
+    }
+    // ---- phase 1: lane <-> row, quads of 4 columns -> LDS (columns past N carry junk: they are masked at the store)
+#pragma unroll
+    for (int t = 0; t < nt; t++) {
+      constexpr int dummy = 0; (void)dummy;
+      const int jv = GEGLU ? 2 * (ot0 + t) : (ot0 + t);
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int nw0 = wn0 + jv * 32 + 8 * g + 4 * half;    // column in W-row space
+        float o[4] = {acc[i][jv][4 * g], acc[i][jv][4 * g + 1], acc[i][jv][4 * g + 2], acc[i][jv][4 * g + 3]};
+        if constexpr (LN) { const float rs = ln_rstd[i]; o[0] *= rs; o[1] *= rs; o[2] *= rs; o[3] *= rs; }   // LayerNorm fold: finish with rstd_m
+        if constexpr (ROWB) {
+          const u32x4_t bq = __builtin_amdgcn_raw_buffer_load_b128(rs_b, rb_off + (unsigned)nw0 * 4u, 0, 0);
+          o[0] += __uint_as_float(bq.x); o[1] += __uint_as_float(bq.y); o[2] += __uint_as_float(bq.z); o[3] += __uint_as_float(bq.w);
+        }
+        if constexpr (GEGLU) {
+          float gt[4] = {acc[i][jv + 1][4 * g], acc[i][jv + 1][4 * g + 1], acc[i][jv + 1][4 * g + 2], acc[i][jv + 1][4 * g + 3]};
+          if constexpr (LN) { const float rs = ln_rstd[i]; gt[0] *= rs; gt[1] *= rs; gt[2] *= rs; gt[3] *= rs; }
+          float g0, g1, g2, g3;
+          gelu_erf_poly2(gt[0], gt[1], g0, g1);
+          gelu_erf_poly2(gt[2], gt[3], g2, g3);
+          o[0] *= g0; o[1] *= g1; o[2] *= g2; o[3] *= g3;
+        }
+        lds_write8(xw + l31 * PITCH + t * 64 + (8 * g + 4 * half) * 2, pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
+      }
+    }
+    wait_lgkmcnt<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 2: read back row-major; request the NEXT pass's residual chunks; add this pass's residual; store full lines
+    uint4 xv[NIT];
+    const int lrow = lane / cw, lc = lane - lrow * cw;
+#pragma unroll
+    for (int it = 0; it < 2 * nt; it++) xv[it] = lds_read16(xw + (it * (64 / cw) + lrow) * PITCH + lc * 16);
+    if constexpr (s_ + 1 < NPASS) load_res(std::integral_constant<int, s_ + 1>{});
+    wait_lgkmcnt<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned vo = lane_off(cw, ot0, ldc2);
+#pragma unroll
+    for (int it = 0; it < 2 * nt; it++) {
+      static_assert(ROWW == 0 || (64 / cw <= ROWW && ROWW % (64 / cw) == 0), "a chunk round must stay inside a patch row");
+      const unsigned so = roff(i * 32 + it * (64 / cw)) * ldc2 + (unsigned)(ot0 * 64);
+      u32x4_t out = {xv[it].x, xv[it].y, xv[it].z, xv[it].w};
+      if constexpr (RES) {
+        float x[8], r[8];
+        unpack16<T>(xv[it], x);
+        unpack16<T>(make_uint4(rv[s_ & 1][it].x, rv[s_ & 1][it].y, rv[s_ & 1][it].z, rv[s_ & 1][it].w), r);   // (no residual: out of range, zeros)
+#pragma unroll
+        for (int e = 0; e < 8; e++) x[e] = (x[e] + r[e]) * p.out_scale;
+        const uint4 pk = pack16<T>(x);
+        out = u32x4_t{pk.x, pk.y, pk.z, pk.w};
+      }
+      // (the moving part of the address goes into the VECTOR offset, the scalar offset stays the literal 0: with an SGPR
+      // offset hipcc lets the next chunk's unpack overwrite the store's data registers in the very next instruction, and the
+      // store then writes that instead for some lanes - seen as `x << 16` patterns in the last tile of a pass once a block
+      // walks several tiles.  Without an SGPR offset the compiler applies the > 8-byte store-data hazard rule.)
+      __builtin_amdgcn_raw_buffer_store_b128(out, rs_c, vo + so, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  });
 }
 
 // Accumulators start at the bias (row-major layout: register quad g of tile j <-> columns j*32 + 8*g + 4*half + {0..3}):
@@ -371,6 +405,20 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
     const int qn = tiles_all >> 3, rn = tiles_all & 7, x = i & 7, idx = i >> 3;
     return (x < rn ? x * (qn + 1) : rn * (qn + 1) + (x - rn) * qn) + idx;
   };
+  // GROUPED order inside an XCD's run: the ~32 * BPC blocks of an XCD work on CONSECUTIVE positions of the order at any time.
+  // With n fastest that is one tile row - one A panel shared by all, but tiles_n DIFFERENT W panels, each used by one CU:
+  // at N = 8192 the XCD's L2 hit rate was 48 % (A hits, W misses), VMEM latency 1160 cycles, 37 % of the wave cycles parked
+  // in s_waitcnt (hipBLASLt on the same shape: 80 %, 450 cycles, 5 %).  Bands of gm tile rows with m fastest inside a band
+  // make the concurrent set a gm x (32 * BPC / gm) block: 4 + 8 panels instead of 1 + 32.  Narrow outputs (tiles_n <= 12) keep
+  // n fastest - their concurrent set already spans several rows.  (p.tile >> 4 overrides gm: tools/bench.)
+  const int gm_hint = (p.tile >> 4) & 15;
+  const int gm = gm_hint > 0 ? gm_hint : (tiles_n > 12 ? (Tile::BPC >= 2 ? 8 : 4) : 1);
+  auto tile_mn = [&](int t, int& tm, int& tn) {
+    if (gm <= 1) { tm = t / tiles_n; tn = t - tm * tiles_n; return; }
+    const int per = gm * tiles_n, g = t / per, r = t - g * per, m0 = g * gm;
+    const int gsz = tiles_m - m0 < gm ? tiles_m - m0 : gm;
+    tn = r / gsz; tm = m0 + (r - tn * gsz);
+  };
   const int nsplit = p.split_k > 1 ? p.split_k : 1;
 
   const T* __restrict__ A = (const T*)p.A;
@@ -399,9 +447,10 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
   const T* b_ptr[LB];
   int l_iter = blockIdx.x, l_kt = 0;   // the loader's tile (stream index) and next stage within the slice
   auto setup_loader = [&](int iter) {
-    const int tile = tile_of(iter);
-    const int64_t lbm = (int64_t)(tile / tiles_n) * BM;
-    const int lbn = (tile % tiles_n) * BN;
+    int ltm, ltn;
+    tile_mn(tile_of(iter), ltm, ltn);
+    const int64_t lbm = (int64_t)ltm * BM;
+    const int lbn = ltn * BN;
 #pragma unroll
     for (int i = 0; i < LA; i++) {
       const int row = (i * NW + wave) * (64 / CPR) + lrow;
@@ -501,7 +550,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
   const int n_out_all = p.geglu ? p.N / 2 : p.N;
   const bool use_lds_epi = !TRANS && sizeof(T) == 2 && nsplit == 1 && nk > 0 && (n_out_all & 7) == 0 && (p.N & 3) == 0 &&
                            (p.ldc & 7) == 0 && (!R || (p.ldr & 7) == 0) && (!p.rowbias || (p.ld_rowbias & 3) == 0) &&
-                           (!p.geglu || (WTN % 2 == 0));
+                           (!p.geglu || (WTN % 2 == 0 && !p.rowbias)) && (!p.rowbias || p.rows_per_batch > 0);
 
   // stream prologue: NS-1 stages in flight
   int gs = 0;   // stream stage counter of the MFMA loop (ring slot = gs % NS)
@@ -517,9 +566,10 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
   }
 
   for (int c_iter = blockIdx.x; c_iter < tiles_all; c_iter += G) {
-  const int c_tile = tile_of(c_iter);
-  const int64_t bm = (int64_t)(c_tile / tiles_n) * BM;
-  const int bn = (c_tile % tiles_n) * BN;
+  int ctm, ctn;
+  tile_mn(tile_of(c_iter), ctm, ctn);
+  const int64_t bm = (int64_t)ctm * BM;
+  const int bn = ctn * BN;
   const int tiles_left = (tiles_all - 1 - c_iter) / G;   // tiles of this block after this one
 
   f32x16 acc[WTM][WTN];
@@ -585,7 +635,11 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
       constexpr int kk = decltype(KK)::value, cur = kk & 1, nxt = cur ^ 1;
       wait_lgkmcnt<0>();                       // fragments of step kk
       __builtin_amdgcn_sched_barrier(0);
-      // side ops of this cluster: the next step's fragment reads, one at a time between the MFMAs
+      // side ops of this cluster: the next step's fragment reads, one at a time between the MFMAs.
+      // Measured and dropped (tools/bench/patches): (a) fragment reads ordered by first use + s_waitcnt lgkmcnt(n)
+      // per MFMA instead of lgkmcnt(0) per step, reads front-loaded two per MFMA - 8192^3 949 -> 989 us; (b) a register-staged
+      // loader (buffer_load_dwordx4 two stages ahead, ds_write_b128 into the ring) instead of LDS-DMA: the glds issue cost
+      // (~1150 cycles per stage in front of the first MFMA) goes away, the k-steps grow by as much - equal within 2 %.
       constexpr int n_rd = (kk + 1 < KSTEPS) ? NRD : 0;
       constexpr int n_side = n_rd;
       static_for<NMMA>([&](auto Q) {
@@ -618,11 +672,18 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
       // next tile's prefetched first stage); it is rewritten by the loader only behind the next stage's barrier
       __builtin_amdgcn_s_barrier();
       const unsigned xbase = lds_base + ((gs + NS - 1) % NS) * Tile::STAGE_BYTES;
-      auto m_of = [&](int i, int row) -> int64_t { const int64_t m = wm0 + i * 32 + row; return m < p.M ? m : -1; };
-      if (p.geglu) {
-        if constexpr (WTN % 2 == 0) epilogue_lds<T, WTM, WTN, NW, Tile::STAGE_BYTES, true>(acc, pe, m_of, wn0, wave, lane, xbase, C, R, ln_on, ln_rstd);
+      const bool res = R != nullptr || p.out_scale != 1.0f, rowb = p.rowbias != nullptr;
+      auto run = [&](auto GG, auto RS, auto RB) {
+        epilogue_lds<T, WTM, WTN, NW, Tile::STAGE_BYTES, decltype(GG)::value, LN, decltype(RS)::value, decltype(RB)::value>(
+            acc, pe, wm0, wn0, wave, lane, xbase, C, R, ln_rstd);
+      };
+      using Tr = std::true_type; using Fa = std::false_type;
+      if (p.geglu) {   // (GEGLU with a row bias is not staged: use_lds_epi)
+        if constexpr (WTN % 2 == 0) { if (res) run(Tr{}, Tr{}, Fa{}); else run(Tr{}, Fa{}, Fa{}); }
+      } else if (rowb) {
+        if (res) run(Fa{}, Tr{}, Tr{}); else run(Fa{}, Fa{}, Tr{});
       } else {
-        epilogue_lds<T, WTM, WTN, NW, Tile::STAGE_BYTES, false>(acc, pe, m_of, wn0, wave, lane, xbase, C, R, ln_on, ln_rstd);
+        if (res) run(Fa{}, Tr{}, Fa{}); else run(Fa{}, Fa{}, Fa{});
       }
     }
   }
@@ -950,12 +1011,15 @@ __global__ __launch_bounds__(32 * PH_, 2) void conv3x3_halo_kernel(const emo_gem
         // the halo buffer of the chunk just finished is free once every wave is past its last tap; the halo loader
         // rewrites it only behind the next stage's barrier
         __builtin_amdgcn_s_barrier();
-        auto m_of = [&](int i, int row) -> int64_t {
-          return ((int64_t)img * p.H + y0 + (wvm * WTM + i) * 2 + (row >> 4)) * p.W_ + x0 + (row & 15);
-        };
+        // (rows of this wave's tile: patch rows (wvm*WTM + i)*2 + r/16, pixels r%16 - the linear-rows epilogue with a row pitch)
+        const int64_t wm0 = ((int64_t)img * p.H + y0 + wvm * WTM * 2) * p.W_ + x0;
         const float no_ln[WTM] = {1.f, 1.f};
-        epilogue_lds<T, WTM, WTN, NW, Halo::HALO_BYTES, false>(acc, pe, m_of, wn0, wave, lane, lds_base + ((gc + 1) & 1) * Halo::HALO_BYTES, C, R,
-                                                               false, no_ln);
+        const unsigned xb = lds_base + ((gc + 1) & 1) * Halo::HALO_BYTES;
+        // (bias and the temb row bias are already in the accumulators)
+        if (R != nullptr || p.out_scale != 1.0f)
+          epilogue_lds<T, WTM, WTN, NW, Halo::HALO_BYTES, false, false, true, false, Halo::PW>(acc, pe, wm0, wn0, wave, lane, xb, C, R, no_ln, p.W_);
+        else
+          epilogue_lds<T, WTM, WTN, NW, Halo::HALO_BYTES, false, false, false, false, Halo::PW>(acc, pe, wm0, wn0, wave, lane, xb, C, R, no_ln, p.W_);
         staged = true;
       }
     }

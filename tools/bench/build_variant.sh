@@ -1,14 +1,21 @@
 #!/bin/bash
 # usage: build_variant.sh NAME "-DFLAG ..."   -> emote_hack_amd/lib/variants/NAME.so
+#        PATCH=tools/bench/patches/gemm_timing.patch build_variant.sh timing   (sources copied to /tmp and patched first)
 # Rebuilds the GEMM translation units that see the flags (gemm.hip: planning, gemm_bf16.hip: kernels) and links them with the
 # other objects of the product build.  BENCH ONLY: the f32 / f16 kernels keep the product's geometry - load the variant with
 # EMO_HIP_LIB=... and run bf16 microbenchmarks (tools/bench/gemm_tiles.py).
 set -e
 cd "$(dirname "$0")/../.."
 N=$1; shift
+SRC=emote_hack_amd/csrc
+if [ -n "$PATCH" ]; then
+  T=/tmp/emo_variant_src_$N; rm -rf $T; mkdir -p $T/x; cp -r $SRC $T/x/csrc; cp -r include $T/include   # (common.h: ../../include/emo_hip.h)
+  patch -s -p0 -d $T/x/csrc gemm_impl.h < $PATCH
+  SRC=$T/x/csrc
+fi
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-variable -Wno-pass-failed"
-/opt/rocm/bin/hipcc $FL $@ -c emote_hack_amd/csrc/gemm.hip -o /tmp/emo_variant_${N}_gemm.o &
-/opt/rocm/bin/hipcc $FL $@ -c emote_hack_amd/csrc/gemm_bf16.hip -o /tmp/emo_variant_${N}_gemm_bf16.o &
+/opt/rocm/bin/hipcc $FL $@ -c $SRC/gemm.hip -o /tmp/emo_variant_${N}_gemm.o &
+/opt/rocm/bin/hipcc $FL $@ -c $SRC/gemm_bf16.hip -o /tmp/emo_variant_${N}_gemm_bf16.o &
 wait
 L=emote_hack_amd/lib
 OBJS=""

@@ -50,6 +50,8 @@ if __name__ == "__main__":
                     (24576, 1920, 640), (24576, 5120, 640), (24576, 640, 2560), (6144, 1280, 1280), (6144, 3840, 1280),
                     (6144, 10240, 1280), (6144, 1280, 5120), (1536, 1280, 1280), (1536, 10240, 1280), (8192, 8192, 8192)):
         dense(M, N, K)
+    if "--dense-only" in sys.argv:
+        raise SystemExit(0)
     for n, H, W, Cin, N in ((24, 64, 64, 320, 320), (24, 64, 64, 640, 320), (24, 32, 32, 640, 640), (24, 32, 32, 1280, 640),
                             (24, 16, 16, 1280, 1280), (24, 16, 16, 2560, 1280), (24, 8, 8, 1280, 1280)):
         try:
