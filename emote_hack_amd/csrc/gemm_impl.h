@@ -626,7 +626,8 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
     for (int j = 0; j < WTN; j++) fb[0][j] = lds_read16(st + fb0[j]);
     constexpr int NMMA = WTM * WTN, NRD = WTM + WTN;
     // the whole next ring stage is requested right behind the barrier: it then has this stage's full MFMA time to land
-    // (spreading the glds between the MFMAs left the last ones ~no time: +10-20 % on the K >= 2560 shapes, 8192^3 980 -> 1130 TF/s)
+    // (spreading the glds between the MFMAs of all four k-steps left the last ones ~no time: 8192^3 980 -> 1130 TF/s clustered;
+    // one glds per MFMA over the first one or two k-steps only: equal to clustered within the run-to-run noise, r02k)
     if (more) {
       static_for<LA>([&](auto I) { issue_a(kt_next, slot_next, I); });
       static_for<LB>([&](auto I) { issue_b(kt_next, slot_next, I); });
