@@ -212,7 +212,6 @@ def layer_norm_stats(x: torch.Tensor, eps=1e-5) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------- GEMM / conv
 GEMM_TILE = 0   # tuning hook for tools/bench: pins emo_gemm_params.tile of every dense GEMM that does not pass tile=
-GEMM_DEBUG_WS = None   # tools/bench/gemm_timing.py: a uint32 tensor handed to single-pass GEMMs as `workspace` (timing builds write it)
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, geglu=False,
@@ -274,8 +273,6 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
     if sk > 1:
         ws = torch.empty(lib.emo_gemm_workspace_bytes(M, N, sk) // 4, device=a.device, dtype=torch.float32)
         p.split_k, p.workspace = sk, ws.data_ptr()
-    elif GEMM_DEBUG_WS is not None:
-        p.workspace = GEMM_DEBUG_WS.data_ptr()
     esz = a.element_size()
     _launch("gemm_conv3x3" if conv is not None else "gemm_dense", 2.0 * M * N * K,
             esz * (float(M) * (K if conv is None else conv["Cin"]) + float(N) * K + float(M) * n_out),
