@@ -255,7 +255,6 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], cons
     // ---- phase 1: lane <-> row, quads of 4 columns -> LDS (columns past N carry junk: they are masked at the store)
 #pragma unroll
     for (int t = 0; t < nt; t++) {
-      constexpr int dummy = 0; (void)dummy;
       const int jv = GEGLU ? 2 * (ot0 + t) : (ot0 + t);
 #pragma unroll
       for (int g = 0; g < 4; g++) {
