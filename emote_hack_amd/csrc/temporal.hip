@@ -6,7 +6,7 @@
 // One workgroup = P pixels x `hpb` heads of one batch element:
 //   stage   Q,K,V[f][p][hpb*d] for all F frames into LDS with fully coalesced row-segment loads (the
 //           einops transposes of the reference are folded into this indexing - nothing is permuted in HBM)
-//   phase A one thread per (p, head, fq, fk): score = scale * <q, k>   -> LDS S
+//   phase A one work item per (p, head, 3 x 3 block of (fq, fk)): score = scale * <q, k>   -> LDS S
 //   phase B one thread per (p, head, fq): softmax over fk in f32
 //   phase C one thread per (p, head, fq, 16-byte channel vector): out = sum_fk P * V, stored straight to the
 //           output rows (coalesced).
@@ -61,21 +61,40 @@ __global__ __launch_bounds__(TA_THREADS) void temporal_attention_kernel(const T*
   }
   __syncthreads();
 
-  // ---- phase A: scores.  Thread -> (fq, fk) on the padded FP x FP grid; loop over the (pixel, head) pairs, whose q / k
-  // vectors are d consecutive channels at (ph * d) of the staged rows
+  // ---- phase A: scores.  Work item -> (pixel-head pair, 3 x 3 block of (fq, fk)): 6 row chunks from LDS feed 9 dot products
+  // (one score per thread re-read the q and k rows of every head 12 times over: 327 KB of LDS reads per 23 KB staged - the
+  // kernel was co-bound by LDS, not by HBM latency, `profiles/` r02: persistent + prefetched variant no faster)
   const int dv = d / V, NPH = P * hpb;
-  for (int pr = tid; pr < FP * FP; pr += TA_THREADS) {
-    const int fq = pr / FP, fk = pr & (FP - 1);
-    if (fq < F && fk < F) {
-      const unsigned char* qp = Qs + fq * ROW;
-      const unsigned char* kp = Ks + fk * ROW;
-      float* sp = S + fq * F + fk;
-      for (int ph = 0; ph < NPH; ph++) {
-        float acc = 0.f;
-        for (int c = 0; c < dv; c++) acc = dot16<T>(*(const uint4*)(qp + c * 16), *(const uint4*)(kp + c * 16), acc);
-        *sp = acc * scale;
-        qp += d * (int)sizeof(T); kp += d * (int)sizeof(T); sp += F * F;
+  {
+    const int nb = (F + 2) / 3, per = nb * nb;
+    for (int it = tid; it < NPH * per; it += TA_THREADS) {
+      const int ph = it / per, r = it - ph * per, bq = r / nb, bk = r - bq * nb;
+      const unsigned char* qp[3];
+      const unsigned char* kp[3];
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        const int fq = bq * 3 + u < F ? bq * 3 + u : F - 1, fk = bk * 3 + u < F ? bk * 3 + u : F - 1;
+        qp[u] = Qs + fq * ROW + ph * d * (int)sizeof(T);
+        kp[u] = Ks + fk * ROW + ph * d * (int)sizeof(T);
       }
+      float acc[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+      for (int c = 0; c < dv; c++) {
+        uint4 qv[3], kv[3];
+#pragma unroll
+        for (int u = 0; u < 3; u++) { qv[u] = *(const uint4*)(qp[u] + c * 16); kv[u] = *(const uint4*)(kp[u] + c * 16); }
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+#pragma unroll
+          for (int w = 0; w < 3; w++) acc[u][w] = dot16<T>(qv[u], kv[w], acc[u][w]);
+      }
+      float* sp = S + ph * F * F;
+#pragma unroll
+      for (int u = 0; u < 3; u++)
+#pragma unroll
+        for (int w = 0; w < 3; w++) {
+          const int fq = bq * 3 + u, fk = bk * 3 + w;
+          if (fq < F && fk < F) sp[fq * F + fk] = acc[u][w] * scale;
+        }
     }
   }
   __syncthreads();
@@ -105,19 +124,29 @@ __global__ __launch_bounds__(TA_THREADS) void temporal_attention_kernel(const T*
     const int hh = (cv * V) / d;
     const float* pbase = S + (pp * hpb + hh) * F * F;
     const unsigned char* vp = Vs + j * 16;
-    for (int fq = r0; fq < F; fq += rstep) {
-      const float* prow = pbase + fq * F;
-      float acc[V];
+    // up to 4 output rows fq = r0 + u * rstep share every V vector read
+    for (int fq0 = r0; fq0 < F; fq0 += 4 * rstep) {
+      float acc[4][V];
 #pragma unroll
-      for (int e = 0; e < V; e++) acc[e] = 0.f;
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int e = 0; e < V; e++) acc[u][e] = 0.f;
       for (int fk = 0; fk < F; fk++) {
         float vv[V];
         unpack16<T>(*(const uint4*)(vp + fk * ROW), vv);
-        const float w = prow[fk];
 #pragma unroll
-        for (int e = 0; e < V; e++) acc[e] += w * vv[e];
+        for (int u = 0; u < 4; u++) {
+          const int fq = fq0 + u * rstep;
+          const float w = fq < F ? pbase[fq * F + fk] : 0.f;
+#pragma unroll
+          for (int e = 0; e < V; e++) acc[u][e] += w * vv[e];
+        }
       }
-      *(uint4*)(out + ((int64_t)(b * F + fq) * HW + pix0 + pp) * ldo + c0 + cv * V) = pack16<T>(acc);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int fq = fq0 + u * rstep;
+        if (fq < F) *(uint4*)(out + ((int64_t)(b * F + fq) * HW + pix0 + pp) * ldo + c0 + cv * V) = pack16<T>(acc[u]);
+      }
     }
   }
 }
