@@ -10,7 +10,7 @@ N=$1; shift
 SRC=emote_hack_amd/csrc
 if [ -n "$PATCH" ]; then
   T=/tmp/emo_variant_src_$N; rm -rf $T; mkdir -p $T/x; cp -r $SRC $T/x/csrc; cp -r include $T/include   # (common.h: ../../include/emo_hip.h)
-  patch -s -p0 -d $T/x/csrc gemm_impl.h < $PATCH
+  patch -s -p2 -d $T/x/csrc < $PATCH
   SRC=$T/x/csrc
 fi
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-variable -Wno-pass-failed"
