@@ -139,6 +139,25 @@ def test_gemm_persistent_many_tiles(dtype, M, N, K, geglu, res):
     close(got, y.cpu(), dtype)
 
 
+@pytest.mark.parametrize("M,N,K,tile", [(128 * 13, 1920, 192, 2), (128 * 13 + 5, 2240, 128, 3), (256 * 5 + 37, 3584, 128, 4),
+                                        (256 * 9, 4096, 64, 0), (64 * 21 + 3, 1024, 64, 1)])
+def test_gemm_grouped_tile_order_covers_every_tile(M, N, K, tile):
+    """Wide outputs (more than 12 column tiles) walk the tiles in bands of 4 / 8 tile rows, m fastest inside a band
+    (gemm_impl.h tile_mn); the last band is short when the tile rows do not divide - every output element must still be written
+    exactly once (a poisoned output buffer would show through), for every tile shape, and with the order pinned both ways."""
+    o = ops()
+    dtype = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(7)
+    a = q(torch.randn(M, K, generator=g), dtype).to(DEV)
+    w = q(torch.randn(N, K, generator=g) / math.sqrt(K), dtype).to(DEV)
+    y = (a.float() @ w.float().t()).cpu()
+    for code in (tile, tile + 16 * 1, tile + 16 * 4, tile + 16 * 8):   # planned order, n fastest, bands of 4, bands of 8
+        out = torch.full((M, N), float("nan"), device=DEV, dtype=dtype)
+        o.gemm(a.to(dtype), w.to(dtype), None, out=out, tile=code, split_k=1)
+        assert bool(torch.isfinite(out).all()), f"tile code {code}: unwritten outputs"
+        close(out, y, dtype)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_asymmetric_identity(dtype):
     """A = I with an asymmetric W catches a transposed C-write (guide: always A=I-check with asymmetric B)."""
