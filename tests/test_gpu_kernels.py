@@ -158,6 +158,23 @@ def test_gemm_grouped_tile_order_covers_every_tile(M, N, K, tile):
         close(out, y, dtype)
 
 
+@pytest.mark.parametrize("M,N,tile", [(98304, 320, 3), (98304, 320, 2), (3072, 5120, 2), (24576, 640, 0), (6144, 1280, 4)])
+def test_gemm_residual_passes_through_exactly_when_the_product_is_zero(M, N, tile):
+    """A = 0, no bias: the output must equal the residual BIT FOR BIT, on every element, with several tiles per persistent
+    block.  Regression for the staged epilogue's store path: a 16-byte buffer store whose data registers were overwritten by
+    the next chunk's unpack wrote `x << 16` patterns into the last tile of a pass for some lanes (gemm_impl.h epilogue_lds) -
+    far inside the bf16 tolerance of a value comparison for small |x|, so compared exactly here."""
+    o = ops()
+    dtype = torch.bfloat16
+    a = torch.zeros(M, 64, device=DEV, dtype=dtype)
+    w = torch.ones(N, 64, device=DEV, dtype=dtype)
+    r = (torch.arange(M, device=DEV)[:, None] % 251 + (torch.arange(N, device=DEV)[None, :] // 8) * 0.5).to(dtype)
+    for _ in range(2):
+        out = torch.full((M, N), 777.0, device=DEV, dtype=dtype)
+        o.gemm(a, w, None, residual=r, out=out, tile=tile, split_k=1)
+        assert torch.equal(out, r)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_asymmetric_identity(dtype):
     """A = I with an asymmetric W catches a transposed C-write (guide: always A=I-check with asymmetric B)."""
