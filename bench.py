@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """bench.py - denoised frames/s of the Emote-hack diffusion hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W [--mode weak|strong]
+        N>1: one rank per GPU over RCCL - either launched by torch.distributed.run (RANK / WORLD_SIZE in the environment), or,
+        when WORLD_SIZE is not set, bench.py re-executes ITSELF under `python -m torch.distributed.run --nnodes=1
+        --nproc-per-node N --master-addr 127.0.0.1` (the reference spawns one process per GPU the same way,
+        magicanimate/pipelines/animation.py:246-269); rank 0 prints the one JSON line.
+        --mode strong = BASELINE configs[3]: ONE 48-frame clip (4 windows x 2 CFG branches = 8 units) whatever N is -
+        one unit per rank at N = 8, two at N = 4, all eight on one GPU at N = 1.
 
 Workload (BASELINE.json configs[1], "cfg2"): 512x512 -> latent 64x64, 12-frame window, 50-step DDPM,
 classifier-free guidance 7.5 (uncond + cond branch batched), ReferenceNet on (midup banks), AnimateDiff motion
@@ -105,34 +111,68 @@ def cpu_baseline(unet, ref):
             "cfg1_seconds_per_forward": t_cfg1, "cfg1": "BASELINE configs[0]: (1,4,1,32,32), t=981, ctx 77x768, no motion module, full forward"}
 
 
-def pmc_traffic(family):
-    """HBM bytes per launch of the kernel family from the LATEST committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
-    collected in separate runs of this same command, FETCH x2 gfx950 correction) - profiles/r*_pmc.json.  PMC counters
-    cannot be read from inside the process: the figure is tagged with the profile (round) it came from, or null."""
+def _profile_of_this_build(pattern):
+    """The committed counter profile (profiles/<pattern>) taken on THE RUNNING BUILD: tools/pmc_to_json.py stamps every
+    profile with the sha256 of the kernel sources (emote_hack_amd.build.csrc_digest); a profile of another build (or an
+    unstamped one from an earlier round) is NOT attached - a stale counter figure next to a fresh timing misleads."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
-    if not files:
+    from emote_hack_amd.build import csrc_digest
+    want = csrc_digest()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("csrc_sha256") == want:
+            return f, d
+    return None, None
+
+
+def pmc_traffic(family):
+    """HBM bytes per launch of the kernel family from the committed rocprofv3 PMC passes of THIS build (FETCH_SIZE / WRITE_SIZE
+    collected in separate runs of this same command, FETCH x2 gfx950 correction) - profiles/r*_pmc.json.  PMC counters
+    cannot be read from inside the process: the figure is tagged with the profile it came from; null when no committed
+    profile matches the running kernel sources."""
+    f, d = _profile_of_this_build("r*_pmc.json")
+    if d is None:
         return None
-    try:
-        d = json.load(open(files[-1]))["per_kernel_family"].get(family)
-        return {"hbm_bytes_per_launch": d["hbm_bytes_per_launch"], "source": os.path.relpath(files[-1], ROOT),
-                "note": "from the committed profile named in `source` (same command, earlier run), not from this run"} if d else None
-    except Exception:
-        return None
+    e = d.get("per_kernel_family", {}).get(family)
+    return {"hbm_bytes_per_launch": e["hbm_bytes_per_launch"], "source": os.path.relpath(f, ROOT), "csrc_sha256": d["csrc_sha256"][:16],
+            "note": "from the committed profile named in `source` (same command, same kernel sources, earlier run), not from this run"} if e else None
 
 
 def mfma_util_from_profiles():
-    """MFMA utilisation of the path from the committed SQ counter pass (profiles/r*_mfma.json, tools/pmc_to_json.py):
-    SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES-equivalent) - tagged with its source; null before the first pass."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma.json")))
-    if not files:
+    """MFMA utilisation of the path from the committed SQ counter pass of THIS build (profiles/r*_mfma.json,
+    tools/pmc_to_json.py): SQ_VALU_MFMA_BUSY_CYCLES over the dispatch cycles of all 1024 SIMDs - tagged with its source; null
+    when no committed profile matches the running kernel sources."""
+    f, d = _profile_of_this_build("r*_mfma.json")
+    if d is None:
         return None
-    try:
-        d = json.load(open(files[-1]))
-        return {"mfma_busy_frac": d["mfma_busy_frac"], "source": os.path.relpath(files[-1], ROOT)}
-    except Exception:
-        return None
+    return {"mfma_busy_frac": d["mfma_busy_frac"], "source": os.path.relpath(f, ROOT), "csrc_sha256": d["csrc_sha256"][:16]}
+
+
+def spawn_command(argv, n, port=None):
+    """The command bench.py re-executes itself as when --gpus N > 1 and no launcher set WORLD_SIZE: one rank per GPU under
+    torch.distributed.run on 127.0.0.1 (the container's hostname may not resolve)."""
+    import socket
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_check(rank, world):
+    """`--spawn-check`: prove the launch geometry without a GPU - every rank joins a gloo group and rank 0 prints the count."""
+    import torch.distributed as td
+    td.init_process_group("gloo")
+    t = torch.ones(1)
+    td.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"spawned_ranks": int(t.item()), "world_size": world}))
+    td.barrier()
+    td.destroy_process_group()
 
 
 def main():
@@ -146,13 +186,24 @@ def main():
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel from Python instead of replaying HIP graphs")
     ap.add_argument("--ref-group", type=int, default=REF_GROUP, help="ReferenceNet timesteps per batched pass")
     ap.add_argument("--no-ln-fold", action="store_true", help="A/B: explicit LayerNorm launches instead of the GEMM fold")
+    ap.add_argument("--mode", default="weak", choices=["weak", "strong"],
+                    help="weak: a 12-frame window per GPU (12*N frames); strong: BASELINE configs[3], one 48-frame clip = 8 units over N GPUs")
+    ap.add_argument("--spawn-check", action="store_true", help="only prove that N ranks start (gloo, no GPU needed)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the N ranks ourselves (replaces this process; the ranks inherit stdout, rank 0 prints the JSON line)
+        cmd = spawn_command(sys.argv[1:], a.gpus)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's hipIpc handles need it on this host driver
+        sys.stdout.flush()
+        os.execv(cmd[0], cmd)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world > 1:
+    if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} != WORLD_SIZE {world}")
+    if a.spawn_check:
+        return spawn_check(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -173,13 +224,15 @@ def main():
         unet_mod.FOLD_LAYERNORM = False
     unet, ref = build_models(dev, dtype)
     F_WIN = 12
-    f_tot = F_WIN * world
+    f_tot = F_WIN * world if a.mode == "weak" else 4 * F_WIN       # strong: BASELINE configs[3] - 48 frames = 4 windows
     pipe = EMOAnimationPipeline(unet=unet, scheduler=DDPMScheduler())
     st = pipe.prepare_denoise(seeded_randn((1, 4, f_tot, 64, 64), 1).to(dev), seeded_randn((1, 4, 64, 64), 3),
                               seeded_randn((2, 77, 768), 2), appearance_encoder=ref, num_inference_steps=NUM_INFERENCE_STEPS,
                               guidance_scale=7.5, context_frames=F_WIN, context_stride=1, context_overlap=0, seed=0,
                               dist=dist, rank=rank, world_size=world, use_graphs=not a.no_graphs, reference_group=a.ref_group)
-    assert len(st.windows) == world and len(st.units) == 2 * world and sum(len(c.units) for c in st.calls) == 2
+    n_win = world if a.mode == "weak" else 4
+    assert len(st.windows) == n_win and len(st.units) == 2 * n_win
+    assert sum(len(c.units) for c in st.calls) == (2 if a.mode == "weak" else len(st.units[rank::world]))
 
     def sync():
         torch.cuda.synchronize()
@@ -230,14 +283,18 @@ def main():
     if rank == 0:
         out = {
             "metric": "denoised frames/s (512x512, 50-step DDPM)", "value": fps, "unit": "frames/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": a.mode,
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "cfg2: 512x512 latents 64x64, 12-frame window per GPU, 50-step DDPM, CFG 7.5 (uc+c batched), "
+            "config": {"workload": ("cfg2: 512x512 latents 64x64, 12-frame window per GPU, 50-step DDPM, CFG 7.5 (uc+c batched), "
+                                    if a.mode == "weak" else
+                                    "cfg4 (BASELINE configs[3]): 512x512 latents 64x64, ONE 48-frame clip = 4 windows of 12 x 2 CFG branches "
+                                    f"= 8 units over {world} GPU(s), 50-step DDPM, CFG 7.5, ") +
                                    "ReferenceNet on (midup), motion modules res 1/2/4/8, ctx 77x768; 1 step = 1 loop iteration "
                                    f"+ 1/{st.T} of a {st.T}-timestep ReferenceNet pass",
                        "frames_total": f_tot, "num_inference_steps": NUM_INFERENCE_STEPS,
-                       "parallelism": f"(window x CFG-branch) units x{world}: rank r owns both branches of window r; all_gather of eps "
-                                      "slices per step, all_gather of ReferenceNet banks per group",
+                       "parallelism": (f"(window x CFG-branch) units x{world}: rank r owns both branches of window r; " if a.mode == "weak" else
+                                       f"8 (window x CFG-branch) units dealt U[r::{world}] ({len(st.units[rank::world])} per rank); ") +
+                                      "all_gather of eps slices per step, all_gather of ReferenceNet banks per group",
                        "latents_finite": finite, "host_enqueue_ms_per_step": host_s / a.steps * 1e3,
                        "hip_graphs": not a.no_graphs, "reference_group": st.T,
                        "reference_passes_in_timed_region": ref_passes,
@@ -247,8 +304,8 @@ def main():
         # runs the ReferenceNet on [uncond-text, cond-text] copies of the image (2 x 0.803 TFLOP); the uncond copy's features
         # are never read (mutual_self_attention.py:243-256 overwrites the uc rows) and everything behind the last bank write
         # is dead, so this path computes less.  The achieved rate is priced on the SURVEY figure for the cond copy only.
-        tflop_ref = world * (TFLOP_COND + TFLOP_UNCOND) + 2 * TFLOP_REFNET
-        tflop_step = world * (TFLOP_COND + TFLOP_UNCOND) + 1 * TFLOP_REFNET
+        tflop_ref = n_win * (TFLOP_COND + TFLOP_UNCOND) + 2 * TFLOP_REFNET
+        tflop_step = n_win * (TFLOP_COND + TFLOP_UNCOND) + 1 * TFLOP_REFNET
         out["config"]["algorithmic_tflop_per_step_reference"] = tflop_ref
         out["config"]["algorithmic_tflop_per_step"] = tflop_step
         out["config"]["achieved_tflops_whole_path"] = tflop_step / (dt_s / a.steps) / world

@@ -21,6 +21,18 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-Wno-unused-variable", "-Wno-pass-failed"]
 
 
+def csrc_digest() -> str:
+    """sha256 over the kernel sources + the C header: names the BUILD a profile was taken on (tools/pmc_to_json.py stamps it into
+    profiles/r*_pmc.json / r*_mfma.json; bench.py attaches counter figures only from a profile of the running build)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    for f in files + [os.path.join(os.path.dirname(HERE), "include", "emo_hip.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def _newer(a, b):
     return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
 

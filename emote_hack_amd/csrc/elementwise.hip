@@ -240,8 +240,11 @@ __global__ __launch_bounds__(256) void cfg_step_kernel(const float* __restrict__
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     int f = (int)((i / HW) % F);
     float inv = 1.0f / counter[f];
-    float uc = np[i] * inv, cc = np[n + i] * inv;   // noise_pred / counter (EMOAnimationPipeline.py:813)
-    float eps = uc + gs * (cc - uc);                // :814
+    float eps = np[i] * inv;                        // noise_pred / counter (EMOAnimationPipeline.py:813)
+    if (gs > 1.0f) {                                // do_classifier_free_guidance = guidance_scale > 1.0 (:622); else np is [1][n]
+      const float cc = np[n + i] * inv;
+      eps = eps + gs * (cc - eps);                  // :814
+    }
     float x = c_x * lat[i] + c_eps * eps;
     if (c_n != 0.f) {
       uint32_t h1 = mix32(((uint32_t)i * 2u + 0u) ^ key), h2 = mix32(((uint32_t)i * 2u + 1u) ^ key);

@@ -55,6 +55,7 @@ class EMOAnimationPipeline:
             scheduler.config.clip_sample = False
         self.vae_scale_factor = 8
         self.device = unet.device
+        self._bank_pg = {}     # world_size -> the ReferenceNet-bank communicator (created once: td.new_group is a collective + leaks)
 
     @property
     def _execution_device(self):
@@ -83,22 +84,32 @@ class EMOAnimationPipeline:
         reference image and their LN1 features join the banks as extra tokens (see denoise_chained)."""
         unet, sch = self.unet, self.scheduler
         dev = unet.device
-        if not guidance_scale > 1.0:
-            raise NotImplementedError("guidance_scale <= 1 (no CFG) is not on the benchmarked path")
+        # `do_classifier_free_guidance = guidance_scale > 1.0` (:622).  Without it the UNet batch is the window batch (:759-763
+        # `.repeat(1)`), the text is the cond embedding alone, every row reads the bank and eps = noise_pred / counter.  (The
+        # reference's own lines do not run in that mode: `pred_uc, pred_c = pred.chunk(2)` (:790) unpacks a one-row batch, and its
+        # reader is built with do_classifier_free_guidance=True (:634), which would mask half of the FRAMES off the bank; this
+        # follows the evident intent, pinned by the `ddim_nocfg` loop golden.)
+        cfg = bool(guidance_scale > 1.0)
         if latents.shape[0] != 1:
             raise ValueError("batch_size must be 1 (EMOAnimationPipeline.py:641-642); run clips as separate calls")
-        if text_embeddings.shape[0] != 2:
-            raise ValueError("text_embeddings must be (2, L, D) = [uncond, cond] (:631)")
+        if text_embeddings.shape[0] == 2 and not cfg:
+            text_embeddings = text_embeddings[1:]          # [uncond, cond] handed over anyway: the cond row is the prompt
+        if text_embeddings.shape[0] != (2 if cfg else 1):
+            raise ValueError("text_embeddings must be (2, L, D) = [uncond, cond] (:631), or (1, L, D) = [cond] without guidance")
         st = SimpleNamespace()
-        st.cbs = cbs = context_batch_size
+        st.cfg = cfg
+        st.cbs = cbs = int(context_batch_size)
+        if cbs < 1:
+            raise ValueError("context_batch_size must be >= 1")
         st.latents = latents.to(dev).float().contiguous()
         _, st.C4, st.f_tot, st.h, st.w = st.latents.shape
         st.HW = st.h * st.w
-        st.text = text_embeddings.to(dev).float()
+        # text rows indexed by VARIANT: 0 = uncond, 1 = cond (without guidance both name the cond row)
+        st.text = text_embeddings.to(dev).float() if cfg else text_embeddings.to(dev).float().expand(2, -1, -1).contiguous()
         st.appearance_encoder = appearance_encoder
         st.writer = ReferenceAttentionControl(appearance_encoder, do_classifier_free_guidance=True, mode="write",
                                               batch_size=cbs, fusion_blocks=fusion_blocks)      # :633
-        st.reader = ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", batch_size=cbs,
+        st.reader = ReferenceAttentionControl(unet, do_classifier_free_guidance=cfg, mode="read", batch_size=cbs,
                                               fusion_blocks=fusion_blocks)                        # :634
         st.num_inference_steps = num_inference_steps
         st.timesteps = sch.set_timesteps(num_inference_steps)
@@ -134,17 +145,37 @@ class EMOAnimationPipeline:
         st.rank, st.world_size = (int(rank), int(world_size)) if st.dist else (0, 1)
         # (branch-major order: with as many windows as ranks a rank owns BOTH branches of one window - balanced, the cond
         # branch costs ~8 % more - and with twice as many ranks as windows, BASELINE configs[3], every rank owns one unit)
-        st.units = [(w, br) for br in (0, 1) for w in range(len(st.windows))]
+        st.branches = (0, 1) if cfg else (1,)
+        st.np_slot = {br: i for i, br in enumerate(st.branches)}           # branch -> plane of the noise_pred accumulator
+        st.units = [(w, br) for br in st.branches for w in range(len(st.windows))]
+        # Text / bank VARIANT of a unit.  The reference stacks `torch.cat([text_embeddings] * context_batch_size)` (:631) =
+        # [uc, c, uc, c, ..] against latent rows [w0, w1, .., w0, w1, ..] (:759-763) and a uc mask [1, .., 0, ..]
+        # (mutual_self_attention.py:186-197): row r = branch * n + j of a batch of n windows is paired with text row r % 2, and a
+        # cond row reads bank row r - written by the ReferenceNet under text row r % 2 as well (:711-716).  At
+        # context_batch_size 1 that is variant = branch; at context_batch_size > 1 it is NOT (window 0's cond row runs under the
+        # uncond text and the uncond-text bank) - reference behaviour, reproduced (golden `ddim_cbs2`).
+        st.unit_tv = {}
+        pos = 0
+        for wb in st.global_context:
+            n = len(wb)
+            for j in range(n):
+                for br in st.branches:
+                    st.unit_tv[(pos + j, br)] = ((br * n + j) % 2) if cfg else 1
+            pos += n
+        st.bank_variants = sorted({st.unit_tv[u] for u in st.units if u[1] == 1})   # the same on every rank
         mine = st.units[st.rank::st.world_size]
         st.n_slots = -(-len(st.units) // st.world_size)                    # units per rank, padded
         st.calls = []
-        for i in range(0, len(mine), 2 * cbs):
-            chunk = mine[i:i + 2 * cbs]
-            order = [k for k, u in enumerate(chunk) if u[1] == 0] + [k for k, u in enumerate(chunk) if u[1] == 1]
-            call = SimpleNamespace(units=[chunk[k] for k in order], slots=[i + k for k in order])
-            call.n_uc = sum(1 for u in call.units if u[1] == 0)
-            call.idx = [torch.tensor(st.windows[w], dtype=torch.int64, device=dev) for w, _ in call.units]
-            st.calls.append(call)
+        for i in range(0, len(mine), len(st.branches) * cbs):
+            chunk = mine[i:i + len(st.branches) * cbs]
+            uc = [k for k, u in enumerate(chunk) if u[1] == 0]
+            # one UNet call reads ONE bank (the row named by a device word): cond units are batched per bank variant
+            for n_call, tv in enumerate(sorted({st.unit_tv[u] for u in chunk if u[1] == 1}, reverse=True) or [None]):
+                order = (uc if n_call == 0 else []) + [k for k, u in enumerate(chunk) if u[1] == 1 and st.unit_tv[u] == tv]
+                call = SimpleNamespace(units=[chunk[k] for k in order], slots=[i + k for k in order], bank_tv=tv)
+                call.n_uc = sum(1 for u in call.units if u[1] == 0)
+                call.idx = [torch.tensor(st.windows[w], dtype=torch.int64, device=dev) for w, _ in call.units]
+                st.calls.append(call)
         st.t_table = torch.tensor(st.timesteps, dtype=torch.int64, device=dev)   # INT timestep table, bit-exact
         st.t_buf = torch.zeros(1, dtype=torch.int64, device=dev)
         st.use_graphs, st.graphs = bool(use_graphs), {}
@@ -163,7 +194,7 @@ class EMOAnimationPipeline:
                 raise ValueError("speed_embeddings must have 1 row (shared) or 2 rows [uncond, cond]")
         for call in st.calls:
             if audio_features is None:
-                call.ctx = torch.cat([st.text[br:br + 1] for _, br in call.units])                       # (n, L, D)
+                call.ctx = torch.cat([st.text[st.unit_tv[u]:st.unit_tv[u] + 1] for u in call.units])    # (n, L, D)
             else:   # per-frame audio context; uncond units get a zero context (design choice)
                 parts = []
                 for (w, br), ix in zip(call.units, call.idx):
@@ -174,29 +205,36 @@ class EMOAnimationPipeline:
             call.speed = None if se is None else torch.cat([se[(br if se.shape[0] == 2 else 0):(br if se.shape[0] == 2 else 0) + 1]
                                                             for _, br in call.units])
         st.text_c = st.text[1:2]
-        st.ref_ctx_kv = appearance_encoder.context_kv(st.text_c)
+        st.ref_ctx_kv = {tv: appearance_encoder.context_kv(st.text[tv:tv + 1]) for tv in st.bank_variants}
         # ---- eps hand-off: every unit's rows (nf*HW, C4); slot = position in the rank's unit list
         st.send = torch.zeros(st.n_slots, nf * st.HW, st.C4, device=dev, dtype=unet.dtype)
         st.recv = torch.zeros(st.world_size, st.n_slots, nf * st.HW, st.C4, device=dev, dtype=unet.dtype) if st.dist else None
-        st.noise_pred = torch.empty(2, st.C4, st.f_tot, st.HW, device=dev, dtype=torch.float32)
+        st.noise_pred = torch.empty(len(st.branches), st.C4, st.f_tot, st.HW, device=dev, dtype=torch.float32)
         st.counter = torch.empty(st.f_tot, device=dev, dtype=torch.float32)
         st.guidance_scale, st.eta, st.seed = guidance_scale, eta, seed
         st.return_eps, st.eps_trace = return_eps, []
         # ---- ReferenceNet groups: the banks depend on the timestep only (never on the latents): T timesteps per pass
         T = max(1, min(int(reference_group), n_steps))
+        if st.dist and st.world_size > 1:
+            # the ranks deal a group's timesteps among themselves: a group size that is not a multiple of world_size pads every
+            # rank to ceil(T / world) timesteps (10 over 8 ranks: 16 computed and shipped, 10 used) - round T up instead
+            T = min(-(-T // st.world_size) * st.world_size, n_steps)
         st.T = T
         st.groups = [list(range(i, min(i + T, n_steps))) for i in range(0, n_steps, T)]
         st.ref_t = torch.zeros(T, dtype=torch.int64, device=dev)
         st.row_table = torch.tensor([((s_ // T) % 2) * T + s_ % T for s_ in range(n_steps)], dtype=torch.int32, device=dev)
         st.bank_idx = torch.zeros(1, dtype=torch.int32, device=dev)
-        st.kv_all, st.group_ready, st.group_pending, st.groups_launched = None, -1, -1, 0
+        st.kv_all, st.group_ready, st.group_pending, st.groups_launched = {}, -1, -1, 0
         st.ref_sel, st.ref_recv, st.ref_gath, st.bank_pg = {}, {}, {}, None
+        st.bank_pack, st.stage = {}, {}
         spec_r = appearance_encoder.spec
         chan = {a.prefix: a.channels for blk in spec_r.down + [spec_r.mid] + spec_r.up for a in blk.attentions if a is not None}
         st.bank_C = [chan[p] for p in st.writer.order]
         if st.dist and st.world_size > 1:
             import torch.distributed as td
-            st.bank_pg = td.new_group(ranks=list(range(st.world_size)))
+            if st.world_size not in self._bank_pg:   # once per pipeline (denoise_chained prepares per clip; new_group leaks a communicator)
+                self._bank_pg[st.world_size] = td.new_group(ranks=list(range(st.world_size)))
+            st.bank_pg = self._bank_pg[st.world_size]
         st.lookahead = bool(reference_lookahead) and dev.type == "cuda"
         st.side = torch.cuda.Stream() if st.lookahead else None
         # ControlNet branch (EMOAnimationPipeline.py:643-650,678-679,718-746): (F_tot,3,H,W) conditioning images in [0,1]
@@ -227,12 +265,13 @@ class EMOAnimationPipeline:
             st.ref_sel[Tg] = torch.tensor(mine, dtype=torch.int64, device=st.ref_t.device)
         return st.ref_sel[Tg]
 
-    def _part_reference_write(self, st, Tg):
-        """ReferenceNet write pass (:711-716) on the cond-text copy of the reference image for this rank's share of the group's
+    def _part_reference_write(self, st, Tg, tv):
+        """ReferenceNet write pass (:711-716) under text variant tv (1 = the cond text) for this rank's share of the group's
         timesteps, batched: (n,4,h,w) with one timestep per row.  The reference runs [uncond-text, cond-text] copies every
-        step, but the reader never uses the uncond bank row (for the uc rows `hidden_states_c` is overwritten by the bank-free
-        uc attention, mutual_self_attention.py:243-256) and the ReferenceNet is batch-independent.  Banks are rounded through
-        fp16 like reader.update() does (:588) and packed for the exchange."""
+        step, but at context_batch_size 1 the reader never uses the uncond bank row (for the uc rows `hidden_states_c` is
+        overwritten by the bank-free uc attention, mutual_self_attention.py:243-256) and the ReferenceNet is batch-independent:
+        only the variants some cond unit reads (st.bank_variants) are computed.  Banks are rounded through fp16 like
+        reader.update() does (:588) and packed for the exchange."""
         t = st.ref_t[:Tg] if st.world_size == 1 else st.ref_t.index_select(0, self._ref_sel(st, Tg))
         n, k = t.numel(), st.n_ref_images
         st.writer.clear()
@@ -241,26 +280,26 @@ class EMOAnimationPipeline:
         # entries along tokens the same way, mutual_self_attention.py:239)
         imgs = st.ref_lat.expand(n, -1, -1, -1) if k == 1 else st.ref_lat.repeat(n, 1, 1, 1)
         tt = t if k == 1 else t.repeat_interleave(k)
-        st.appearance_encoder(imgs, tt, encoder_hidden_states=st.text_c, return_dict=False, _ctx_kv=st.ref_ctx_kv)
+        st.appearance_encoder(imgs, tt, encoder_hidden_states=st.text[tv:tv + 1], return_dict=False, _ctx_kv=st.ref_ctx_kv[tv])
         tgt = self.unet.dtype
         st.bank_L = [k * st.writer.bank[p][0].shape[1] for p in st.writer.order]
         banks = [ops.convert(st.writer.bank[p][0], tgt, fp16_round=True).reshape(n, -1) for p in st.writer.order]
         st.writer.clear()                                                                      # :823
-        st.bank_pack = banks if st.world_size == 1 else torch.cat(banks, dim=1)                # (n, total) plumbing copy
+        st.bank_pack[tv] = banks if st.world_size == 1 else torch.cat(banks, dim=1)            # (n, total) plumbing copy
 
-    def _part_reference_project(self, st, Tg):
+    def _part_reference_project(self, st, Tg, tv):
         """K / V^T projections of the group's banks with the BACKBONE's attn1.to_k / to_v (the read side of
         mutual_self_attention.py:238-241), once per group instead of once per step."""
-        st.stage = {}
+        st.stage[tv] = {}
         off = 0
         for i, (pr, L, C_) in enumerate(zip(st.reader.order, st.bank_L, st.bank_C)):
             if st.world_size == 1:
-                rows = st.bank_pack[i]
+                rows = st.bank_pack[tv][i]
             else:   # bank i occupies columns [off, off + L*C) of every gathered row (rows in group order)
-                rows = st.ref_gath[Tg][:Tg, off:off + L * C_].contiguous()
+                rows = st.ref_gath[(Tg, tv)][:Tg, off:off + L * C_].contiguous()
                 off += L * C_
             k, vt = self.unet.bank_kv(pr, rows.reshape(-1, C_), L)
-            st.stage[pr] = (k, vt, L)
+            st.stage[tv][pr] = (k, vt, L)
 
     def _reference_group(self, st, g):
         """Compute group g's projected banks on the CURRENT stream and store them in slot g % 2 of the resident cache."""
@@ -268,32 +307,33 @@ class EMOAnimationPipeline:
         Tg, T, slot = len(steps), st.T, g % 2
         st.groups_launched += 1
         st.ref_t[:Tg].copy_(st.t_table[steps[0]:steps[0] + Tg], non_blocking=True)
-        self._run(st, ("ref_write", Tg), lambda: self._part_reference_write(st, Tg), pool=st.writer_pool)
-        if st.world_size > 1:
-            # north_star: "RCCL all-gather over xGMI to broadcast ReferenceNet features" - rank r computed timesteps
-            # r, r+world, ... of the group; ONE all_gather hands every rank every timestep's banks (own communicator: the
-            # exchange rides the side stream and must not queue in front of the per-step eps all_gather)
-            import torch.distributed as td
-            send = st.bank_pack
-            n = send.shape[0]
-            if Tg not in st.ref_gath:
-                st.ref_recv[Tg] = torch.empty(st.world_size * n, send.shape[1], device=send.device, dtype=send.dtype)
-                st.ref_gath[Tg] = torch.empty(st.world_size * n, send.shape[1], device=send.device, dtype=send.dtype)
-            td.all_gather_into_tensor(st.ref_recv[Tg].view(-1), send.contiguous().view(-1), group=st.bank_pg)
-            # row (rank r, slot i) is group-local timestep i*world + r -> group order
-            st.ref_gath[Tg].view(n, st.world_size, -1).copy_(st.ref_recv[Tg].view(st.world_size, n, -1).transpose(0, 1))
-        self._run(st, ("ref_project", Tg), lambda: self._part_reference_project(st, Tg), pool=st.writer_pool)
-        if st.kv_all is None:   # resident cache: two groups of T timesteps per block
-            st.kv_all = {}
-            for pr, (k, vt, L) in st.stage.items():
-                st.kv_all[pr] = (torch.zeros(2 * T * L, k.shape[1], device=k.device, dtype=k.dtype),
-                                 torch.zeros(2 * T, vt.shape[1], vt.shape[2], device=vt.device, dtype=vt.dtype), L)
-        dsts, srcs = [], []
-        for pr, (k, vt, L) in st.stage.items():
-            ka, va, _ = st.kv_all[pr]
-            dsts += [ka[slot * T * L:slot * T * L + Tg * L], va[slot * T:slot * T + Tg]]
-            srcs += [k[:Tg * L], vt[:Tg]]
-        torch._foreach_copy_(dsts, srcs)
+        for tv in st.bank_variants:
+            self._run(st, ("ref_write", Tg, tv), lambda tv=tv: self._part_reference_write(st, Tg, tv), pool=st.writer_pool)
+            if st.world_size > 1:
+                # north_star: "RCCL all-gather over xGMI to broadcast ReferenceNet features" - rank r computed timesteps
+                # r, r+world, ... of the group; ONE all_gather hands every rank every timestep's banks (own communicator: the
+                # exchange rides the side stream and must not queue in front of the per-step eps all_gather)
+                import torch.distributed as td
+                send = st.bank_pack[tv]
+                n = send.shape[0]
+                if (Tg, tv) not in st.ref_gath:
+                    st.ref_recv[(Tg, tv)] = torch.empty(st.world_size * n, send.shape[1], device=send.device, dtype=send.dtype)
+                    st.ref_gath[(Tg, tv)] = torch.empty(st.world_size * n, send.shape[1], device=send.device, dtype=send.dtype)
+                td.all_gather_into_tensor(st.ref_recv[(Tg, tv)].view(-1), send.contiguous().view(-1), group=st.bank_pg)
+                # row (rank r, slot i) is group-local timestep i*world + r -> group order
+                st.ref_gath[(Tg, tv)].view(n, st.world_size, -1).copy_(st.ref_recv[(Tg, tv)].view(st.world_size, n, -1).transpose(0, 1))
+            self._run(st, ("ref_project", Tg, tv), lambda tv=tv: self._part_reference_project(st, Tg, tv), pool=st.writer_pool)
+            if tv not in st.kv_all:   # resident cache: two groups of T timesteps per block
+                st.kv_all[tv] = {}
+                for pr, (k, vt, L) in st.stage[tv].items():
+                    st.kv_all[tv][pr] = (torch.zeros(2 * T * L, k.shape[1], device=k.device, dtype=k.dtype),
+                                         torch.zeros(2 * T, vt.shape[1], vt.shape[2], device=vt.device, dtype=vt.dtype), L)
+            dsts, srcs = [], []
+            for pr, (k, vt, L) in st.stage[tv].items():
+                ka, va, _ = st.kv_all[tv][pr]
+                dsts += [ka[slot * T * L:slot * T * L + Tg * L], va[slot * T:slot * T + Tg]]
+                srcs += [k[:Tg * L], vt[:Tg]]
+            torch._foreach_copy_(dsts, srcs)
 
     def _ensure_group(self, st, si):
         """Group of step si resident (waiting for / computing it if needed), the NEXT group launched on the side stream."""
@@ -343,7 +383,9 @@ class EMOAnimationPipeline:
         call = st.calls[ci]
         x = torch.cat([st.latents.index_select(2, ix) for ix in call.idx])                     # :759-763 (index/copy only)
         x = self.scheduler.scale_model_input(x, None)
-        st.reader.set_projected_banks(st.kv_all, st.bank_idx, call.n_uc)                       # replaces reader.update (:774)
+        # (a call of uncond units only names any resident cache: every one of its batches skips the bank segment)
+        bank_tv = call.bank_tv if call.bank_tv is not None else st.bank_variants[0]
+        st.reader.set_projected_banks(st.kv_all[bank_tv], st.bank_idx, call.n_uc)               # replaces reader.update (:774)
         rows = self.unet(x, st.t_buf, encoder_hidden_states=call.ctx, speed_embeddings=call.speed, return_dict=False,
                          _return_rows=True, _ctx_kv=call.ctx_kv, **self._controlnet_residuals(st, call))   # :777-786
         n_rows = st.nf * st.HW
@@ -355,8 +397,8 @@ class EMOAnimationPipeline:
         redundantly on the gathered rows, so the accumulators (and the latents) are bit-identical on all ranks."""
         for i, (w, br) in enumerate(st.units):
             rows = st.send[i] if not st.dist else st.recv[i % st.world_size, i // st.world_size]
-            ops.accumulate_window(rows, st.noise_pred[br], st.counter, st.frame_idx[w], C_=st.C4, F=st.f_tot, HW=st.HW,
-                                  add_counter=(br == 0))
+            ops.accumulate_window(rows, st.noise_pred[st.np_slot[br]], st.counter, st.frame_idx[w], C_=st.C4, F=st.f_tot, HW=st.HW,
+                                  add_counter=(br == st.branches[0]))
 
     def _run(self, st, key, fn, pool=None):
         """Eager on first use (warm-up: lazy kernel attributes, allocator), HIP-graph capture on the second, replay after.
@@ -404,11 +446,7 @@ class EMOAnimationPipeline:
         if st.return_eps:
             st.eps_trace.append(eps_out.view(1, st.C4, st.f_tot, st.h, st.w))
 
-    @torch.no_grad()
-    def denoise(self, latents, ref_image_latents, text_embeddings, *, num_actual_inference_steps=None, callback=None,
-                callback_steps=1, **kw):
-        """The whole loop; returns the denoised latents f32 (1,4,F_tot,h,w) (and the eps trace if asked)."""
-        st = self.prepare_denoise(latents, ref_image_latents, text_embeddings, **kw)
+    def _run_loop(self, st, num_actual_inference_steps=None, callback=None, callback_steps=1):
         n = st.num_inference_steps
         for si, t in enumerate(st.timesteps):
             if num_actual_inference_steps is not None and si < n - num_actual_inference_steps:   # :699-700
@@ -419,6 +457,34 @@ class EMOAnimationPipeline:
         return (st.latents, st.eps_trace) if st.return_eps else st.latents
 
     @torch.no_grad()
+    def denoise(self, latents, ref_image_latents, text_embeddings, *, num_actual_inference_steps=None, callback=None,
+                callback_steps=1, **kw):
+        """The whole loop; returns the denoised latents f32 (1,4,F_tot,h,w) (and the eps trace if asked)."""
+        st = self.prepare_denoise(latents, ref_image_latents, text_embeddings, **kw)
+        return self._run_loop(st, num_actual_inference_steps, callback, callback_steps)
+
+    def reset_denoise(self, st, latents, motion_latents=None):
+        """Re-arm a prepared loop state for another clip of the SAME geometry: new noisy latents (and motion frames) are copied
+        IN PLACE, so the captured HIP graphs, the resident bank cache, the context K / V^T and the communicators are reused -
+        only the ReferenceNet groups are recomputed (the motion frames enter them)."""
+        if tuple(latents.shape) != tuple(st.latents.shape):
+            raise ValueError(f"reset_denoise: latents {tuple(latents.shape)} != prepared {tuple(st.latents.shape)}")
+        st.latents.copy_(latents.to(st.latents.device).float())
+        if motion_latents is not None:
+            ml = motion_latents.to(st.latents.device).float()
+            if ml.dim() == 5:
+                ml = ml[0].permute(1, 0, 2, 3)
+            if ml.shape[0] != st.n_ref_images - 1 or tuple(ml.shape[1:]) != (st.C4, st.h, st.w):
+                raise ValueError(f"reset_denoise: motion_latents must be ({st.n_ref_images - 1}, {st.C4}, {st.h}, {st.w}), got {tuple(ml.shape)}")
+            st.ref_lat[1:].copy_(ml)
+        elif st.n_ref_images != 1:
+            raise ValueError("reset_denoise: the state was prepared with motion frames")
+        if st.side is not None:   # nothing of the previous clip may still be writing the bank cache
+            torch.cuda.current_stream().wait_stream(st.side)
+        st.group_ready, st.group_pending, st.eps_trace = -1, -1, []
+        return st
+
+    @torch.no_grad()
     def denoise_chained(self, clips, ref_image_latents, text_embeddings, *, n_motion_frames=4, **kw):
         """Long-video generation by clip chaining (intent of Net.py:56-72 `pre_extract_motion_features` and
         junk/EMo-write-up.txt:104-110 - the reference never wires it): clip k+1 is denoised with the LAST n_motion_frames
@@ -426,18 +492,56 @@ class EMOAnimationPipeline:
         the ReferenceNet together with the reference image at every timestep and their LN1 features are appended to the
         reference banks as extra tokens, i.e. every spatial self-attention of the Backbone's mid / up path also attends to
         the previous clip's tail (same bank mechanism, Lk1 = (1 + n_motion_frames) * L).  `clips`: list of noisy latents
-        (1, 4, F, h, w).  Returns the list of denoised latents.  Design choice - no reference behaviour to match."""
-        out, prev = [], None
+        (1, 4, F, h, w), each with F >= n_motion_frames.  Clips of one geometry share ONE prepared state (graphs, bank cache,
+        context K/V); a clip of another shape prepares afresh.  Returns the list of denoised latents.  Design choice - no
+        reference behaviour to match."""
+        out, prev, st = [], None, None
+        run_kw = {k: kw.pop(k) for k in ("num_actual_inference_steps", "callback", "callback_steps") if k in kw}
         for lat in clips:
+            _, c4, f, h, w = lat.shape
             if n_motion_frames > 0:
-                _, c4, f, h, w = lat.shape
+                if f < n_motion_frames:
+                    raise ValueError(f"denoise_chained: a clip of {f} frames cannot hand over {n_motion_frames} motion frames")
                 motion = torch.zeros(n_motion_frames, c4, h, w) if prev is None else prev[0, :, -n_motion_frames:].permute(1, 0, 2, 3)
+                if motion.shape[0] != n_motion_frames or tuple(motion.shape[2:]) != (h, w):
+                    raise ValueError("denoise_chained: consecutive clips must share the latent size")
             else:
                 motion = None
-            res = self.denoise(lat, ref_image_latents, text_embeddings, motion_latents=motion, **kw)
-            prev = res[0] if isinstance(res, tuple) else res
+            if st is not None and tuple(st.latents.shape) == tuple(lat.shape):
+                self.reset_denoise(st, lat, motion)
+            else:
+                st = self.prepare_denoise(lat, ref_image_latents, text_embeddings, motion_latents=motion, **kw)
+            res = self._run_loop(st, **run_kw)
+            prev = (res[0] if isinstance(res, tuple) else res).clone()   # (the state's latents are overwritten by the next clip)
             out.append(prev)
         return out
+
+    @torch.no_grad()
+    def images2latents(self, images, dtype=None):
+        """EMOAnimationPipeline.py:402-414: uint8 RGB frames (f, h, w, c) -> `/ 127.5 - 1`, 'f h w c -> f c h w',
+        `vae.encode(frame)['latent_dist'].mean * 0.18215`, frame by frame."""
+        if self.vae is None:
+            raise ValueError("images2latents needs a VAE (emote_hack_amd.vae.AutoencoderKL)")
+        import numpy as np
+        x = torch.from_numpy(np.ascontiguousarray(images)) if isinstance(images, np.ndarray) else torch.as_tensor(images)
+        if x.dim() != 4 or x.shape[-1] != 3:
+            raise ValueError(f"images2latents: expected (f, h, w, 3) RGB frames, got {tuple(x.shape)}")
+        x = (x.float() / 127.5 - 1.0).permute(0, 3, 1, 2).contiguous()
+        return torch.cat([self.vae.encode(x[i:i + 1])["latent_dist"].mean * 0.18215 for i in range(x.shape[0])])
+
+    def _source_image_latents(self, source_image, width, height):
+        """:686-689: a path is opened and resized to (width, height); an (H, W, 3) uint8 array is taken as it is."""
+        import numpy as np
+        if isinstance(source_image, str):
+            from PIL import Image
+            source_image = np.array(Image.open(source_image).convert("RGB").resize((width, height)))
+        elif torch.is_tensor(source_image):
+            source_image = source_image.detach().cpu().numpy()
+        if not isinstance(source_image, np.ndarray) or source_image.ndim != 3 or source_image.shape[-1] != 3:
+            raise ValueError("source_image must be a file path or an (H, W, 3) uint8 RGB array (EMOAnimationPipeline.py:686-689)")
+        if source_image.shape[0] % 8 or source_image.shape[1] % 8:
+            raise ValueError(f"source_image {source_image.shape[:2]} must be a multiple of 8 in both directions")
+        return self.images2latents(source_image[None], None)
 
     # ------------------------------------------------------------------ reference-compatible entry point
     @torch.no_grad()
@@ -482,7 +586,7 @@ class EMOAnimationPipeline:
         if ref_lat is None:
             if self.vae is None or source_image is None:
                 raise ValueError("pass ref_image_latents=(1,4,h,w) (no VAE in this build)")
-            ref_lat = self.vae.encode(source_image).latent_dist.mean * 0.18215   # :402-414
+            ref_lat = self._source_image_latents(source_image, width, height)   # :686-689 -> images2latents (:402-414)
         if audio is not None and kwargs.get("audio_features") is None:
             raise NotImplementedError("wav2vec feature extraction is out of scope: pass audio_features=")
         if head_rotation_speeds is not None and kwargs.get("speed_embeddings") is None:

@@ -59,6 +59,9 @@ class DiagonalGaussianDistribution:
 class AutoencoderKLOutput:
     latent_dist: DiagonalGaussianDistribution
 
+    def __getitem__(self, k):   # diffusers BaseOutput: the reference reads `vae.encode(x)['latent_dist']` (EMOAnimationPipeline.py:411)
+        return self.latent_dist if k in ("latent_dist", 0) else getattr(self, k)
+
 
 def _round_up(x, m):
     return (x + m - 1) // m * m
@@ -239,18 +242,20 @@ class AutoencoderKL:
         w = self._w
         C_ = x.shape[1]
         h = self._gn(p + ".group_norm", x, n_img, False)
-        q = ops.gemm(h, w[p + ".to_q.weight"], w[p + ".to_q.bias"])
+        # q leaves its projection already SCALED by 1/sqrt(C): unscaled Q.K^T over 512 channels overflows fp16 (the known SD-VAE
+        # inf -> NaN) and costs bf16 ~22x the absolute precision of the logits; scaling q keeps every stored tensor in range
+        scale = float(C_) ** -0.5
+        q = ops.gemm(h, w[p + ".to_q.weight"], w[p + ".to_q.bias"], out_scale=scale)
         k = ops.gemm(h, w[p + ".to_k.weight"], w[p + ".to_k.bias"])
         ld = _round_up(HW, 8)
         vt = ops.gemm(h, w[p + ".to_v.weight"], w[p + ".to_v.bias"], transpose_rows=HW, transpose_ld=ld)   # (n, C, ld)
         if ld != HW:
             vt[:, :, HW:].zero_()
         att = torch.empty(n_img * HW, C_, device=x.device, dtype=x.dtype)
-        scale = float(C_) ** -0.5
         for i in range(n_img):
-            s = ops.gemm(q[i * HW:(i + 1) * HW], k[i * HW:(i + 1) * HW].contiguous())                  # (HW, HW) scores
+            s = ops.gemm(q[i * HW:(i + 1) * HW], k[i * HW:(i + 1) * HW].contiguous())                  # (HW, HW) scaled scores
             pm = torch.zeros(HW, ld, device=x.device, dtype=x.dtype) if ld != HW else torch.empty(HW, HW, device=x.device, dtype=x.dtype)
-            ops.softmax_rows(s, scale, out=pm[:, :HW])
+            ops.softmax_rows(s, 1.0, out=pm[:, :HW])
             ops.gemm(pm, vt[i], out=att[i * HW:(i + 1) * HW])
         return ops.gemm(att, w[p + ".to_out.0.weight"], w[p + ".to_out.0.bias"], residual=x)
 

@@ -187,7 +187,9 @@ int emo_temporal_attention(const void* qkv, int64_t ldqkv, void* out, int64_t ld
  * (EMOAnimationPipeline.py:812-817):  eps = uc + s*(c - uc) on noise_pred/counter;
  * x <- c_x*x + c_eps*eps + c_noise*z,  z = counter-based N(0,1) keyed by (seed, step, element).
  * noise_pred f32 [2][n] (uc, c), counter f32 per frame [F] broadcast over (C, H*W): element
- * (c, f, p) has index (c*F + f)*HW + p.  latents f32 [n], updated in place; eps_out optional. */
+ * (c, f, p) has index (c*F + f)*HW + p.  latents f32 [n], updated in place; eps_out optional.
+ * guidance_scale <= 1 is the reference's "no classifier-free guidance" (:622 `do_classifier_free_guidance =
+ * guidance_scale > 1.0`): noise_pred is then [1][n] and eps = noise_pred / counter. */
 int emo_cfg_step(const float* noise_pred, const float* counter, float* latents, float* eps_out, int C, int F,
                  int HW, float guidance_scale, float c_x, float c_eps, float c_noise, uint32_t seed, uint32_t step,
                  void* stream);

@@ -36,14 +36,27 @@ def denoise_loop(unet_sd, unet_cfg, ref_sd, ref_cfg, latents, ref_latents, text_
     '(b f) c h w -> b c f h w' and repeated for CFG (:514-540) and added inside the UNet (unet_controlnet.py:430-447)."""
     timesteps = scheduler.set_timesteps(num_inference_steps)
     cbs = context_batch_size
-    text = torch.cat([text_embeddings] * cbs) if cbs > 1 else text_embeddings  # (:631) [uc.., c..] per cat
+    # do_classifier_free_guidance = guidance_scale > 1.0 (:622).  Without it the UNet batch is the window batch (:759-763), the
+    # text is the cond embedding alone and eps = noise_pred / counter.  (The reference's own lines do not run in that mode -
+    # `pred_uc, pred_c = pred.chunk(2)` (:790) unpacks a one-row batch - and its reader is built with
+    # do_classifier_free_guidance=True (:634), which would mask the first half of the FRAMES off the bank; the restatement follows
+    # the evident intent, like the generator of tests/golden/loop_tiny.safetensors `ddim_nocfg`: no chunk, every row reads the bank.)
+    cfg = guidance_scale > 1.0
+    nbr = 2 if cfg else 1
+    if not cfg:
+        if motion_latents is not None or controlnet is not None or audio_features is not None:
+            raise NotImplementedError("oracle: the no-CFG loop is restated for the plain path only")
+        text_embeddings = text_embeddings[-1:]
+    # (:631) torch.cat([text] * cbs) = [uc, c, uc, c, ...] - against latent rows [w0, w1, .., w0, w1, ..] and the reader's
+    # uc mask [1, .., 0, ..] this pairs window j's rows with text row (branch * n + j) % 2 at cbs > 1: reference behaviour, kept
+    text = torch.cat([text_embeddings] * cbs) if cbs > 1 else text_embeddings
     f_tot = latents.shape[2]
     eps_trace = []
     for si, t in enumerate(timesteps):
-        noise_pred = torch.zeros(2, *latents.shape[1:])
+        noise_pred = torch.zeros(nbr, *latents.shape[1:])
         counter = torch.zeros(1, 1, f_tot, 1, 1)
         if motion_latents is None:
-            ref_in = ref_latents.repeat(2 * cbs, 1, 1, 1).unsqueeze(2)  # F=1 instance (SURVEY A15)
+            ref_in = ref_latents.repeat(nbr * cbs, 1, 1, 1).unsqueeze(2)  # F=1 instance (SURVEY A15)
             _, written = unet_forward(ref_sd, ref_cfg, ref_in, t, text, bank_mode="write", fusion_blocks=fusion_blocks)
         else:
             # motion-frame conditioning (SURVEY 8f row 3; design, no reference behaviour): [reference image, motion frames] through
@@ -68,11 +81,12 @@ def denoise_loop(unet_sd, unet_cfg, ref_sd, ref_cfg, latents, ref_latents, text_
                     cn_cache[k] = ([d[j:j + 1] for d in dn], md[j:j + 1])
         for r in range(world_size):
             for context in batches[r::world_size]:
-                x = torch.cat([latents[:, :, c] for c in context]).repeat(2, 1, 1, 1, 1)
+                x = torch.cat([latents[:, :, c] for c in context]).repeat(nbr, 1, 1, 1, 1)
                 x = scheduler.scale_model_input(x, t)
                 b, _, f, _, _ = x.shape
                 uc_rows = torch.zeros(b * f, dtype=torch.bool)
-                uc_rows[: (b // 2) * f] = True
+                if cfg:
+                    uc_rows[: (b // 2) * f] = True
                 af = None
                 if audio_features is not None:  # (F_tot, L_a, D) per-frame ctx; uc rows get zeros
                     cond = torch.cat([audio_features[c] for c in context])
@@ -91,8 +105,11 @@ def denoise_loop(unet_sd, unet_cfg, ref_sd, ref_cfg, latents, ref_latents, text_
                 pred = unet_forward(unet_sd, unet_cfg, x, t, text[:b], bank_mode="read", banks=banks,
                                     uc_rows=uc_rows, fusion_blocks=fusion_blocks, audio_features=af,
                                     speed_embeddings=speed_embeddings, **ckw)
-                pred_uc, pred_c = pred.chunk(2)
-                pred = torch.stack([pred_uc, pred_c])
+                if cfg:
+                    pred_uc, pred_c = pred.chunk(2)
+                    pred = torch.stack([pred_uc, pred_c])
+                else:
+                    pred = pred.unsqueeze(0)
                 for j, c in enumerate(context):
                     # reference (:792-794): noise_pred[:, :, c] = noise_pred[:, :, c] + pred[:, j]; counter likewise.  A wrapped
                     # window at context_stride > 1 lists a frame twice; torch leaves WHICH of the two writes of an index
@@ -103,8 +120,11 @@ def denoise_loop(unet_sd, unet_cfg, ref_sd, ref_cfg, latents, ref_latents, text_
                     frames = [c[i] for i in keep]
                     noise_pred[:, :, frames] = noise_pred[:, :, frames] + pred[:, j][:, :, keep]
                     counter[:, :, frames] = counter[:, :, frames] + 1
-        uc, cc = (noise_pred / counter).chunk(2)
-        eps = uc + guidance_scale * (cc - uc)
+        if cfg:
+            uc, cc = (noise_pred / counter).chunk(2)
+            eps = uc + guidance_scale * (cc - uc)
+        else:
+            eps = noise_pred / counter
         if return_eps:
             eps_trace.append(eps.clone())
         z = None

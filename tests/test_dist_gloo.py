@@ -100,7 +100,7 @@ def _patch_ops():
 
     def cfg_step(noise_pred, counter, latents, *, C_, F, HW, guidance_scale, c_x, c_eps, c_noise, seed, step, eps_out=None):
         avg = noise_pred / counter.view(1, 1, F, 1)
-        eps = avg[0] + guidance_scale * (avg[1] - avg[0])
+        eps = avg[0] + guidance_scale * (avg[1] - avg[0]) if guidance_scale > 1.0 else avg[0]
         x = c_x * latents.view(C_, F, HW) + c_eps * eps
         if c_noise != 0.0:
             x = x + c_noise * counter_normal(seed, step, latents.numel()).view(C_, F, HW)
@@ -124,7 +124,7 @@ def _inputs(f_tot=8):
     return seeded_randn((1, 4, f_tot, 16, 16), 5), seeded_randn((1, 4, 16, 16), 3), seeded_randn((2, 5, 32), 2)
 
 
-def _worker(rank, world, port, kind, out_dir, f_tot, ref_group):
+def _worker(rank, world, port, kind, out_dir, f_tot, ref_group, cbs=1, gs=7.5, overlap=0):
     import torch.distributed as td
     torch.set_num_threads(1 if world > 4 else 2)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -137,9 +137,9 @@ def _worker(rank, world, port, kind, out_dir, f_tot, ref_group):
     ref = OracleBackedUNet(cases.TINY, ref_sd, has_out=False)
     pipe = EMOAnimationPipeline(unet=unet, scheduler=DDIMScheduler() if kind == "ddim" else DDPMScheduler())
     lat, refl, text = _inputs(f_tot)
-    out = pipe.denoise(lat, refl, text, appearance_encoder=ref, num_inference_steps=3, guidance_scale=7.5, context_frames=4,
-                       context_stride=1, context_overlap=0, seed=0, dist=True, rank=rank, world_size=world,
-                       reference_group=ref_group)
+    out = pipe.denoise(lat, refl, text, appearance_encoder=ref, num_inference_steps=3, guidance_scale=gs, context_frames=4,
+                       context_stride=1, context_overlap=overlap, seed=0, dist=True, rank=rank, world_size=world,
+                       reference_group=ref_group, context_batch_size=cbs)
     torch.save(out.clone(), os.path.join(out_dir, f"lat_{kind}_{rank}.pt"))
     td.barrier()
     td.destroy_process_group()
@@ -163,6 +163,27 @@ def test_multi_rank_gloo_loop_matches_single_process_oracle(tmp_path, kind, worl
     # (the pipeline's write pass runs on the cond image only and batches timesteps, its UNet calls batch units differently
     # from the oracle's [uc, c] pairs: same maths, different f32 summation order inside the CPU GEMMs; the stochastic DDPM
     # sampler amplifies that to a few 1e-4 on isolated elements)
+    torch.testing.assert_close(lats[0], ref, rtol=2e-3, atol=5e-4)
+
+
+@pytest.mark.parametrize("world,cbs,gs,overlap", [(1, 2, 7.5, 2), (2, 2, 7.5, 2), (3, 2, 7.5, 0), (1, 1, 1.0, 2), (2, 1, 1.0, 2), (2, 2, 1.0, 0)])
+def test_context_batch_size_and_no_cfg_match_the_oracle(tmp_path, world, cbs, gs, overlap):
+    """context_batch_size 2 (three windows at overlap 2: a full batch of two + a partial one) reproduces the reference's literal
+    text / bank pairing at cbs > 1 (row r = branch * n + j runs under text row r % 2 and reads the bank written under it), which
+    needs a SECOND ReferenceNet variant (uncond text) and per-variant UNet calls; guidance_scale 1.0 drops the uncond branch
+    altogether.  Single rank and sharded, every rank identical, equal to the oracle loop (itself pinned by the `ddim_cbs2` /
+    `ddim_nocfg` goldens of tests/golden/loop_tiny.safetensors)."""
+    from oracle.pipeline_ref import denoise_loop
+    from oracle.scheduler_ref import SchedulerRef
+    mp.spawn(_worker, args=(world, _free_port(), "ddim", str(tmp_path), 8, 10, cbs, gs, overlap), nprocs=world, join=True)
+    lats = [torch.load(os.path.join(tmp_path, f"lat_ddim_{r}.pt")) for r in range(world)]
+    for r in range(1, world):
+        assert torch.equal(lats[0], lats[r])
+    unet_sd, ref_sd = _models()
+    lat, refl, text = _inputs(8)
+    ref = denoise_loop(unet_sd, cases.TINY_MOTION, ref_sd, cases.TINY, lat, refl, text, scheduler=SchedulerRef("ddim"),
+                       num_inference_steps=3, guidance_scale=gs, context_frames=4, context_stride=1, context_overlap=overlap, seed=0,
+                       context_batch_size=cbs)
     torch.testing.assert_close(lats[0], ref, rtol=2e-3, atol=5e-4)
 
 

@@ -65,11 +65,14 @@ def cfg2_models():
     return unet, ref
 
 
-def _run_loop(unet, ref, steps, *, graphs, ref_group, audio=None, n_steps=50):
-    from emote_hack_amd import DDPMScheduler
+def _run_loop(unet, ref, steps, *, graphs, ref_group, audio=None, n_steps=50, frames=12, ddim=False, frame_slice=None):
+    from emote_hack_amd import DDIMScheduler, DDPMScheduler
     from emote_hack_amd.pipeline import EMOAnimationPipeline
-    pipe = EMOAnimationPipeline(unet=unet, scheduler=DDPMScheduler())
-    st = pipe.prepare_denoise(seeded_randn((1, 4, 12, 64, 64), 1).to(DEV), seeded_randn((1, 4, 64, 64), 3), seeded_randn((2, 77, 768), 2),
+    pipe = EMOAnimationPipeline(unet=unet, scheduler=DDIMScheduler() if ddim else DDPMScheduler())
+    lat0 = seeded_randn((1, 4, frames, 64, 64), 1)
+    if frame_slice is not None:
+        lat0 = lat0[:, :, frame_slice].contiguous()
+    st = pipe.prepare_denoise(lat0.to(DEV), seeded_randn((1, 4, 64, 64), 3), seeded_randn((2, 77, 768), 2),
                               appearance_encoder=ref, num_inference_steps=n_steps, guidance_scale=7.5, context_frames=12,
                               context_stride=1, context_overlap=0, seed=0, use_graphs=graphs, reference_group=ref_group,
                               return_eps=True, audio_features=audio)
@@ -140,3 +143,26 @@ def test_cfg3_audio_context_in_the_loop(cfg2_models):
     lat_t, eps_t = _run_loop(unet, ref, 3, graphs=True, ref_group=3)
     assert bool(torch.isfinite(lat_a).all())
     assert float((eps_a[0] - eps_t[0]).abs().mean()) > 1e-3
+
+
+def test_cfg4_48_frames_four_windows_full_size(cfg2_models):
+    """BASELINE configs[3] ("cfg4") on ONE GPU at full size: a 48-frame clip = 4 windows of 12 at context_overlap 0 x 2 CFG
+    branches = 8 units (on 8 GPUs: one per rank, tests/test_dist_gloo.py; here 4 UNet calls of [uc, c] per step), bf16,
+    ReferenceNet on (EMOAnimationPipeline.py:752-757,796-821).
+      * 50-step DDPM, 2 steps: HIP-graph replay reproduces the eager launches bit for bit;
+      * windows are independent at overlap 0 (every frame belongs to one window, counter == 1): the first step's eps of window 0
+        equals the eps of the 12-frame single-window run on the same frames, and under the deterministic DDIM sampler so do the
+        latents after two steps (the DDPM noise is keyed by the element index of the whole clip, so it differs by construction)."""
+    unet, ref = cfg2_models
+    lat_e, eps_e = _run_loop(unet, ref, 2, graphs=False, ref_group=2, frames=48)
+    lat_g, eps_g = _run_loop(unet, ref, 2, graphs=True, ref_group=2, frames=48)
+    assert lat_e.shape == (1, 4, 48, 64, 64) and bool(torch.isfinite(lat_e).all())
+    for a, b in zip(eps_e, eps_g):
+        assert torch.equal(a, b)
+    assert torch.equal(lat_e, lat_g)
+    _, eps_1 = _run_loop(unet, ref, 1, graphs=False, ref_group=2, frames=48, frame_slice=slice(0, 12))
+    assert torch.equal(eps_e[0][:, :, :12], eps_1[0])
+    assert not torch.equal(eps_e[0][:, :, 12:24], eps_1[0])               # the other windows see other latents
+    lat_48, _ = _run_loop(unet, ref, 2, graphs=True, ref_group=2, frames=48, ddim=True)
+    lat_12, _ = _run_loop(unet, ref, 2, graphs=True, ref_group=2, frames=48, ddim=True, frame_slice=slice(36, 48))
+    assert torch.equal(lat_48[:, :, 36:], lat_12)                          # the LAST window: the fourth UNet call of a step

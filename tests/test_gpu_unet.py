@@ -116,9 +116,34 @@ def test_reference_write_read(tiny, dtype):
     reader.update(writer)
     y = unet(x.to(DEV), 961, ctx.to(DEV)).sample
     reader.clear()
-    check(y, tiny["read/out"], dtype, tiny["read/out_fp16"] if dtype == torch.float16 else None)
+    # low-precision gate = the reference's own read-path forward in that dtype (bf16: banks rounded through fp16 like update(),
+    # then cast to the model dtype - the reference's literal fp16 banks do not run in a bf16 model, see gen_golden.run_reader)
+    check(y, tiny["read/out"], dtype, {torch.float16: tiny["read/out_fp16"], torch.bfloat16: tiny["read/out_bf16"]}.get(dtype))
     if dtype == torch.float32:  # uc rows equal the no-bank run
         torch.testing.assert_close(y[:1].cpu(), tiny["motion/out"][:1], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_reference_write_read_fusion_blocks_full(tiny, dtype):
+    """fusion_blocks="full" (mutual_self_attention.py:532-537): the down-path transformer blocks write / read banks too - all 16
+    blocks, paired in the reference's order.  Goldens from the reference's own control object."""
+    from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
+    from emote_hack_amd.reference_control import ReferenceAttentionControl
+    x, ctx = cases.tiny_inputs(2, 4)
+    ref = build(cases.TINY, dtype, cases.REF_PREFIX, cls=AppearanceEncoderModel, has_out=False)
+    unet = build(cases.TINY_MOTION, dtype)
+    writer = ReferenceAttentionControl(ref, do_classifier_free_guidance=True, mode="write", batch_size=1, fusion_blocks="full")
+    reader = ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", batch_size=1, fusion_blocks="full")
+    assert len(writer.order) == len(reader.order) == 16
+    ref(seeded_randn((1, 4, 16, 16), 3).repeat(2, 1, 1, 1).to(DEV), 961, encoder_hidden_states=ctx.to(DEV), return_dict=False)
+    for i, p in enumerate(writer.order):
+        check(writer.bank[p][0], tiny[f"banks_full/{i}"], dtype)
+    reader.update(writer)
+    y = unet(x.to(DEV), 961, ctx.to(DEV)).sample
+    reader.clear()
+    check(y, tiny["read/out_full"], dtype)
+    if dtype == torch.float32:
+        assert float((y[1].cpu() - tiny["read/out"][1]).abs().max()) > 1e-2    # the down-path banks are live
 
 
 @pytest.mark.parametrize("ref_group", [10, 2, 1])
@@ -143,6 +168,31 @@ def test_denoise_loop_vs_golden(kind, graphs, ref_group):
     for i in range(3):
         torch.testing.assert_close(eps[i].cpu(), g[f"{kind}/eps{i}"], rtol=1e-3, atol=1e-4)
     torch.testing.assert_close(lat.cpu(), g[f"{kind}/latents"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+@pytest.mark.parametrize("prefix,cbs,gs", [("ddim_cbs2", 2, 7.5), ("ddim_nocfg", 1, 1.0)])
+def test_denoise_loop_context_batch_size_and_no_cfg_vs_golden(prefix, cbs, gs, graphs):
+    """Goldens re-enacted around the reference's own UNet (tools/oracle/gen_golden.py gen_loop):
+    ddim_cbs2 - context_batch_size 2 over three windows (a full batch + a partial one) with the reference's literal pairing at
+        cbs > 1: `torch.cat([text] * cbs)` (:631) puts window 0's cond row under the UNCOND text and the bank written under it, so
+        the ReferenceNet runs under both texts and the UNet calls are split per bank variant;
+    ddim_nocfg - guidance_scale 1.0 (`do_classifier_free_guidance = guidance_scale > 1.0`, :622): cond units only, every row
+        reads the bank, eps = noise_pred / counter (emo_cfg_step with guidance_scale <= 1)."""
+    from emote_hack_amd import DDIMScheduler
+    from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
+    from emote_hack_amd.pipeline import EMOAnimationPipeline
+    g = load_file(os.path.join(G, "loop_tiny.safetensors"))
+    ref = build(cases.TINY, torch.float32, cases.REF_PREFIX, cls=AppearanceEncoderModel, has_out=False)
+    unet = build(cases.TINY_MOTION, torch.float32)
+    pipe = EMOAnimationPipeline(unet=unet, scheduler=DDIMScheduler())
+    text = seeded_randn((2, 5, 32), 2)
+    lat, eps = pipe.denoise(seeded_randn((1, 4, 8, 16, 16), 5).to(DEV), seeded_randn((1, 4, 16, 16), 3), text if gs > 1 else text[1:],
+                            appearance_encoder=ref, num_inference_steps=3, guidance_scale=gs, context_frames=4, context_stride=1,
+                            context_overlap=2, seed=0, return_eps=True, use_graphs=graphs, context_batch_size=cbs)
+    for i in range(3):
+        torch.testing.assert_close(eps[i].cpu(), g[f"{prefix}/eps{i}"], rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(lat.cpu(), g[f"{prefix}/latents"], rtol=1e-3, atol=1e-4)
 
 
 @pytest.mark.parametrize("graphs", [False, True])

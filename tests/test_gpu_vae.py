@@ -93,3 +93,39 @@ def test_vae_full_size_decode_one_frame_bf16_vs_f32():
         del m
     assert outs[torch.float32].shape == (1, 3, 512, 512) and bool(torch.isfinite(outs[torch.bfloat16]).all())
     check(outs[torch.bfloat16], outs[torch.float32], torch.bfloat16)
+
+
+def test_pipeline_source_image_goes_through_images2latents(tmp_path):
+    """EMOAnimationPipeline.py:686-689 + 402-414: `source_image` is a file path (opened, resized to (width, height)) or an
+    (H, W, 3) uint8 array; images2latents scales by / 127.5 - 1, moves channels first and takes `vae.encode(x)['latent_dist'].mean
+    * 0.18215`.  A reference-style call with vae= + source_image= must produce the same video as one fed the oracle's latents
+    of that image (the path used to hand the raw HWC uint8 array to vae.encode)."""
+    import numpy as np
+    from PIL import Image
+    from oracle import vae_ref as V
+    from emote_hack_amd import DDIMScheduler
+    from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
+    from emote_hack_amd.pipeline import EMOAnimationPipeline
+    from tests import cases
+    from tests.test_gpu_unet import build as build_unet
+    vae, vsd = build(SMALL, torch.float32)
+    ref = build_unet(cases.TINY, torch.float32, cases.REF_PREFIX, cls=AppearanceEncoderModel, has_out=False)
+    unet = build_unet(cases.TINY_MOTION, torch.float32)
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, size=(128, 128, 3)).astype(np.uint8)
+    want_lat = V.encode(vsd, torch.from_numpy(img).float().div(127.5).sub(1.0).permute(2, 0, 1)[None], layers_per_block=1, groups=8)[:, :4] * 0.18215
+    pipe = EMOAnimationPipeline(vae=vae, unet=unet, scheduler=DDIMScheduler())
+    got_lat = pipe.images2latents(img[None])
+    assert got_lat.shape == (1, 4, 16, 16)
+    torch.testing.assert_close(got_lat.cpu(), want_lat, rtol=1e-3, atol=1e-4)
+    kw = dict(height=128, width=128, num_inference_steps=2, appearance_encoder=ref, context_frames=4, init_latents=seeded_randn((4, 4, 16, 16), 5),
+              text_embeddings=seeded_randn((2, 5, 32), 2), output_type="latent")
+    a = pipe("", 4, source_image=img, **kw).videos
+    b = pipe("", 4, ref_image_latents=want_lat, **kw).videos
+    torch.testing.assert_close(a.cpu(), b.cpu(), rtol=2e-3, atol=2e-4)
+    path = str(tmp_path / "ref.png")
+    Image.fromarray(rng.randint(0, 256, size=(96, 160, 3)).astype(np.uint8)).save(path)     # resized to (width, height) by the path branch
+    c = pipe("", 4, source_image=path, **kw).videos
+    assert tuple(c.shape) == (1, 4, 4, 16, 16) and bool(torch.isfinite(c).all())
+    with pytest.raises(ValueError):
+        pipe("", 4, source_image=img[:, :, :2], **kw)

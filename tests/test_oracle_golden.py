@@ -207,17 +207,37 @@ def test_reference_write_read(tiny):
     assert (y[1] - tiny["motion/out"][1]).abs().max() > 1e-2
 
 
-@pytest.mark.parametrize("kind", ["ddim", "ddpm"])
-def test_denoise_loop(kind):
+def test_reference_write_read_fusion_blocks_full(tiny):
+    """fusion_blocks="full" (mutual_self_attention.py:532-537): all 16 transformer blocks write / read, down path included."""
+    x, ctx = cases.tiny_inputs(2, 4)
+    ref_lat = seeded_randn((1, 4, 16, 16), 3).repeat(2, 1, 1, 1).unsqueeze(2)
+    _, written = U.unet_forward(tiny_sd(cases.TINY, cases.REF_PREFIX), cases.TINY, ref_lat, 961, ctx, bank_mode="write", fusion_blocks="full")
+    order = U.transformer_block_order(cases.TINY, "full")
+    assert len(order) == 16
+    for i, p in enumerate(order):
+        close(written[p], tiny[f"banks_full/{i}"])
+    y = U.unet_forward(tiny_sd(cases.TINY_MOTION), cases.TINY_MOTION, x, 961, ctx, bank_mode="read", banks=U.round_banks_fp16(written),
+                       uc_rows=cases.uc_rows(2, 4), fusion_blocks="full")
+    close(y, tiny["read/out_full"])
+    assert (y[1] - tiny["read/out"][1]).abs().max() > 1e-2
+
+
+# (prefix of tests/golden/loop_tiny.safetensors, scheduler, context_batch_size, guidance_scale): ddim_cbs2 = three windows in a
+# full + a partial batch with the reference's literal text / bank-row pairing at cbs > 1; ddim_nocfg = guidance_scale 1.0
+LOOP_CASES = [("ddim", "ddim", 1, 7.5), ("ddpm", "ddpm", 1, 7.5), ("ddim_cbs2", "ddim", 2, 7.5), ("ddim_nocfg", "ddim", 1, 1.0)]
+
+
+@pytest.mark.parametrize("prefix,kind,cbs,gs", LOOP_CASES)
+def test_denoise_loop(prefix, kind, cbs, gs):
     g = load_file(os.path.join(G, "loop_tiny.safetensors"))
     lat, eps = denoise_loop(tiny_sd(cases.TINY_MOTION), cases.TINY_MOTION, tiny_sd(cases.TINY, cases.REF_PREFIX),
                             cases.TINY, seeded_randn((1, 4, 8, 16, 16), 5), seeded_randn((1, 4, 16, 16), 3),
                             seeded_randn((2, 5, 32), 2), scheduler=S.SchedulerRef(kind), num_inference_steps=3,
-                            guidance_scale=7.5, context_frames=4, context_stride=1, context_overlap=2, seed=0,
-                            return_eps=True)
+                            guidance_scale=gs, context_frames=4, context_stride=1, context_overlap=2, seed=0,
+                            return_eps=True, context_batch_size=cbs)
     for i in range(3):
-        close(eps[i], g[f"{kind}/eps{i}"], 1e-3, 1e-4)  # measured worst 0.68 of the bound (profiles/r02f_loop_error.txt holds the HIP side)
-    close(lat, g[f"{kind}/latents"], 1e-3, 1e-4)
+        close(eps[i], g[f"{prefix}/eps{i}"], 1e-3, 1e-4)  # measured worst 0.68 of the bound (profiles/r02f_loop_error.txt holds the HIP side)
+    close(lat, g[f"{prefix}/latents"], 1e-3, 1e-4)
 
 
 # ------------------------------------------------------------------ scheduler self-consistency (parity unpinned)

@@ -222,11 +222,11 @@ def gen_modules():
 
 
 # =============================================================================== tiny UNet end to end
-def run_writer(ref_unet, ref_lat, t, ctx):
+def run_writer(ref_unet, ref_lat, t, ctx, fusion="midup"):
     """ReferenceNet pass = the no-motion 3-D UNet at F=1 in 'write' mode."""
-    ctl = ReferenceAttentionControl(ref_unet, do_classifier_free_guidance=True, mode="write", batch_size=1)
+    ctl = ReferenceAttentionControl(ref_unet, do_classifier_free_guidance=True, mode="write", batch_size=1, fusion_blocks=fusion)
     ref_unet(ref_lat.unsqueeze(2), t, ctx)
-    blocks = sorted_blocks(ref_unet, "midup")
+    blocks = sorted_blocks(ref_unet, fusion)
     banks = [b.bank[0].clone() for b in blocks]
     ctl.clear()
     for b in blocks:  # un-hook
@@ -234,11 +234,14 @@ def run_writer(ref_unet, ref_lat, t, ctx):
     return banks
 
 
-def run_reader(unet, x, t, ctx, banks, **kw):
-    ctl = ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", batch_size=1)
-    blocks = sorted_blocks(unet, "midup")
+def run_reader(unet, x, t, ctx, banks, fusion="midup", cfg=True, batch_size=1, bank_dtype=None, **kw):
+    """bank_dtype: the reference's update() hands fp16 banks to the reader whatever the model dtype (:588); a bf16 model then
+    fails inside torch.cat / the to_k Linear (bf16 x fp16 promotes to f32) - the low-precision yard-stick of the bf16 mode
+    therefore rounds through fp16 like update() and THEN casts to the model dtype (what the product's bank hand-off does)."""
+    ctl = ReferenceAttentionControl(unet, do_classifier_free_guidance=cfg, mode="read", batch_size=batch_size, fusion_blocks=fusion)
+    blocks = sorted_blocks(unet, fusion)
     for b, v in zip(blocks, banks):  # what update() does (mutual_self_attention.py:588)
-        b.bank = [v.clone().to(torch.float16)]
+        b.bank = [v.clone().to(torch.float16) if bank_dtype is None else v.clone().to(torch.float16).to(bank_dtype)]
     y = unet(x, t, ctx, **kw).sample
     ctl.clear()
     for b in blocks:
@@ -272,6 +275,11 @@ def gen_unet_tiny():
     for i, b in enumerate(banks):
         T[f"banks/{i}"] = b
     T["read/out"] = run_reader(u1, x, 961, ctx, banks)
+    # (c2) fusion_blocks="full" (mutual_self_attention.py:532-537): the down-path transformer blocks write / read banks too
+    banks_full = run_writer(ref, ref_lat, 961, ctx, fusion="full")
+    for i, b in enumerate(banks_full):
+        T[f"banks_full/{i}"] = b
+    T["read/out_full"] = run_reader(u1, x, 961, ctx, banks_full, fusion="full")
     # (b4) H / W not a multiple of 2^num_upsamplers: the upsamplers interpolate to the skip's size (unet_controlnet.py:357-365,456-459)
     T["motion/out_20x12"] = u1(seeded_randn((1, 4, 2, 20, 12), 1), 500, seeded_randn((1, 5, 32), 2)).sample
     # (d) the reference's OWN low-precision forwards of the same models / inputs: the yard-stick for the bf16 / fp16 HIP
@@ -283,7 +291,8 @@ def gen_unet_tiny():
             T[f"motion/out_{name}"] = um(x.to(dt), torch.tensor(961), ctx.to(dt)).sample.float()
             up = copy.deepcopy(u0).to(dt)
             T[f"plain/out_{name}"] = up(x[:, :, :2].to(dt), 981, ctx.to(dt)).sample.float()
-            T[f"read/out_{name}"] = run_reader(um, x.to(dt), 961, ctx.to(dt), [b.to(dt) for b in banks]).float()
+            T[f"read/out_{name}"] = run_reader(um, x.to(dt), 961, ctx.to(dt), [b.to(dt) for b in banks],
+                                               bank_dtype=None if dt == torch.float16 else dt).float()
         except Exception as ex:   # a CPU op without a half kernel
             print(f"reference forward in {name} failed: {ex}")
     save_file({k: v.contiguous() for k, v in T.items()}, os.path.join(GOLD, "unet_tiny.safetensors"))
@@ -295,42 +304,67 @@ def gen_unet_tiny():
 def gen_loop(u1, ref):
     """Re-enact EMOAnimationPipeline.py:698-823 around the reference's own UNet (the file itself
     cannot be imported: `animated_diff`, diffusers pipelines).  Scheduler = oracle/scheduler_ref.py
-    (diffusers absent => parity unpinned there)."""
+    (diffusers absent => parity unpinned there).
+
+    Variants (key prefix): ddim / ddpm = CFG 7.5, context_batch_size 1;  ddim_cbs2 = context_batch_size 2 with THREE windows
+    (a full batch of two + a partial batch), text rows exactly as the reference builds them - `torch.cat([text] * cbs)` (:631)
+    is [uc, c, uc, c] against latent rows [w0, w1, w0, w1] and the reader's uc mask [1, 1, 0, 0];  ddim_nocfg =
+    guidance_scale 1.0: `do_classifier_free_guidance = guidance_scale > 1.0` (:622) is False, the UNet batch is the window
+    batch (:759-763 `.repeat(1)`), text is the cond embedding alone (_encode_prompt without the uncond half), eps =
+    noise_pred / counter (:812-814 skipped).  The reference's own no-CFG lines do not run as written (`pred_uc, pred_c =
+    pred.chunk(2)` at :790 unpacks a one-row batch, and the reader is built with do_classifier_free_guidance=True at :634, which
+    would mask the first half of the FRAMES off the bank): the golden re-enacts the evident intent - no chunk, every row reads
+    the bank (reader built with do_classifier_free_guidance=False)."""
     import math as _m
 
-    from oracle.scheduler_ref import SchedulerRef
+    from oracle.scheduler_ref import SchedulerRef, counter_normal
     T = {}
-    for kind in ("ddim", "ddpm"):
+
+    def run(prefix, kind, cbs=1, gs=7.5, ov=2):
+        cfg = gs > 1.0
         sch = SchedulerRef(kind)
-        steps, gs = 3, 7.5
+        steps = 3
         timesteps = sch.set_timesteps(steps)
-        f_tot, cf, ov, cbs = 8, 4, 2, 1
+        f_tot, cf = 8, 4
         latents = seeded_randn((1, 4, f_tot, 16, 16), 5)
         ref_lat = seeded_randn((1, 4, 16, 16), 3)
-        text = seeded_randn((2, 5, 32), 2)
-        from oracle.scheduler_ref import counter_normal
+        text2 = seeded_randn((2, 5, 32), 2)
+        text = torch.cat([text2 if cfg else text2[1:]] * cbs)                                  # :625-631
+        nbr = 2 if cfg else 1
         for si, t in enumerate(timesteps):
-            noise_pred = torch.zeros(2, *latents.shape[1:])
+            noise_pred = torch.zeros(nbr, *latents.shape[1:])
             counter = torch.zeros(1, 1, f_tot, 1, 1)
-            banks = run_writer(ref, ref_lat.repeat(2 * cbs, 1, 1, 1), t, text)              # :711-716
+            banks = run_writer(ref, ref_lat.repeat(nbr * cbs, 1, 1, 1), t, text)               # :711-716
             queue = list(ref_uniform(0, steps, f_tot, cf, 1, ov))                             # :748-750
             nb = _m.ceil(len(queue) / cbs)
             for i in range(nb):
                 context = queue[i * cbs:(i + 1) * cbs]
-                lmi = torch.cat([latents[:, :, c] for c in context]).repeat(2, 1, 1, 1, 1)   # :759-763
+                lmi = torch.cat([latents[:, :, c] for c in context]).repeat(nbr, 1, 1, 1, 1)   # :759-763
                 b = lmi.shape[0]
-                pred = run_reader(u1, lmi, t, text[:b], banks)                               # :774-788
-                pred_uc, pred_c = pred.chunk(2)
-                pred = torch.cat([pred_uc.unsqueeze(0), pred_c.unsqueeze(0)])
+                # (a partial last batch: `.repeat(1, video_length, 1, 1)[:hidden_states.shape[0]]` (:236) cuts the bank rows to the batch)
+                pred = run_reader(u1, lmi, t, text[:b], banks, cfg=cfg, batch_size=cbs)       # :774-788
+                if cfg:
+                    pred_uc, pred_c = pred.chunk(2)
+                    pred = torch.cat([pred_uc.unsqueeze(0), pred_c.unsqueeze(0)])
+                else:
+                    pred = pred.unsqueeze(0)
                 for j, c in enumerate(context):
                     noise_pred[:, :, c] = noise_pred[:, :, c] + pred[:, j]                   # :792-794
                     counter[:, :, c] = counter[:, :, c] + 1
-            uc, cc = (noise_pred / counter).chunk(2)                                          # :813
-            eps = uc + gs * (cc - uc)                                                         # :814
-            T[f"{kind}/eps{si}"] = eps.clone()
+            if cfg:
+                uc, cc = (noise_pred / counter).chunk(2)                                      # :813
+                eps = uc + gs * (cc - uc)                                                     # :814
+            else:
+                eps = noise_pred / counter
+            T[f"{prefix}/eps{si}"] = eps.clone()
             z = counter_normal(0, si, latents.numel()).reshape(latents.shape) if kind == "ddpm" else None
             latents = sch.step(eps, t, latents, noise=z)
-        T[f"{kind}/latents"] = latents
+        T[f"{prefix}/latents"] = latents
+
+    run("ddim", "ddim")
+    run("ddpm", "ddpm")
+    run("ddim_cbs2", "ddim", cbs=2)
+    run("ddim_nocfg", "ddim", gs=1.0)
     save_file({k: v.contiguous() for k, v in T.items()}, os.path.join(GOLD, "loop_tiny.safetensors"))
     print("loop_tiny.safetensors", list(T))
 

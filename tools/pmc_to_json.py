@@ -7,9 +7,13 @@ profiles/rNN_pmc.json: HBM-side bytes per launch for each kernel family bench.py
 FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts 128-byte requests at 64 bytes, so it is doubled
 (MI355X_MICROARCH.md, HBM section).  WRITE_SIZE is uncalibrated (reported as is)."""
 import json
+import os
 import re
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from emote_hack_amd.build import csrc_digest  # noqa: E402  (the build the counters belong to)
 
 FAMILY = [("layernorm_stats_kernel", "layernorm_stats"), ("softmax_rows_kernel", "softmax_rows"), ("conv3x3_halo_kernel", "gemm_conv3x3"), (r"gemm_kernel<[^>]*?(unsigned short|float), true", "gemm_conv3x3"),
           ("gemm_kernel", "gemm_dense"), ("gemm_splitk_epilogue", "gemm_splitk_epilogue"), ("temporal_attention_kernel", "temporal_attention"),
@@ -70,6 +74,7 @@ def mfma(path):
             tot_b += b
             tot_a += a
     out["mfma_busy_frac"] = tot_b / (tot_a / XCDS * SIMDS) if tot_a else None
+    out["csrc_sha256"] = csrc_digest()
     out["mfma_busy_frac_note"] = "over every dispatch of the path's kernel families (GEMM, conv, attention AND the HBM-bound kernels), weighted by time in flight"
     print(json.dumps(out, indent=1))
 
@@ -81,7 +86,7 @@ def main():
     out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1 --no-graphs "
                    "--no-profile --no-cpu-baseline` (2 loop iterations), gfx950 correction FETCH x2 (MI355X_MICROARCH.md HBM section); "
                    "WRITE_SIZE uncalibrated; GroupNorm = stats + apply launches",
-           "per_kernel_family": {}}
+           "csrc_sha256": csrc_digest(), "per_kernel_family": {}}
     for fam in sorted(set(fetch) | set(write)):
         nf, f = fetch.get(fam, [0, 0.0])
         nw, w = write.get(fam, [0, 0.0])

@@ -13,6 +13,7 @@ PMC_CMD="python bench.py --steps 1 --warmup 1 --no-graphs --no-profile --no-cpu-
 rocprofv3 -L > $OUT/counters.txt 2>&1 || true
 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $CMD > $OUT/kt.log 2>&1
 python tools/rocpd_summary.py $(ls /tmp/prof_kt/*/kt_results.db /tmp/prof_kt/kt_results.db 2>/dev/null | head -1) > $OUT/kernel_stats.md 2>> $OUT/kt.log
+python tools/trace_gaps.py $(ls /tmp/prof_kt/*/kt_results.db /tmp/prof_kt/kt_results.db 2>/dev/null | head -1) > $OUT/trace_gaps.txt 2>> $OUT/kt.log
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -o f -- $PMC_CMD > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o w -- $PMC_CMD > $OUT/pmc_write.log 2>&1
 python tools/pmc_to_json.py $(ls /tmp/prof_f/*/f_results.db /tmp/prof_f/f_results.db 2>/dev/null | head -1) \
