@@ -400,6 +400,41 @@ def test_attention_bank_segment_and_shared_context(dtype):
     close(got2, ref2, dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("d", [40, 48])
+def test_attention_two_query_tiles_per_wave(dtype, d):
+    """The d <= 48 kernel of the 2-byte types with TWO 32-query tiles per wave (256 query rows per block; picked when the launch
+    has >= 1024 such blocks: 8 batches x 8 heads x 4096 queries here - the 64x64 level's shape).  K rows are stored UNPADDED at
+    d = 40 (5 chunks: the last k-step's second half reads the next row against a zero Q chunk) and padded at d = 48 (7).
+    Ragged key counts in both segments (200 = 3 tiles + 8 keys, 77 = 1 tile + 13), a bank row selected by the device word for
+    batches >= 4, a late spike that forces the O rescale, and a ragged last query block are all on this path."""
+    o = ops()
+    B, Lq, Lk, Lb, heads = 8, 4096 - 40, 200, 77, 8
+    C_ = heads * d
+    qq, kk, vv = (q(seeded_randn((B, L, C_), s), dtype) for L, s in ((Lq, 44), (Lk, 45), (Lk, 46)))
+    bk, bv = q(seeded_randn((3, Lb, C_), 47), dtype), q(seeded_randn((3, Lb, C_), 48), dtype)
+    kk[5, 150] = q(qq[5, 300] * 3.0, dtype)
+    row = 2
+    sp = lambda t: t.reshape(t.shape[0], -1, heads, d).permute(0, 2, 1, 3)
+    dvf = lambda t: t.to(DEV).float()
+    refs = []
+    for b in range(B):
+        k_, v_ = kk[b:b + 1], vv[b:b + 1]
+        if b >= 4:
+            k_, v_ = torch.cat([k_, bk[row:row + 1]], 1), torch.cat([v_, bv[row:row + 1]], 1)
+        refs.append(attn_ref(sp(dvf(qq[b:b + 1])), sp(dvf(k_)), sp(dvf(v_)), d ** -0.5).permute(0, 2, 1, 3).reshape(Lq, C_).cpu())
+    ref = torch.cat(refs)
+    dv = lambda t: t.to(DEV).to(dtype)
+    vt = torch.full((B, C_, 200), float("nan"))
+    vt[:, :, :Lk] = vv.permute(0, 2, 1)
+    bvt = torch.zeros(3, C_, 80)
+    bvt[:, :, :Lb] = bv.permute(0, 2, 1)
+    got = o.attention(dv(qq.reshape(-1, C_)), dv(kk.reshape(-1, C_)), dv(vt), Lk, B=B, Lq=Lq, heads=heads, d=d, scale=d ** -0.5,
+                      k1=dv(bk.reshape(-1, C_)), v1t=dv(bvt), Lk1=Lb, seg1_div=B, seg1_first_batch=4,
+                      seg1_row=torch.tensor([row], dtype=torch.int32, device=DEV))
+    close(got, ref, dtype)
+
+
 def test_attention_online_softmax_rescale_forced():
     """Spike one key late in the sequence so the running max jumps in a later KV tile (rescale branch)."""
     o = ops()

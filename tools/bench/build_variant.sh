@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: build_variant.sh NAME "-DFLAG ..."   -> emote_hack_amd/lib/variants/NAME.so
+#        TUS="attention" build_variant.sh att_qt1 -DEMO_ATT_QT=1     (translation units that see the flags; default: gemm gemm_bf16)
 #        PATCH=tools/bench/patches/gemm_timing.patch build_variant.sh timing   (sources copied to /tmp and patched first)
 # Rebuilds the GEMM translation units that see the flags (gemm.hip: planning, gemm_bf16.hip: kernels) and links them with the
 # other objects of the product build.  BENCH ONLY: the f32 / f16 kernels keep the product's geometry - load the variant with
@@ -14,13 +15,15 @@ if [ -n "$PATCH" ]; then
   SRC=$T/x/csrc
 fi
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-variable -Wno-pass-failed"
-/opt/rocm/bin/hipcc $FL $@ -c $SRC/gemm.hip -o /tmp/emo_variant_${N}_gemm.o &
-/opt/rocm/bin/hipcc $FL $@ -c $SRC/gemm_bf16.hip -o /tmp/emo_variant_${N}_gemm_bf16.o &
+TUS=${TUS:-"gemm gemm_bf16"}
+for tu in $TUS; do
+  /opt/rocm/bin/hipcc $FL $@ -c $SRC/$tu.hip -o /tmp/emo_variant_${N}_$tu.o &
+done
 wait
 L=emote_hack_amd/lib
 OBJS=""
 for o in elementwise norm gemm gemm_f32 gemm_bf16 gemm_f16 attention temporal conditioning frontend; do
-  if [ "$o" == "gemm" ] || [ "$o" == "gemm_bf16" ]; then OBJS="$OBJS /tmp/emo_variant_${N}_$o.o"; else OBJS="$OBJS $L/$o.o"; fi
+  if [[ " $TUS " == *" $o "* ]]; then OBJS="$OBJS /tmp/emo_variant_${N}_$o.o"; else OBJS="$OBJS $L/$o.o"; fi
 done
 mkdir -p $L/variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $L/variants/$N.so

@@ -1,34 +1,25 @@
-import torch, sys
+"""f32 / low-precision attention vs a torch statement at the full-size shapes of BASELINE configs[4] (768x768: 9216 queries)."""
+import sys, torch
 sys.path.insert(0, '.')
 from emote_hack_amd import ops as o
-from emote_hack_amd.synth import seeded_randn
-DEV='cuda'
-def attn_ref(qh, k, v, scale):
-    s = torch.matmul(qh, k.transpose(-1, -2)) * scale
-    return torch.matmul(s.softmax(-1), v)
-def run(Bc, Fr, L, heads, d, Lb, first):
-    C_ = heads*d; nb = Bc*Fr
-    qq, kk, vv = (seeded_randn((nb, L, C_), s) for s in (27, 28, 29))
-    bk, bv = seeded_randn((Bc, Lb, C_), 30), seeded_randn((Bc, Lb, C_), 31)
-    sp = lambda t: t.reshape(t.shape[0], -1, heads, d).permute(0, 2, 1, 3)
-    refs = []
-    for b in range(nb):
-        k_, v_ = kk[b:b+1], vv[b:b+1]
-        if b >= first:
-            k_ = torch.cat([k_, bk[b//Fr:b//Fr+1]], 1); v_ = torch.cat([v_, bv[b//Fr:b//Fr+1]], 1)
-        refs.append(attn_ref(sp(qq[b:b+1]), sp(k_), sp(v_), d**-0.5).permute(0,2,1,3).reshape(L, C_))
-    ref = torch.cat(refs)
-    dv = lambda t: t.to(DEV)
-    got = o.attention(dv(qq.reshape(-1, C_)), dv(kk.reshape(-1, C_)), dv(vv.permute(0,2,1).contiguous()), L, B=nb, Lq=L, heads=heads, d=d, scale=d**-0.5,
-                      k1=dv(bk.reshape(-1, C_)), v1t=dv(bv.permute(0,2,1).contiguous()), Lk1=Lb, seg1_div=Fr, seg1_first_batch=first).cpu()
-    err = (got-ref).abs().reshape(nb, L, heads, d)
-    print(f"Bc={Bc} Fr={Fr} L={L} h={heads} d={d} Lb={Lb} first={first}: per-batch max err", [f"{float(err[b].max()):.2e}" for b in range(nb)],
-          "per-head", [f"{float(err[:, :, h].max()):.2e}" for h in range(heads)])
-run(2,3,48,4,40,80,3)
-run(1,1,64,1,32,64,0)
-run(1,1,64,1,32,32,0)
-run(1,1,32,1,32,32,0)
-run(2,1,64,1,32,64,0)
-run(2,1,64,1,32,64,1)
-run(1,2,64,2,32,64,0)
-run(2,3,64,4,32,64,3)
+dev = 'cuda'
+
+
+def run(dt, B, Lq, Lk, heads, d):
+    C = heads * d
+    g = torch.Generator(device=dev).manual_seed(1)
+    q = torch.randn(B * Lq, C, device=dev, generator=g).to(dt); k = torch.randn(B * Lk, C, device=dev, generator=g).to(dt)
+    v = torch.randn(B, Lk, C, device=dev, generator=g).to(dt)
+    ld = (Lk + 7) // 8 * 8
+    vt = torch.full((B, C, ld), float('nan'), device=dev, dtype=dt)
+    vt[:, :, :Lk] = v.permute(0, 2, 1)
+    got = o.attention(q, k, vt, Lk, B=B, Lq=Lq, heads=heads, d=d, scale=d ** -0.5).float()
+    sp = lambda t, L: t.float().reshape(B, L, heads, d).permute(0, 2, 1, 3)
+    ref = torch.softmax(sp(q, Lq) @ sp(k, Lk).transpose(-1, -2) * d ** -0.5, -1) @ sp(v, Lk)
+    ref = ref.permute(0, 2, 1, 3).reshape(B * Lq, C)
+    print(f"{dt} B={B} Lq={Lq} Lk={Lk} d={d}: nan={int(torch.isnan(got).sum())} max err {float((got - ref).abs().nan_to_num(9e9).max()):.3e}", flush=True)
+
+
+for dt in (torch.float32, torch.float16, torch.bfloat16):
+    run(dt, 4, 9216, 9216, 8, 40); run(dt, 48, 9216, 5, 8, 40); run(dt, 4, 2304, 2304, 8, 80); run(dt, 48, 2304, 5, 8, 80)
+    run(dt, 4, 576, 576, 8, 160); run(dt, 48, 576, 5, 8, 160); run(dt, 48, 144, 144, 8, 160); run(dt, 48, 144, 5, 8, 160)
