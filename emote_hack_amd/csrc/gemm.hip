@@ -53,13 +53,15 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
   }
   {
     const int bk = KBYTES / (p.dtype == EMO_F32 ? 4 : 2);
-    if (conv && p.stride == 1 && !p.conv_asym && !p.upsample2x && !p.up_h && !p.transpose_out && !p.geglu && S == 1 && p.Cin % bk == 0 &&
-        p.H % 8 == 0 && p.W_ % HaloGeom::PW == 0 && (p.N & 3) == 0 &&
-        (!p.rowbias || (p.rows_per_batch % (p.H * p.W_) == 0 && (p.ld_rowbias & 3) == 0))) {
+    // (the nearest x2 upsampling of resnet.py:74-82 rides along: the patch grid lives on the upsampled frame)
+    const int He = p.upsample2x ? 2 * p.H : p.H, We = p.upsample2x ? 2 * p.W_ : p.W_;
+    if (conv && p.stride == 1 && !p.conv_asym && !p.up_h && !p.transpose_out && !p.geglu && S == 1 && p.Cin % bk == 0 &&
+        He % 8 == 0 && We % HaloGeom::PW == 0 && (p.N & 3) == 0 &&
+        (!p.rowbias || (p.rows_per_batch % (He * We) == 0 && (p.ld_rowbias & 3) == 0))) {
       const int64_t nt = (p.N + HaloGeom::BN - 1) / HaloGeom::BN;
       // 16-row patches (8 waves, one block per CU) when they still give (nearly) every CU a block; p.tile 1 / 2 pins 8 / 16
       const int64_t tiles16 = (p.M / 256) * nt;
-      const bool ph16 = p.H % 16 == 0 && (p.tile == 2 || (p.tile != 1 && tiles16 >= 200));
+      const bool ph16 = He % 16 == 0 && (p.tile == 2 || (p.tile != 1 && tiles16 >= 200));
       const int64_t tiles = ph16 ? tiles16 : (p.M / 128) * nt, slots = ph16 ? 256 : 512;
       const int64_t gx = tiles > slots ? slots : tiles;
       int rc_h = EMO_OK;

@@ -195,6 +195,12 @@ __device__ __forceinline__ void lds_write8(unsigned addr, unsigned lo, unsigned 
 //     to vmcnt(0) at every join (and spilled row addresses around them) - the very round trips this function removes.
 //   * ROWW = 0: row r of the wave's tile is output row wm0 + r.  ROWW = 16 (halo conv): the tile is a stack of 16-pixel patch
 //     rows, row r is output row wm0 + (r / 16) * row_pitch + r % 16 (a chunk round never straddles a patch row).
+// Output tiles are STREAMED: a tile's 16-128 KB are written once and read back by another kernel (on another XCD, i.e. through the
+// fabric anyway) - stored non-temporally (aux bit 1 = nt) they do not displace the operand panels the XCD's L2 holds for the
+// blocks still in their main loops: -8 % at M=98304 N=2560 K=320 GEGLU, -11 % at N=960, -18 % at M=24576 N=K=640 + residual,
+// neutral on the long-K shapes (profiles/r03h_epilogue_store_policy.txt; sc1 / sc0+sc1 write-through: neutral; nt on the
+// residual LOADS as well gives the gain back).
+static constexpr int EPI_STORE_AUX = 2;
 template <typename T, int WTM, int WTN, int NW, int XBYTES, bool GEGLU, bool LN, bool RES, bool ROWB, int ROWW = 0>
 __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], const emo_gemm_params& p, int64_t wm0, int wn0, int wave, int lane,
                                                     unsigned xbase, T* __restrict__ C, const T* __restrict__ R, const float (&ln_rstd)[WTM],
@@ -305,7 +311,7 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], cons
       // offset hipcc lets the next chunk's unpack overwrite the store's data registers in the very next instruction, and the
       // store then writes that instead for some lanes - seen as `x << 16` patterns in the last tile of a pass once a block
       // walks several tiles.  Without an SGPR offset the compiler applies the > 8-byte store-data hazard rule.)
-      __builtin_amdgcn_raw_buffer_store_b128(out, rs_c, vo + so, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(out, rs_c, vo + so, 0, EPI_STORE_AUX);
     }
     __builtin_amdgcn_sched_barrier(0);
   });
@@ -802,8 +808,12 @@ __global__ __launch_bounds__(32 * PH_, 2) void conv3x3_halo_kernel(const emo_gem
   const int wvm = wave >> 1, wvn = wave & 1;
   const int half = lane >> 5, l31 = lane & 31;
 
-  const int tpx = p.W_ / Halo::PW, tpy = p.H / Halo::PH, tpi = tpx * tpy;   // patches per frame
-  const int tiles_m = (int)(p.M / ((int64_t)p.H * p.W_)) * tpi;
+  // nearest x2 upsampling folded into the halo loader (resnet.py:74-82: the interpolated tensor never exists): the patch
+  // grid lives on the UPSAMPLED frame (He x We), a halo pixel (y, x) is read from source pixel (y >> 1, x >> 1)
+  const int ups = p.upsample2x ? 1 : 0;
+  const int He = p.H << ups, We = p.W_ << ups;
+  const int tpx = We / Halo::PW, tpy = He / Halo::PH, tpi = tpx * tpy;   // patches per frame
+  const int tiles_m = (int)(p.M / ((int64_t)He * We)) * tpi;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_all = tiles_m * tiles_n;
   const int G = gridDim.x;
@@ -841,8 +851,8 @@ __global__ __launch_bounds__(32 * PH_, 2) void conv3x3_halo_kernel(const emo_gem
 #pragma unroll
     for (int i = 0; i < LH; i++) {
       const int iy = y0 + h_y[i], ix = x0 + h_x[i];
-      const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W_;
-      h_ptr[i] = ok ? A + (((int64_t)img * p.H + iy) * p.W_ + ix) * p.lda + h_klog[i] * V : zero;
+      const bool ok = iy >= 0 && iy < He && ix >= 0 && ix < We;
+      h_ptr[i] = ok ? A + (((int64_t)img * p.H + (iy >> ups)) * p.W_ + (ix >> ups)) * p.lda + h_klog[i] * V : zero;
       h_inc[i] = ok ? BK : 0;
     }
   };
@@ -931,7 +941,7 @@ __global__ __launch_bounds__(32 * PH_, 2) void conv3x3_halo_kernel(const emo_gem
     init_acc_bias<WTM, WTN>(acc, p.bias, (c_tile % tiles_n) * BN + wvn * 32 * WTN, half, p.N);   // zeros without a bias
     if (p.rowbias) {   // temb row bias (resnet.py:188): one row per frame, a patch lies inside one frame
       const int tm0 = c_tile / tiles_n;
-      const int64_t m0 = (int64_t)(tm0 / tpi) * p.H * p.W_;
+      const int64_t m0 = (int64_t)(tm0 / tpi) * He * We;
       const float* rb = p.rowbias + (m0 / p.rows_per_batch) * p.ld_rowbias;
       const int wnb = (c_tile % tiles_n) * BN + wvn * 32 * WTN;
 #pragma unroll
@@ -1012,14 +1022,14 @@ __global__ __launch_bounds__(32 * PH_, 2) void conv3x3_halo_kernel(const emo_gem
         // rewrites it only behind the next stage's barrier
         __builtin_amdgcn_s_barrier();
         // (rows of this wave's tile: patch rows (wvm*WTM + i)*2 + r/16, pixels r%16 - the linear-rows epilogue with a row pitch)
-        const int64_t wm0 = ((int64_t)img * p.H + y0 + wvm * WTM * 2) * p.W_ + x0;
+        const int64_t wm0 = ((int64_t)img * He + y0 + wvm * WTM * 2) * We + x0;
         const float no_ln[WTM] = {1.f, 1.f};
         const unsigned xb = lds_base + ((gc + 1) & 1) * Halo::HALO_BYTES;
         // (bias and the temb row bias are already in the accumulators)
         if (R != nullptr || p.out_scale != 1.0f)
-          epilogue_lds<T, WTM, WTN, NW, Halo::HALO_BYTES, false, false, true, false, Halo::PW>(acc, pe, wm0, wn0, wave, lane, xb, C, R, no_ln, p.W_);
+          epilogue_lds<T, WTM, WTN, NW, Halo::HALO_BYTES, false, false, true, false, Halo::PW>(acc, pe, wm0, wn0, wave, lane, xb, C, R, no_ln, We);
         else
-          epilogue_lds<T, WTM, WTN, NW, Halo::HALO_BYTES, false, false, false, false, Halo::PW>(acc, pe, wm0, wn0, wave, lane, xb, C, R, no_ln, p.W_);
+          epilogue_lds<T, WTM, WTN, NW, Halo::HALO_BYTES, false, false, false, false, Halo::PW>(acc, pe, wm0, wn0, wave, lane, xb, C, R, no_ln, We);
         staged = true;
       }
     }
@@ -1027,7 +1037,7 @@ __global__ __launch_bounds__(32 * PH_, 2) void conv3x3_halo_kernel(const emo_gem
 #pragma unroll
       for (int i = 0; i < WTM; i++) {
         const int y = y0 + (wvm * WTM + i) * 2 + (l31 >> 4), x = x0 + (l31 & 15);
-        const int64_t m = ((int64_t)img * p.H + y) * p.W_ + x;
+        const int64_t m = ((int64_t)img * He + y) * We + x;
         epilogue_row<T, WTN>(acc[i], pe, m, true, wn0, half, C, R);
       }
     }

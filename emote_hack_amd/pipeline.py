@@ -76,7 +76,7 @@ class EMOAnimationPipeline:
                         context_batch_size=1, context_schedule="uniform", audio_features=None, speed_embeddings=None, seed=0,
                         fusion_blocks="midup", dist=False, rank=0, world_size=1, return_eps=False, use_graphs=False,
                         controlnet=None, controlnet_cond=None, controlnet_conditioning_scale=1.0, reference_group=10,
-                        reference_lookahead=True, motion_latents=None):
+                        reference_lookahead=None, motion_latents=None):
         """Set up the loop state (EMOAnimationPipeline.py:628-696).  latents f32 (1,4,F_tot,h,w);
         ref_image_latents (1,4,h,w); text_embeddings (2,L,D) = [uncond, cond].
         reference_group = T: ReferenceNet timesteps computed per batched pass (1 = the reference's per-step order).
@@ -235,6 +235,12 @@ class EMOAnimationPipeline:
             if st.world_size not in self._bank_pg:   # once per pipeline (denoise_chained prepares per clip; new_group leaks a communicator)
                 self._bank_pg[st.world_size] = td.new_group(ranks=list(range(st.world_size)))
             st.bank_pg = self._bank_pg[st.world_size]
+        # look-ahead = group g+1's ReferenceNet pass on a second stream under group g's Backbone steps.  With world_size > 1 that
+        # pass carries an RCCL all_gather on its own communicator, concurrent with the per-step eps all_gather on the main
+        # stream - two collectives whose device-side start order can differ between ranks.  Off by default there (the pass
+        # then costs ~1 % on the main stream); pass reference_lookahead=True to overlap it anyway.
+        if reference_lookahead is None:
+            reference_lookahead = not (st.dist and st.world_size > 1)
         st.lookahead = bool(reference_lookahead) and dev.type == "cuda"
         st.side = torch.cuda.Stream() if st.lookahead else None
         # ControlNet branch (EMOAnimationPipeline.py:643-650,678-679,718-746): (F_tot,3,H,W) conditioning images in [0,1]

@@ -269,6 +269,27 @@ def test_conv3x3_halo_patch_heights(dtype, ph, n, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ph", [8, 16])
+@pytest.mark.parametrize("n,H,W,Cin,Cout", [(3, 8, 8, 128, 192), (2, 16, 8, 64, 320), (5, 4, 16, 192, 132)])
+def test_conv3x3_halo_upsample(dtype, ph, n, H, W, Cin, Cout):
+    """Upsample3D (resnet.py:74-82: F.interpolate(scale_factor=2, mode="nearest") -> conv 3x3) on the halo-reuse kernel: the
+    patch grid lives on the upsampled frame and a halo pixel (y, x) is read from source pixel (y >> 1, x >> 1) - the upsampled
+    tensor never exists.  Shapes whose upsampled frame is a multiple of the 8x16 / 16x16 patch; both patch heights."""
+    if ph == 16 and (2 * H) % 16:
+        pytest.skip("upsampled frame is not a multiple of the 16-row patch")
+    o = ops()
+    x = q(seeded_randn((n, Cin, H, W), 141), dtype)
+    wt, bias = q(seeded_randn((Cout, Cin, 3, 3), 142) / math.sqrt(9 * Cin), dtype), 0.1 * seeded_randn((Cout,), 143)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), wt, bias, padding=1)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous()
+    wp = wt.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)
+    got, Ho, Wo = o.conv3x3(rows.to(DEV).to(dtype), wp.to(DEV).to(dtype).contiguous(), bias.to(DEV), n, H, W, upsample2x=True, split_k=1,
+                            tile=1 if ph == 8 else 2)
+    assert (Ho, Wo) == (2 * H, 2 * W)
+    close(got, ref.permute(0, 2, 3, 1).reshape(-1, Cout), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("M,N,K,res", [(1000, 320, 320, True), (700, 640, 192, False), (513, 960, 64, True)])
 def test_gemm_every_tile_shape(dtype, tile, M, N, K, res):

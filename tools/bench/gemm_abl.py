@@ -1,18 +1,23 @@
-import sys, torch
-sys.path.insert(0, '.')
-from emote_hack_amd import ops as o
-dev='cuda'; dt=torch.bfloat16
-def run(M,N,K):
-    a = torch.randn(M,K,device=dev,dtype=dt); w = torch.randn(N,K,device=dev,dtype=dt)/30
-    f = lambda: o.gemm(a,w,None)
-    for _ in range(3): f()
-    torch.cuda.synchronize(); e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10): f()
-    e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1)/10*1e3
-    print(f"M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s", flush=True)
-run(8192,8192,8192)
-run(98304,2560,320)
-run(24576,640,2560)
-run(98304,320,320)
+"""Per-part ablation of the dense GEMM (variants built from tools/bench/patches/gemm_ablation.patch with -DEMO_GEMM_ABL=n:
+1 no LDS-DMA after a block's first stage, 2 no fragment reads after a stage's first k-step, 3 no epilogue, 4 = 1 + 2,
+5 = 4 without the per-stage barrier): python tools/bench/gemm_abl.py product lib1.so ...   (results are wrong by design)"""
+import os, subprocess, sys
+if len(sys.argv) > 1 and sys.argv[1] != "--child":
+    for lib in sys.argv[1:]:
+        env = dict(os.environ)
+        if lib != "product":
+            env["EMO_HIP_LIB"] = os.path.abspath(lib)
+        print(f"=== {lib}", flush=True)
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env)
+    sys.exit(0)
+sys.path.insert(0, ".")
+sys.path.insert(0, "tools/bench")
+from gemm_tiles import dense
+dense(8192, 8192, 8192, (4,))
+dense(98304, 2560, 320, (4,), geglu=True, ln=True)
+dense(24576, 5120, 640, (4,), geglu=True, ln=True)
+dense(6144, 10240, 1280, (4,), geglu=True, ln=True)
+dense(98304, 960, 320, (4,), ln=True)
+dense(98304, 320, 320, (3,), res=True)
+dense(24576, 640, 640, (2,), res=True)
+dense(6144, 1280, 1280, (2,), res=True)
