@@ -21,3 +21,8 @@ dense(98304, 960, 320, (4,), ln=True)
 dense(98304, 320, 320, (3,), res=True)
 dense(24576, 640, 640, (2,), res=True)
 dense(6144, 1280, 1280, (2,), res=True)
+dense(98304, 320, 1280, (3,), res=True)
+dense(24576, 640, 2560, (2,), res=True)
+dense(6144, 1280, 5120, (2,), res=True)
+dense(6144, 3840, 1280, (4,), ln=True)
+dense(24576, 1920, 640, (4,), ln=True)
