@@ -166,14 +166,32 @@ class EMOAnimationPipeline:
         mine = st.units[st.rank::st.world_size]
         st.n_slots = -(-len(st.units) // st.world_size)                    # units per rank, padded
         st.calls = []
-        for i in range(0, len(mine), len(st.branches) * cbs):
-            chunk = mine[i:i + len(st.branches) * cbs]
+        # which of the rank's units share a UNet call (a unit's SLOT - its place in the exchange buffer - stays its index in
+        # `mine`).  context_batch_size 1: the two branches of a window go together, [uncond, cond] - the reference's batch
+        # (:759-763), and the one whose halves share their prefix (unet._begin); units whose sibling lives on another rank are
+        # batched in pairs.  context_batch_size > 1: consecutive units, 2 * cbs per call.
+        if cbs == 1 and cfg:
+            byw = {}
+            for k, (w_, br) in enumerate(mine):
+                byw.setdefault(w_, {})[br] = k
+            chunks = [[byw[w_][0], byw[w_][1]] for w_ in sorted(byw) if len(byw[w_]) == 2]
+            singles = sorted((k for w_ in byw if len(byw[w_]) == 1 for k in byw[w_].values()), key=lambda k: (mine[k][1], k))
+            chunks += [singles[i:i + 2] for i in range(0, len(singles), 2)]
+        else:
+            n_per = len(st.branches) * cbs
+            chunks = [list(range(i, min(i + n_per, len(mine)))) for i in range(0, len(mine), n_per)]
+        for idxs in chunks:
+            chunk = [mine[k] for k in idxs]
             uc = [k for k, u in enumerate(chunk) if u[1] == 0]
             # one UNet call reads ONE bank (the row named by a device word): cond units are batched per bank variant
             for n_call, tv in enumerate(sorted({st.unit_tv[u] for u in chunk if u[1] == 1}, reverse=True) or [None]):
                 order = (uc if n_call == 0 else []) + [k for k, u in enumerate(chunk) if u[1] == 1 and st.unit_tv[u] == tv]
-                call = SimpleNamespace(units=[chunk[k] for k in order], slots=[i + k for k in order], bank_tv=tv)
+                call = SimpleNamespace(units=[chunk[k] for k in order], slots=[idxs[k] for k in order], bank_tv=tv)
                 call.n_uc = sum(1 for u in call.units if u[1] == 0)
+                # [uncond windows..., cond windows...] over the SAME windows in the same order: the two halves of the UNet batch
+                # carry identical latents and differ only from the first cross-attention on (unet._begin shares that prefix)
+                call.halves_identical = (call.n_uc * 2 == len(call.units) and call.n_uc > 0 and
+                                         [u[0] for u in call.units[:call.n_uc]] == [u[0] for u in call.units[call.n_uc:]])
                 call.idx = [torch.tensor(st.windows[w], dtype=torch.int64, device=dev) for w, _ in call.units]
                 st.calls.append(call)
         st.t_table = torch.tensor(st.timesteps, dtype=torch.int64, device=dev)   # INT timestep table, bit-exact
@@ -393,7 +411,8 @@ class EMOAnimationPipeline:
         bank_tv = call.bank_tv if call.bank_tv is not None else st.bank_variants[0]
         st.reader.set_projected_banks(st.kv_all[bank_tv], st.bank_idx, call.n_uc)               # replaces reader.update (:774)
         rows = self.unet(x, st.t_buf, encoder_hidden_states=call.ctx, speed_embeddings=call.speed, return_dict=False,
-                         _return_rows=True, _ctx_kv=call.ctx_kv, **self._controlnet_residuals(st, call))   # :777-786
+                         _return_rows=True, _ctx_kv=call.ctx_kv, _halves_identical=call.halves_identical,
+                         **self._controlnet_residuals(st, call))   # :777-786
         n_rows = st.nf * st.HW
         for k, slot in enumerate(call.slots):
             st.send[slot].copy_(rows[k * n_rows:(k + 1) * n_rows])

@@ -46,6 +46,8 @@ def _round_up(x, m):
 # ln_stats): a read-only statistics pass replaces LayerNorm's read + write and the GEMM reads the raw tokens.  The one exception is the LN1 of a block
 # whose output is WRITTEN to a reference bank (mutual_self_attention.py:230): that tensor has to exist.
 FOLD_LAYERNORM = True
+# The two halves of a classifier-free-guidance batch share everything up to the first cross-attention (see _begin): computed once.
+SHARE_CFG_PREFIX = True
 
 
 class _Ctx:
@@ -382,14 +384,28 @@ class UNet3DConditionModel:
         tb = prefix + ".transformer_blocks.0"
         return self._kv(bank_rows, self._w[tb + ".attn1.k"], self._w[tb + ".attn1.v"], L)
 
-    def _transformer(self, a, x, ctx_rows, ctx_len, ctx_div, c: _Ctx, H, W, out=None, ctx_kv=None):
-        """attention.py:112-161 + 276-320, and the write/read hooks of mutual_self_attention.py:199-284."""
+    @staticmethod
+    def _dup_rows(xh):
+        """[x; x]: the two halves of a classifier-free-guidance batch after their shared prefix (two strided row copies)."""
+        y = torch.empty(2 * xh.shape[0], xh.shape[1], device=xh.device, dtype=xh.dtype)
+        ops.copy_cols(xh, y[:xh.shape[0]], 0)
+        ops.copy_cols(xh, y[xh.shape[0]:], 0)
+        return y
+
+    def _transformer(self, a, x, ctx_rows, ctx_len, ctx_div, c: _Ctx, H, W, out=None, ctx_kv=None, shared_half=False):
+        """attention.py:112-161 + 276-320, and the write/read hooks of mutual_self_attention.py:199-284.
+        shared_half: x holds the FIRST half of the batch only and the second half is identical (a [uncond, cond] batch before its
+        first cross-attention): GroupNorm, proj_in, LN1, q|k / V^T, self-attention and its output projection run on those rows,
+        the result is duplicated in front of the cross-attention (c describes the FULL batch)."""
         w, p = self._w, a.prefix
         tb = p + ".transformer_blocks.0"
         C_, heads = a.channels, a.heads
         d = C_ // heads
         HW, nb = H * W, c.B * c.F
         scale = d ** -0.5
+        nb_full = nb
+        if shared_half:
+            nb = nb // 2
         h = ops.group_norm(x, w[p + ".norm.g"], w[p + ".norm.b"], nb, self.config["norm_num_groups"], 1e-6, False)
         h = ops.gemm(h, w[p + ".proj_in.w"], w[p + ".proj_in.b"])
         # --- self attention (+ reference bank)
@@ -423,6 +439,8 @@ class UNet3DConditionModel:
                 kw = dict(k1=kb, v1t=vbt, Lk1=Lb, seg1_div=c.F, seg1_first_batch=c.uc_batches, seg1_skip=c.bank_skip)
         att = ops.attention(qk[:, :C_], qk[:, C_:], vt, HW, B=nb, Lq=HW, heads=heads, d=d, scale=scale, **kw)
         h = ops.gemm(att, w[tb + ".attn1.o.w"], w[tb + ".attn1.o.b"], residual=h)
+        if shared_half:     # the halves part ways at the text / audio cross-attention
+            h, x, nb = self._dup_rows(h), self._dup_rows(x), nb_full
         # --- cross attention to the text / audio context
         if self._fold_ln:
             wq, cs, bq = w[tb + ".attn2.q_ln"]
@@ -486,7 +504,8 @@ class UNet3DConditionModel:
     # ------------------------------------------------------------------ forward (three stages so that the sampler can
     # overlap the ReferenceNet pass with the bank-independent down path on a second HIP stream)
     def _begin(self, sample, timestep, encoder_hidden_states, audio_features=None, speed_embeddings=None,
-               down_block_additional_residuals=None, mid_block_additional_residual=None, add_after_conv_in=None, _ctx_kv=None):
+               down_block_additional_residuals=None, mid_block_additional_residual=None, add_after_conv_in=None, _ctx_kv=None,
+               halves_identical=False):
         if self._w is None:
             absent = self._absent_keys()
             raise EmoHipError("UNet3DConditionModel: weights not loaded / model not on a HIP device "
@@ -543,7 +562,23 @@ class UNet3DConditionModel:
         # into its LEFT columns - the concatenation never runs.  (ControlNet residuals re-materialise the skips: old path.)
         s.zero_copy = down_block_additional_residuals is None and len(self.spec.up) > 0
         s.skips, s.n_pushed = [], 0
-        s.x, _, _ = ops.conv3x3(x, w["conv_in.w"], w["conv_in.b"], B * F, H, W, out=self._skip_slot(s, B * F * H * W, self.spec.down[0].resnets[0].cin))
+        # SHARED PREFIX under classifier-free guidance (the sampler's [uncond, cond] batch, EMOAnimationPipeline.py:759-763): the two
+        # halves of the batch carry the SAME latents, timestep and (speed) embedding and differ only from the first text
+        # cross-attention on - conv_in, the first resnet and the first transformer up to and including its self-attention
+        # output projection (no reference bank in the down path under fusion_blocks="midup") are computed ONCE on half the rows
+        # and duplicated.  Same arithmetic, half the rows: ~0.8 ms of the 44 ms step (a 64x64-level self-attention alone is 0.45).
+        s.dup = SHARE_CFG_PREFIX and bool(halves_identical) and B % 2 == 0 and add_after_conv_in is None and speed_embeddings is None
+        s.x_half = None
+        if s.dup:
+            Mh = (B // 2) * F * H * W
+            s.x_half, _, _ = ops.conv3x3(x[:Mh], w["conv_in.w"], w["conv_in.b"], (B // 2) * F, H, W)
+            s.x = self._skip_slot(s, B * F * H * W, self.spec.down[0].resnets[0].cin)
+            if s.x is None:
+                s.x = torch.empty(B * F * H * W, s.x_half.shape[1], device=dev, dtype=dtp)
+            ops.copy_cols(s.x_half, s.x[:Mh], 0)
+            ops.copy_cols(s.x_half, s.x[Mh:], 0)
+        else:
+            s.x, _, _ = ops.conv3x3(x, w["conv_in.w"], w["conv_in.b"], B * F, H, W, out=self._skip_slot(s, B * F * H * W, self.spec.down[0].resnets[0].cin))
         if add_after_conv_in is not None:   # ControlNet: sample += controlnet_cond_embedding(cond) (controlnet.py:523-525)
             s.x = ops.add(s.x, add_after_conv_in)
         self._push_skip(s, s.x, (H, W))
@@ -580,9 +615,23 @@ class UNet3DConditionModel:
     def _run_down(self, s):
         w, spec, dtp, dev = self._w, self.spec, self.dtype, self.device
         x, c, h_, w_ = s.x, s.c, s.h, s.w
+        first = True
         for blk in spec.down:
             for r, a, mo in zip(blk.resnets, blk.attentions, blk.motions):
                 slot = self._skip_slot(s, x.shape[0], r.cout)          # the sub-block's last op writes the skip in place
+                # the shared prefix of a [uncond, cond] batch (see _begin): first resnet + first transformer's self-attention
+                # half on B / 2 rows; not when that transformer reads or writes a reference bank (fusion_blocks="full")
+                dup = first and s.dup and a is not None and not a.gutted and not (c.bank_mode is not None and a.prefix in c.active)
+                first = False
+                if dup:
+                    ch = _Ctx(c.B // 2, c.F, c.H, c.W)
+                    xh = self._resnet(r, s.x_half, s.temb_all[:c.B // 2], ch, h_, w_)
+                    x = self._transformer(a, xh, s.ctx_rows, s.ctx_len, s.ctx_div, c, h_, w_, out=slot if mo is None else None, ctx_kv=s.ctx_kv,
+                                          shared_half=True)
+                    if mo is not None:
+                        x = self._motion(mo, x, c, h_, w_, out=slot)
+                    self._push_skip(s, x, (h_, w_))
+                    continue
                 x = self._resnet(r, x, s.temb_all, c, h_, w_, out=slot if (a is None and mo is None) else None)
                 if a is not None:
                     x = self._transformer(a, x, s.ctx_rows, s.ctx_len, s.ctx_div, c, h_, w_, out=slot if mo is None else None, ctx_kv=s.ctx_kv)
@@ -657,7 +706,8 @@ class UNet3DConditionModel:
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None,
                 down_block_additional_residuals: Optional[Tuple[torch.Tensor]] = None,
                 mid_block_additional_residual: Optional[torch.Tensor] = None, return_dict: bool = True,
-                audio_features=None, speed_embeddings=None, _return_rows=False, _ctx_kv=None) -> Union[UNet3DConditionOutput, Tuple]:
+                audio_features=None, speed_embeddings=None, _return_rows=False, _ctx_kv=None,
+                _halves_identical=False) -> Union[UNet3DConditionOutput, Tuple]:
         """unet_controlnet.py:328-483.  sample (B,C,F,h,w); timestep Tensor|int|float;
         encoder_hidden_states (B|B*F, L, D).  EMO extension kwargs (EMOAnimationPipeline.py:783-784):
         audio_features (B*F, L_a, D) per-frame attn2 context; speed_embeddings (B, 4*C0) added to emb."""
@@ -666,7 +716,8 @@ class UNet3DConditionModel:
         if class_labels is not None:
             raise NotImplementedError("class embeddings are outside the hot path")
         s = self._begin(sample, timestep, encoder_hidden_states, audio_features, speed_embeddings,
-                        down_block_additional_residuals, mid_block_additional_residual, _ctx_kv=_ctx_kv)
+                        down_block_additional_residuals, mid_block_additional_residual, _ctx_kv=_ctx_kv,
+                        halves_identical=_halves_identical)
         if self._reference_control is not None:
             self._reference_control._prepare(s.c, self)
         self._run_down(s)

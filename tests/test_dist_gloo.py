@@ -50,7 +50,7 @@ class OracleBackedUNet:
         return rows, rows.new_zeros(rows.shape[0] // L, 1, 1)
 
     def __call__(self, sample, timestep, encoder_hidden_states, return_dict=False, _return_rows=False, audio_features=None,
-                 speed_embeddings=None, _ctx_kv=None):
+                 speed_embeddings=None, _ctx_kv=None, _halves_identical=False):
         from oracle import unet_ref as U
         rc = self._reference_control
         if sample.dim() == 4:

@@ -154,6 +154,12 @@ def test_cfg4_48_frames_four_windows_full_size(cfg2_models):
         equals the eps of the 12-frame single-window run on the same frames, and under the deterministic DDIM sampler so do the
         latents after two steps (the DDPM noise is keyed by the element index of the whole clip, so it differs by construction)."""
     unet, ref = cfg2_models
+    from emote_hack_amd.pipeline import EMOAnimationPipeline
+    from emote_hack_amd import DDPMScheduler
+    st = EMOAnimationPipeline(unet=unet, scheduler=DDPMScheduler()).prepare_denoise(
+        seeded_randn((1, 4, 48, 64, 64), 1).to(DEV), seeded_randn((1, 4, 64, 64), 3), seeded_randn((2, 77, 768), 2), appearance_encoder=ref,
+        num_inference_steps=50, context_frames=12, context_overlap=0)
+    assert [c.units for c in st.calls] == [[(w, 0), (w, 1)] for w in range(4)] and all(c.halves_identical for c in st.calls)
     lat_e, eps_e = _run_loop(unet, ref, 2, graphs=False, ref_group=2, frames=48)
     lat_g, eps_g = _run_loop(unet, ref, 2, graphs=True, ref_group=2, frames=48)
     assert lat_e.shape == (1, 4, 48, 64, 64) and bool(torch.isfinite(lat_e).all())

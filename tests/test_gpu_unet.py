@@ -225,6 +225,23 @@ def test_denoise_loop_multi_gpu_code_path_single_rank(graphs):
         td.destroy_process_group()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_shared_prefix_of_a_cfg_batch_is_the_same_forward(dtype):
+    """The sampler's [uncond, cond] batch carries the same latents in both halves (EMOAnimationPipeline.py:759-763) and the two
+    rows differ only from the first text cross-attention on: with _halves_identical the UNet runs conv_in, the first resnet and
+    the first transformer's self-attention half ONCE on B / 2 rows and duplicates the result.  Same arithmetic - the outputs
+    must agree with the plain forward (f32: to rounding of a different GEMM tile plan; bf16: to a bf16 ulp of the activations)."""
+    x, ctx = cases.tiny_inputs(1, 4)
+    x2 = x.repeat(2, 1, 1, 1, 1)
+    ctx2 = torch.cat([ctx, seeded_randn(tuple(ctx.shape), 77)])
+    m = build(cases.TINY_MOTION, dtype)
+    y_plain = m(x2.to(DEV), 961, ctx2.to(DEV)).sample.float()
+    y_dup = m(x2.to(DEV), 961, ctx2.to(DEV), _halves_identical=True).sample.float()
+    assert float((y_plain[0] - y_plain[1]).abs().max()) > 1e-3          # the two rows do differ (different text)
+    tol = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(y_dup, y_plain, **tol)
+
+
 def test_pipeline_call_signature_and_errors():
     from emote_hack_amd import DDIMScheduler
     from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
