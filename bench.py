@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--mode", default="weak", choices=["weak", "strong"],
                     help="weak: a 12-frame window per GPU (12*N frames); strong: BASELINE configs[3], one 48-frame clip = 8 units over N GPUs")
     ap.add_argument("--spawn-check", action="store_true", help="only prove that N ranks start (gloo, no GPU needed)")
+    ap.add_argument("--share-gpu", action="store_true", help="validation on a 1-GPU box: every rank on cuda:0, exchange through gloo "
+                                                             "(RCCL takes one device per rank) - the number is NOT a multi-GPU measurement")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -207,13 +209,18 @@ def main():
         return spawn_check(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if a.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = world > 1
     if dist:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("nccl", device_id=dev)
+        if a.share_gpu:
+            td.init_process_group("gloo")
+        else:
+            td.init_process_group("nccl", device_id=dev)
 
     from emote_hack_amd import DDPMScheduler, ops
     from emote_hack_amd.pipeline import EMOAnimationPipeline
@@ -288,7 +295,7 @@ def main():
         out = {
             "metric": "denoised frames/s (512x512, 50-step DDPM)", "value": fps, "unit": "frames/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": a.mode,
-            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic" if not a.share_gpu else "synthetic; --share-gpu: ranks time-share ONE GPU over gloo (logic validation, not a multi-GPU number)",
             "config": {"workload": ("cfg2: 512x512 latents 64x64, 12-frame window per GPU, 50-step DDPM, CFG 7.5 (uc+c batched), "
                                     if a.mode == "weak" else
                                     "cfg4 (BASELINE configs[3]): 512x512 latents 64x64, ONE 48-frame clip = 4 windows of 12 x 2 CFG branches "

@@ -1,0 +1,37 @@
+"""SURVEY 8(e) on the GPU box: world_size 2 / 3 runs of the product loop with the real HIP kernels.  The box has ONE MI355X and
+RCCL takes one device per rank, so the ranks share cuda:0 and exchange through gloo (tests/dist_gpu_worker.py); the RCCL
+transport itself is measured by the driver's multi-GPU bench.  Targets: the reference-generated loop goldens."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(world, *args):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), *map(str, args)],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+# (world, golden prefix, graphs, reference_group, look-ahead stream, context_batch_size, guidance_scale)
+@pytest.mark.parametrize("world,kind,graphs,ref_group,lookahead,cbs,gs", [
+    (2, "ddpm", 1, 2, 1, 1, 7.5),        # 3 windows = 6 units over 2 ranks, two ReferenceNet groups, look-ahead next to the collectives
+    (2, "ddim", 0, 10, 0, 1, 7.5),
+    (3, "ddpm", 1, 1, 0, 1, 7.5),        # uneven deal, per-step ReferenceNet order, one timestep per group dealt over 3 ranks
+    (4, "ddim", 1, 10, 0, 1, 7.5),       # more ranks than a rank's fair share: 6 units over 4 ranks (slots padded)
+    (2, "ddim_cbs2", 1, 10, 0, 2, 7.5),  # literal context_batch_size > 1 pairing: two ReferenceNet variants exchanged
+    (2, "ddim_nocfg", 1, 10, 0, 1, 1.0),
+])
+def test_multi_rank_loop_with_hip_kernels_matches_the_loop_goldens(world, kind, graphs, ref_group, lookahead, cbs, gs):
+    _run(world, kind, graphs, ref_group, lookahead, cbs, gs)
