@@ -116,14 +116,18 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
   // ---- zero the whole ring once: V^T pad rows (n >= d) are never written by the loader and must be 0
   // ... except V^T row d, which is all ONES when the head dim leaves a pad row (d < NT*32: 40, 80): row d of O^T = V^T P^T
   // is then the softmax denominator sum_k P[q][k], accumulated by the matrix pipe instead of 32 VALU adds per tile
+  // Only the V^T PAD rows need it: every K chunk and every V^T row < d is rewritten by the loader for each tile (pad chunks from
+  // the zero page), so the prologue touches (NT*32 - d) rows per slot instead of the whole ring - it was 48 KB of LDS stores per
+  // block, a visible share of the two-tile launches against the 77-key text context.
   const bool ones_row = d < NT * 32;
   {
-    const int ones_begin = K_CHUNKS * 16 + d * VROW, ones_end = ones_begin + VCH * 16;
+    const int pad_begin = K_CHUNKS * 16 + d * VROW, pad_bytes = (NT * 32 - d) * VROW;    // rows d .. NT*32-1 of the V^T region
+    const int ones_end = pad_begin + VCH * 16;
     const unsigned one_bits = OnesBits<T>::value;
-    for (int i = tid * 16; i < NSR * stage_bytes; i += ATT_THREADS * 16) {
-      const int off = i % stage_bytes;
-      const unsigned v = (ones_row && off >= ones_begin && off < ones_end) ? one_bits : 0u;
-      *(uint4*)(smem + i) = make_uint4(v, v, v, v);
+    for (int i = tid * 16; i < NSR * pad_bytes; i += ATT_THREADS * 16) {
+      const int slot = i / pad_bytes, off = pad_begin + (i - slot * pad_bytes);
+      const unsigned v = (ones_row && off < ones_end) ? one_bits : 0u;
+      *(uint4*)(smem + slot * stage_bytes + off) = make_uint4(v, v, v, v);
     }
   }
 
