@@ -359,6 +359,31 @@ def test_gemm_layernorm_fold(dtype, tile, M, N, K, mode):
     torch.testing.assert_close(got.float().cpu(), y, rtol=tol["rtol"], atol=tol["atol"] * (2.0 if dtype != torch.float32 else 1.0))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("ln", [False, True])
+@pytest.mark.parametrize("M,L,N,K", [(512, 128, 200, 96), (1088, 64, 320, 320), (4096 + 64, 4096 + 64, 64, 64)])
+def test_gemm_transposed_store_whole_tile_batches(dtype, ln, M, L, N, K):
+    """V^T outputs whose batches are whole multiples of the 64-row tile (the UNet's case: L = H*W): ragged N, several batches, a
+    batch longer than one tile, with and without the LayerNorm fold.  (An LDS-staged transposed store - full 128-byte lines per
+    V^T row instead of 8-byte column pieces - was measured on these shapes: 79.0 -> 74.5 us at M=98304 N=K=320, nothing at the
+    smaller levels; not kept.)"""
+    o = ops()
+    x = q(seeded_randn((M, K), 180) + (2.0 * seeded_randn((M, 1), 181) if ln else 0), dtype)
+    wt, bias = seeded_randn((N, K), 182) / math.sqrt(K), 0.1 * seeded_randn((N,), 183)
+    a = x.to(DEV).to(dtype)
+    if ln:
+        gamma, beta = 1 + 0.2 * seeded_randn((K,), 184), 0.2 * seeded_randn((K,), 185)
+        ref = F.linear(F.layer_norm(x, (K,), gamma, beta), q(wt, dtype), bias)
+        wp, cs, bp = _ln_fold(wt, bias, gamma, beta, dtype)
+        got = o.gemm(a, wp.to(DEV).contiguous(), bp.to(DEV), ln=(cs.to(DEV).contiguous(), o.layer_norm_stats(a, 1e-5)), transpose_rows=L, transpose_ld=L)
+    else:
+        ref = F.linear(x, q(wt, dtype), bias)
+        got = o.gemm(a, q(wt, dtype).to(DEV).to(dtype), bias.to(DEV), transpose_rows=L, transpose_ld=L)
+    assert tuple(got.shape) == (M // L, N, L)
+    tol = TOL[dtype]
+    torch.testing.assert_close(got.float().cpu().permute(0, 2, 1).reshape(M, N), ref, rtol=tol["rtol"], atol=tol["atol"] * (2.0 if ln else 1.0))
+
+
 def attn_ref(qh, k, v, scale):
     s = torch.matmul(qh, k.transpose(-1, -2)) * scale
     return torch.matmul(s.softmax(-1), v)
