@@ -414,10 +414,12 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
   // With n fastest that is one tile row - one A panel shared by all, but tiles_n DIFFERENT W panels, each used by one CU:
   // at N = 8192 the XCD's L2 hit rate was 48 % (A hits, W misses), VMEM latency 1160 cycles, 37 % of the wave cycles parked
   // in s_waitcnt (hipBLASLt on the same shape: 80 %, 450 cycles, 5 %).  Bands of gm tile rows with m fastest inside a band
-  // make the concurrent set a gm x (32 * BPC / gm) block: 4 + 8 panels instead of 1 + 32.  Narrow outputs (tiles_n <= 12) keep
+  // make the concurrent set a gm x (32 * BPC / gm) block: 4 + 8 panels instead of 1 + 32.  Narrow outputs (tiles_n < 5) keep
   // n fastest - their concurrent set already spans several rows.  (p.tile >> 4 overrides gm: tools/bench.)
   const int gm_hint = (p.tile >> 4) & 15;
-  const int gm = gm_hint > 0 ? gm_hint : (tiles_n > 12 ? (Tile::BPC >= 2 ? 8 : 4) : 1);
+  // (bands of 4 already from 5 column tiles on: -3 % at M=98304 N=2560 K=320 GEGLU, -2..3 % at N=640 K=2560 / N=1280 K=5120,
+  // neutral on the square projections - tools/bench/gemm_gm_sweep.py)
+  const int gm = gm_hint > 0 ? gm_hint : (tiles_n > 12 ? (Tile::BPC >= 2 ? 8 : 4) : (tiles_n >= 5 ? 4 : 1));
   auto tile_mn = [&](int t, int& tm, int& tn) {
     if (gm <= 1) { tm = t / tiles_n; tn = t - tm * tiles_n; return; }
     const int per = gm * tiles_n, g = t / per, r = t - g * per, m0 = g * gm;
@@ -719,7 +721,16 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
     // contiguous elements of V^T: Ct[m / t_rows][n][m % t_rows] -> one 8-byte (bf16) / 16-byte (f32) store per quad
     const bool quad_ok = (p.t_rows & 3) == 0 && (p.t_ld & 3) == 0 && (p.t_batch_stride & 3) == 0;
 #pragma unroll
-    for (int i = 0; i < WTM; i++)
+    for (int i = 0; i < WTM; i++) {
+      // LayerNorm fold: the statistics of row 8g + 4half + e live in lane (row) of this wave - fetched with EVERY lane active,
+      // before the column mask below (a lane masked off for n >= N is the SOURCE of other lanes' shuffles: in a ragged last N
+      // tile the valid columns read rstd from inactive lanes - wrong V^T columns whenever N is not a multiple of the tile)
+      float rr_all[16];
+#pragma unroll
+      for (int r_ = 0; r_ < 16; r_++) {
+        if constexpr (LN) rr_all[r_] = __shfl(ln_rstd[i], 8 * (r_ >> 2) + 4 * half + (r_ & 3), 64);
+        else rr_all[r_] = 1.f;
+      }
 #pragma unroll
       for (int j = 0; j < WTN; j++) {
         const int n = wn0 + j * 32 + l31;
@@ -728,12 +739,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
 #pragma unroll
         for (int g = 0; g < 4; g++) {
           const int64_t m0 = wm0 + i * 32 + 8 * g + 4 * half;
-          float rrstd[4];   // LayerNorm fold: the statistics of rows 8g + 4half + e live in lane (row) of this wave
+          float rrstd[4];
 #pragma unroll
-          for (int e = 0; e < 4; e++) {
-            if constexpr (LN) rrstd[e] = __shfl(ln_rstd[i], 8 * g + 4 * half + e, 64);
-            else rrstd[e] = 1.f;
-          }
+          for (int e = 0; e < 4; e++) rrstd[e] = rr_all[4 * g + e];
           if (m0 >= p.M) continue;
           if (nsplit > 1) {
 #pragma unroll
@@ -764,6 +772,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
           }
         }
       }
+    }
   }
   }   // tiles of this block
 }
