@@ -187,6 +187,7 @@ def main():
     ap.add_argument("--ref-group", type=int, default=REF_GROUP, help="ReferenceNet timesteps per batched pass")
     ap.add_argument("--no-ln-fold", action="store_true", help="A/B: explicit LayerNorm launches instead of the GEMM fold")
     ap.add_argument("--no-shared-prefix", action="store_true", help="A/B: compute the shared prefix of the [uncond, cond] batch for both halves")
+    ap.add_argument("--no-fused-tail", action="store_true", help="A/B: ff.net.2 and proj_out as two GEMMs instead of one over [g | h]")
     ap.add_argument("--mode", default="weak", choices=["weak", "strong"],
                     help="weak: a 12-frame window per GPU (12*N frames); strong: BASELINE configs[3], one 48-frame clip = 8 units over N GPUs")
     ap.add_argument("--spawn-check", action="store_true", help="only prove that N ranks start (gloo, no GPU needed)")
@@ -233,6 +234,9 @@ def main():
     if a.no_shared_prefix:
         from emote_hack_amd import unet as unet_mod
         unet_mod.SHARE_CFG_PREFIX = False
+    if a.no_fused_tail:
+        from emote_hack_amd import unet as unet_mod
+        unet_mod.FUSE_FF_TAIL = False
     unet, ref = build_models(dev, dtype)
     F_WIN = 12
     f_tot = F_WIN * world if a.mode == "weak" else 4 * F_WIN       # strong: BASELINE configs[3] - 48 frames = 4 windows

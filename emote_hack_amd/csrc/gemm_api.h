@@ -57,8 +57,13 @@ static GemmPlan plan_gemm(int64_t M, int N, int K, int dtype, int geglu, int tra
   // long-K shapes (every conv) stay on 128-row tiles + split-K.  V^T outputs also take them: the column-per-lane
   // store of the transposed epilogue is cheaper from 32x32 wave tiles (measured 91 -> 59 us at M=98304 N=K=320).
   const int64_t blocks128 = ((M + 127) / 128) * ((N + (nt5 ? 159 : 127)) / (nt5 ? 160 : 128));
-  const bool small = !big && !geglu && nk <= 24 && (blocks128 < 256 || transpose_out);
-  pl.tile = big ? EMO_TILE_256x256 : (small ? EMO_TILE_64x64 : (nt5 ? EMO_TILE_128x160 : EMO_TILE_128x128));
+  // (nk <= 40: M=1536 N=1280 K=2560 27 us on 64x64 tiles against 32 split 4 ways on 128x128, tools/bench/conv_split_sweep.py)
+  const bool small = !big && !geglu && (nk <= 24 || (nk <= 40 && blocks128 < 256)) && (blocks128 < 256 || transpose_out);
+  // few tiles and a LONG K (the 8x8-level 3x3 convs through the im2col loader: M = 1536, K = 11520 / 23040): 256x256 tiles
+  // split 256 / tiles ways - the same block count as 128x128 tiles split 4 ways at half the LDS-DMA traffic per MFMA
+  // (85 vs 105 us at Cin 1280, 132 vs 172 us at Cin 2560; M = 640, the ReferenceNet group: 55 vs 75)
+  const bool deep = !big && !small && dtype != EMO_F32 && !ln && !geglu && !transpose_out && nk >= 128 && tiles256 * 4 <= 256 && N % 4 == 0;
+  pl.tile = big || deep ? EMO_TILE_256x256 : (small ? EMO_TILE_64x64 : (nt5 ? EMO_TILE_128x160 : EMO_TILE_128x128));
   // (256x160 / 256x320 tiles exist behind the hint: on the UNet's shapes they measured SLOWER than the 128-row tiles - 342 /
   // 250 vs 351 TFLOP/s at M=98304 N=K=320, 576 / 732 vs 696-725 at M=24576 N=640 K=2560 - one block per CU leaves the
   // epilogue uncovered, which costs more than the lighter LDS-DMA stream saves; the planner does not pick them)
@@ -74,7 +79,11 @@ static GemmPlan plan_gemm(int64_t M, int N, int K, int dtype, int geglu, int tra
   const int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
   const int64_t slots = 512;                      // co-resident blocks to aim at
   int s = 1;
-  if (!ln && bm <= 128 && tiles * 2 <= slots && nk >= 8 && N % 4 == 0) {
+  if (deep && hint <= 0) {
+    s = (int)(256 / tiles);                       // one block per CU
+    if (s > nk / 4) s = nk / 4;
+    if (s > 32) s = 32;
+  } else if (!ln && bm <= 128 && tiles * 2 <= slots && nk >= 8 && N % 4 == 0) {
     s = (int)(slots / tiles);                     // whole blocks only: one block more than the slots costs a second round
     const int max_by_k = nk / 4;                  // keep >= 4 stages per slice
     if (s > max_by_k) s = max_by_k;

@@ -48,6 +48,11 @@ def _round_up(x, m):
 FOLD_LAYERNORM = True
 # The two halves of a classifier-free-guidance batch share everything up to the first cross-attention (see _begin): computed once.
 SHARE_CFG_PREFIX = True
+# ff.net.2 and proj_out as ONE GEMM over K = 4C + C: (g W2^T + b2 + h) Wo^T + bo + x = [g | h] [Wo W2 | Wo]^T + (Wo b2 + bo) + x.
+# The GEGLU output g and the residual stream h are written side by side into one (rows, 5C) buffer by their producers, so the
+# concatenated operand is a plain row view: the (rows, C) intermediate is neither written nor re-read, one launch less per
+# transformer / motion module (attention.py:154-161,316-320, motion_module.py:215-227,322-334).
+FUSE_FF_TAIL = True
 
 
 class _Ctx:
@@ -231,6 +236,14 @@ class UNet3DConditionModel:
             return geglu_rows(wp).contiguous(), geglu_rows(cs).contiguous(), geglu_rows(bp).contiguous()
 
         fold = self._fold_ln = bool(FOLD_LAYERNORM)
+        self._fuse_tail = bool(FUSE_FF_TAIL)
+
+        def ff_tail(ff2, proj_out):
+            """([Wo W2 | Wo] in the compute dtype, Wo b2 + bo) - products formed in f32, rounded once."""
+            wo = m[proj_out + ".weight"].float()
+            wo = wo.reshape(wo.shape[0], -1)
+            w2, b2 = m[ff2 + ".weight"].float(), m[ff2 + ".bias"].float()
+            return torch.cat([wo @ w2, wo], 1).to(dtp).contiguous(), (wo @ b2 + m[proj_out + ".bias"].float()).contiguous()
 
         def geglu(prefix):  # interleave (32 value, 32 gate)
             wt, b = m[prefix + ".weight"], m[prefix + ".bias"]
@@ -285,6 +298,8 @@ class UNet3DConditionModel:
                 w[tb + ".attn2.v"] = lin(tb + ".attn2.to_v.weight")
                 w[tb + ".attn2.o.w"], w[tb + ".attn2.o.b"] = lin(tb + ".attn2.to_out.0.weight"), f32(tb + ".attn2.to_out.0.bias")
                 w[tb + ".ff2.w"], w[tb + ".ff2.b"] = lin(tb + ".ff.net.2.weight"), f32(tb + ".ff.net.2.bias")
+                if self._fuse_tail:
+                    w[tb + ".tail.w"], w[tb + ".tail.b"] = ff_tail(tb + ".ff.net.2", p + ".proj_out")
                 if fold:
                     w[tb + ".attn1.qk_ln"] = ln_fold(torch.cat([m[tb + ".attn1.to_q.weight"], m[tb + ".attn1.to_k.weight"]], 0), None, tb + ".norm1")
                     w[tb + ".attn1.v_ln"] = ln_fold(m[tb + ".attn1.to_v.weight"], None, tb + ".norm1")
@@ -320,6 +335,8 @@ class UNet3DConditionModel:
                     w[tb + ".ff_norm.g"], w[tb + ".ff_norm.b"] = f32(tb + ".ff_norm.weight"), f32(tb + ".ff_norm.bias")
                     w[tb + ".ff1.w"], w[tb + ".ff1.b"] = geglu(tb + ".ff.net.0.proj")
                 w[tb + ".ff2.w"], w[tb + ".ff2.b"] = lin(tb + ".ff.net.2.weight"), f32(tb + ".ff.net.2.bias")
+                if self._fuse_tail:
+                    w[tb + ".tail.w"], w[tb + ".tail.b"] = ff_tail(tb + ".ff.net.2", p + ".proj_out")
             if blk.sampler:
                 w[blk.sampler + ".w"], w[blk.sampler + ".b"] = conv3(blk.sampler + ".conv.weight"), f32(blk.sampler + ".conv.bias")
         w["temb_all.w"] = torch.cat(temb_w, 0).to(dtp).contiguous()
@@ -453,16 +470,26 @@ class UNet3DConditionModel:
         else:
             kc, vct = self._kv(ctx_rows, w[tb + ".attn2.k"], w[tb + ".attn2.v"], ctx_len)
         att = ops.attention(q2, kc, vct, ctx_len, B=nb, Lq=HW, heads=heads, d=d, scale=scale, seg0_div=ctx_div)
-        h = ops.gemm(att, w[tb + ".attn2.o.w"], w[tb + ".attn2.o.b"], residual=h)
+        gh, g_out, h_out = self._tail_buffer(h, C_)
+        h = ops.gemm(att, w[tb + ".attn2.o.w"], w[tb + ".attn2.o.b"], residual=h, out=h_out)
         # --- GEGLU feed-forward
         if self._fold_ln:
             wf, cs, bf = w[tb + ".ff1_ln"]
-            g = ops.gemm(h, wf, bf, geglu=True, ln=(cs, ops.layer_norm_stats(h, LN_EPS)))
+            g = ops.gemm(h, wf, bf, geglu=True, ln=(cs, ops.layer_norm_stats(h, LN_EPS)), out=g_out)
         else:
             n3 = ops.layer_norm(h, w[tb + ".norm3.g"], w[tb + ".norm3.b"])
-            g = ops.gemm(n3, w[tb + ".ff1.w"], w[tb + ".ff1.b"], geglu=True)
+            g = ops.gemm(n3, w[tb + ".ff1.w"], w[tb + ".ff1.b"], geglu=True, out=g_out)
+        if gh is not None:      # ff.net.2 + residual + proj_out + residual in one pass over [g | h]
+            return ops.gemm(gh, w[tb + ".tail.w"], w[tb + ".tail.b"], residual=x, out=out)
         h = ops.gemm(g, w[tb + ".ff2.w"], w[tb + ".ff2.b"], residual=h)
         return ops.gemm(h, w[p + ".proj_out.w"], w[p + ".proj_out.b"], residual=x, out=out)
+
+    def _tail_buffer(self, h, C_):
+        """(rows, 5C) buffer [g | h] of the fused ff.net.2 + proj_out GEMM and its two column views (FUSE_FF_TAIL); Nones when off."""
+        if not self._fuse_tail:
+            return None, None, None
+        gh = torch.empty(h.shape[0], 5 * C_, device=h.device, dtype=h.dtype)
+        return gh, gh[:, :4 * C_], gh[:, 4 * C_:]
 
     def _motion(self, mo, x, c: _Ctx, H, W, out=None):
         """motion_module.py:139-163,215-227,275-334 (VanillaTemporalModule)."""
@@ -491,13 +518,19 @@ class UNet3DConditionModel:
                 n = ops.layer_norm(h, w[f"{tb}.norms.{k}.g"], w[f"{tb}.norms.{k}.b"], pe=w.get(ab + ".pe"), rows_per_frame=HW, frames=c.F)
                 qkv = ops.gemm(n, w[ab + ".qkv"])
             att = ops.temporal_attention(qkv, c.B, c.F, HW, heads, d, d ** -0.5)
-            h = ops.gemm(att, w[ab + ".o.w"], w[ab + ".o.b"], residual=h)
+            if k == mo.n_attn - 1:
+                gh, g_out, h_out = self._tail_buffer(h, C_)
+            h = ops.gemm(att, w[ab + ".o.w"], w[ab + ".o.b"], residual=h, out=h_out if k == mo.n_attn - 1 else None)
+        if mo.n_attn == 0:
+            gh, g_out, h_out = None, None, None
         if self._fold_ln:
             wf, cs, bf = w[tb + ".ff1_ln"]
-            g = ops.gemm(h, wf, bf, geglu=True, ln=(cs, ops.layer_norm_stats(h, 1e-5)))
+            g = ops.gemm(h, wf, bf, geglu=True, ln=(cs, ops.layer_norm_stats(h, 1e-5)), out=g_out)
         else:
             n = ops.layer_norm(h, w[tb + ".ff_norm.g"], w[tb + ".ff_norm.b"])
-            g = ops.gemm(n, w[tb + ".ff1.w"], w[tb + ".ff1.b"], geglu=True)
+            g = ops.gemm(n, w[tb + ".ff1.w"], w[tb + ".ff1.b"], geglu=True, out=g_out)
+        if gh is not None:
+            return ops.gemm(gh, w[tb + ".tail.w"], w[tb + ".tail.b"], residual=x, out=out)
         h = ops.gemm(g, w[tb + ".ff2.w"], w[tb + ".ff2.b"], residual=h)
         return ops.gemm(h, w[p + ".proj_out.w"], w[p + ".proj_out.b"], residual=x, out=out)
 

@@ -242,6 +242,25 @@ def test_shared_prefix_of_a_cfg_batch_is_the_same_forward(dtype):
     torch.testing.assert_close(y_dup, y_plain, **tol)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_feed_forward_tail_is_the_same_forward(dtype):
+    """FUSE_FF_TAIL: ff.net.2 (+ residual) and proj_out (+ residual) run as ONE GEMM over the side-by-side [g | h] buffer with
+    the weights [Wo W2 | Wo] (attention.py:154-161,316-320; motion_module.py:215-227).  Same function, different association:
+    f32 agrees to rounding, bf16 to the bf16 noise of one fewer rounding of the intermediate."""
+    from emote_hack_amd import unet as unet_mod
+    x, ctx = cases.tiny_inputs(2, 4)
+    try:
+        unet_mod.FUSE_FF_TAIL = False
+        y_plain = build(cases.TINY_MOTION, dtype)(x.to(DEV), 961, ctx.to(DEV)).sample.float()
+    finally:
+        unet_mod.FUSE_FF_TAIL = True
+    m = build(cases.TINY_MOTION, dtype)
+    assert m._fuse_tail and any(k.endswith(".tail.w") for k in m._w)
+    y_fused = m(x.to(DEV), 961, ctx.to(DEV)).sample.float()
+    tol = dict(rtol=1e-4, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(y_fused, y_plain, **tol)
+
+
 def test_pipeline_call_signature_and_errors():
     from emote_hack_amd import DDIMScheduler
     from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
