@@ -188,6 +188,7 @@ def main():
     ap.add_argument("--no-ln-fold", action="store_true", help="A/B: explicit LayerNorm launches instead of the GEMM fold")
     ap.add_argument("--no-shared-prefix", action="store_true", help="A/B: compute the shared prefix of the [uncond, cond] batch for both halves")
     ap.add_argument("--no-fused-tail", action="store_true", help="A/B: ff.net.2 and proj_out as two GEMMs instead of one over [g | h]")
+    ap.add_argument("--gn-fold-min-hw", type=int, default=None, help="A/B: pixels per frame from which the transformer GroupNorm is folded into proj_in (0 = never)")
     ap.add_argument("--mode", default="weak", choices=["weak", "strong"],
                     help="weak: a 12-frame window per GPU (12*N frames); strong: BASELINE configs[3], one 48-frame clip = 8 units over N GPUs")
     ap.add_argument("--spawn-check", action="store_true", help="only prove that N ranks start (gloo, no GPU needed)")
@@ -237,6 +238,9 @@ def main():
     if a.no_fused_tail:
         from emote_hack_amd import unet as unet_mod
         unet_mod.FUSE_FF_TAIL = False
+    if a.gn_fold_min_hw is not None:
+        from emote_hack_amd import unet as unet_mod
+        unet_mod.GN_FOLD_MIN_HW = a.gn_fold_min_hw
     unet, ref = build_models(dev, dtype)
     F_WIN = 12
     f_tot = F_WIN * world if a.mode == "weak" else 4 * F_WIN       # strong: BASELINE configs[3] - 48 frames = 4 windows

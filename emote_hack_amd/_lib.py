@@ -37,6 +37,7 @@ class GemmParams(C.Structure):
         ("tile", C.c_int),
         ("conv_asym", C.c_int),
         ("up_h", C.c_int), ("up_w", C.c_int),
+        ("w_slab_rows", C.c_int), ("w_slab_stride", C.c_int64),
     ]
 
 
@@ -70,6 +71,7 @@ SIGNATURES = {
     "emo_groupnorm_workspace_bytes": (C.c_size_t, [_i, _i64, _i, _i]),
     "emo_groupnorm_stats": (_i, [_p, _i, _p, _i, _i64, _i, _i, _i, _p]),
     "emo_groupnorm_apply": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _f, _i, _i, _p]),
+    "emo_groupnorm_fold_linear": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _i, _f, _i, _p]),
     "emo_layernorm": (_i, [_p, _i, _p, _p, _p, _i, _i64, _i, _f, _p, _i, _i, _i, _p]),
     "emo_layernorm_stats": (_i, [_p, _i, _p, _i64, _i, _f, _i, _p]),
     "emo_gemm": (_i, [C.POINTER(GemmParams), _p]),

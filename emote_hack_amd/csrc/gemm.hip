@@ -45,6 +45,12 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
     EMO_CHECK(((uintptr_t)p.C % 16) == 0 && (!p.residual || ((uintptr_t)p.residual % 8) == 0), EMO_ERR_BAD_SHAPE, "emo_gemm: C/residual alignment");
   }
   const int S = p.split_k > 1 ? p.split_k : 1;
+  if (p.w_slab_rows) {
+    EMO_CHECK(p.w_slab_rows > 0 && p.w_slab_rows % 256 == 0 && p.w_slab_stride >= (int64_t)p.N * p.K && p.M % p.w_slab_rows == 0, EMO_ERR_BAD_SHAPE,
+              "emo_gemm: w_slab_rows=%d must be a positive multiple of 256 dividing M, w_slab_stride >= N*K", p.w_slab_rows);
+    EMO_CHECK(!conv && S == 1 && !p.ln_colsum && !p.transpose_out && p.N % 4 == 0, EMO_ERR_UNSUPPORTED,
+              "emo_gemm: per-instance weights need a dense, single-pass, row-major GEMM with N %% 4 == 0 and without the LayerNorm fold");
+  }
   if (p.ln_colsum || p.ln_stats) {
     EMO_CHECK(p.ln_colsum && p.ln_stats, EMO_ERR_NULL, "emo_gemm: the LayerNorm fold needs both ln_colsum and ln_stats");
     EMO_CHECK(!conv && S == 1, EMO_ERR_UNSUPPORTED, "emo_gemm: the LayerNorm fold needs a dense, single-pass GEMM (conv=%d split_k=%d)", (int)conv, S);

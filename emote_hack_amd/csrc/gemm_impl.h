@@ -475,11 +475,14 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
         a_ptr[i] = A + mc * p.lda + klog * V + (int64_t)kt0 * BK;
       }
     }
+    // per-instance weights (emo_gemm_params.w_slab_rows: GroupNorm folded into proj_in): the tile's rows pick the slab
+    const T* Wt = W;
+    if constexpr (!CONV) { if (p.w_slab_rows > 0) Wt += (lbm / p.w_slab_rows) * p.w_slab_stride; }
 #pragma unroll
     for (int i = 0; i < LB; i++) {
       const int row = (i * NW + wave) * (64 / CPR) + lrow;
       const int n = lbn + row < p.N ? lbn + row : p.N - 1;
-      b_ptr[i] = W + (int64_t)n * p.K + klog * V + (int64_t)kt0 * BK;
+      b_ptr[i] = Wt + (int64_t)n * p.K + klog * V + (int64_t)kt0 * BK;
     }
   };
   const bool k_ragged = (p.K % BK) != 0;            // only the very last stage can run past K
@@ -595,7 +598,10 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
     if constexpr (!TRANS) init_acc_ln<WTM, WTN>(acc, p.bias, p.ln_colsum, ln_mean, ln_rstd, bn + wvn * 32 * WTN, half, p.N);
     else init_acc_ln_trans<WTM, WTN>(acc, p.bias, p.ln_colsum, ln_mean, ln_rstd, bn + wvn * 32 * WTN, l31, half, p.N);
   } else if (bias_in_acc) {
-    init_acc_bias<WTM, WTN>(acc, p.bias, bn + wvn * 32 * WTN, half, p.N);
+    // (per-instance weights carry a per-instance bias [slab][N]: uniform over the tile's rows, so it rides here too)
+    const float* tbias = p.bias;
+    if constexpr (!CONV) { if (p.w_slab_rows > 0) tbias += (bm / p.w_slab_rows) * (int64_t)p.N; }
+    init_acc_bias<WTM, WTN>(acc, tbias, bn + wvn * 32 * WTN, half, p.N);
   } else {
 #pragma unroll
     for (int i = 0; i < WTM; i++)

@@ -317,6 +317,93 @@ extern "C" int emo_groupnorm_apply(const void* x, int ldx, const void* partials,
   return EMO_OK;
 }
 
+// ------------------------------------------------------------------------------------------ GroupNorm folded into a Linear
+// GN(x) W^T + b = x W'_n^T + b'_n per instance n (emo_hip.h emo_groupnorm_fold_linear): the per-frame GroupNorm in front of
+// proj_in (attention.py:124,135-146; motion_module.py:147-151) has no activation behind it, so its scale / shift move into a
+// per-instance copy of the weights - N x Cout x C elements (4.9 MB at the 64x64 level against 2 x 63 MB of activation traffic
+// for the apply pass it replaces).  block = (instance, 8 output rows); a wave per row, lanes over 16-byte column vectors.
+static constexpr int GNF_ROWS = 8, GNF_MAXC = 2560;   // (8: two rows per wave - the kernel is a chain of dependent loads, not bandwidth)
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_fold_linear_kernel(const float* __restrict__ partials, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const T* __restrict__ W,
+                                                             const float* __restrict__ bias, T* __restrict__ w_out,
+                                                             float* __restrict__ rowbias, int C, int G, int nsplit_stats, double count,
+                                                             float eps, int Cout) {
+  constexpr int V = TT<T>::VEC;
+  __shared__ float s_stats[GN_MAXG * 2];
+  __shared__ float s_scale[GNF_MAXC], s_mean[GNF_MAXC], s_beta[GNF_MAXC];
+  const int n = blockIdx.x, o0 = blockIdx.y * GNF_ROWS, tid = threadIdx.x, cpg = C / G;
+  {   // (mean, rstd) per group: the apply pass's combine - TPG adjacent lanes per group, strided f64 sums, shuffle tree
+    int TPG = 1;
+    while (TPG * 2 * G <= 256 && TPG < 64) TPG *= 2;
+    const float* pin = partials + (int64_t)n * nsplit_stats * G * 2;
+    for (int g0 = 0; g0 < G; g0 += 256 / TPG) {
+      const int g = g0 + tid / TPG, part = tid % TPG;
+      double a = 0.0, b = 0.0;
+      if (g < G)
+        for (int q = part; q < nsplit_stats; q += TPG) {
+          const float2 pv = *(const float2*)(pin + ((int64_t)q * G + g) * 2);
+          a += (double)pv.x; b += (double)pv.y;
+        }
+      for (int d = TPG / 2; d > 0; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+      if (g < G && part == 0) {
+        const double mean = a / count;
+        double var = b / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_stats[2 * g] = (float)mean;
+        s_stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+      }
+    }
+    __syncthreads();
+  }
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cpg;
+    s_scale[c] = gamma[c] * s_stats[2 * g + 1];
+    s_mean[c] = s_stats[2 * g];
+    s_beta[c] = beta[c];
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int o = o0 + wave; o < o0 + GNF_ROWS && o < Cout; o += 4) {
+    const T* wr = W + (int64_t)o * C;
+    T* wo = w_out + ((int64_t)n * Cout + o) * C;
+    float acc = 0.f;
+    for (int c = lane * V; c < C; c += 64 * V) {
+      float f[V];
+      unpack16<T>(*(const uint4*)(wr + c), f);
+#pragma unroll
+      for (int e = 0; e < V; e++) {
+        const float t = round_through<T>(f[e] * s_scale[c + e]);   // the value the GEMM multiplies by
+        acc += f[e] * s_beta[c + e] - s_mean[c + e] * t;
+        f[e] = t;
+      }
+      *(uint4*)(wo + c) = pack16<T>(f);
+    }
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if (lane == 0) rowbias[(int64_t)n * Cout + o] = acc + (bias ? bias[o] : 0.f);
+  }
+}
+
+extern "C" int emo_groupnorm_fold_linear(const void* partials, const float* gamma, const float* beta, const void* W, const float* bias,
+                                         void* w_out, float* rowbias_out, int N, int64_t S, int C, int G, int Cout, float eps, int dtype,
+                                         void* stream) {
+  EMO_CHECK(partials && gamma && beta && W && w_out && rowbias_out, EMO_ERR_NULL, "emo_groupnorm_fold_linear: null pointer");
+  int rc = gn_check("emo_groupnorm_fold_linear", N, S, C, G, C, dtype);
+  if (rc) return rc;
+  EMO_CHECK(Cout > 0 && C <= GNF_MAXC, EMO_ERR_UNSUPPORTED, "emo_groupnorm_fold_linear: C=%d Cout=%d", C, Cout);
+  EMO_CHECK(((uintptr_t)W % 16) == 0 && ((uintptr_t)w_out % 16) == 0, EMO_ERR_BAD_SHAPE, "emo_groupnorm_fold_linear: W alignment");
+  const GnGeom gg = gn_geom(N, S, C, G, emo_dtype_vec(dtype));
+  const double count = (double)S * (C / G);
+  const dim3 grid((unsigned)N, (unsigned)((Cout + GNF_ROWS - 1) / GNF_ROWS));
+  hipStream_t st = as_stream(stream);
+  EMO_DISPATCH(dtype, "emo_groupnorm_fold_linear",
+               (gn_fold_linear_kernel<T><<<grid, 256, 0, st>>>((const float*)partials, gamma, beta, (const T*)W, bias, (T*)w_out, rowbias_out, C, G,
+                                                              gg.nsplit_stats, count, eps, Cout)));
+  EMO_LAUNCH_CHECK();
+  return EMO_OK;
+}
+
 // ------------------------------------------------------------------------------------------ LayerNorm
 // A wavefront normalises 64/LPR rows at once: LPR lanes (a power of two) share a row, each lane holds up to
 // LN_MAXV 16-byte vectors of it in registers (lane-strided, so a row group reads contiguous 16*LPR-byte runs).

@@ -184,8 +184,31 @@ def group_norm(x: torch.Tensor, gamma, beta, n_inst: int, groups: int, eps: floa
         check(lib.emo_groupnorm_stats(px, ldx, _ptr(part), n_inst, S, Cc, groups, dt(x), _stream()), "emo_groupnorm_stats")
         check(lib.emo_groupnorm_apply(px, ldx, _ptr(part), _ptr(gamma), _ptr(beta), py, ldy, n_inst, S, Cc, groups, float(eps),
                                       int(silu_), dt(x), _stream()), "emo_groupnorm_apply")
-    _launch("groupnorm", 0.0, x.element_size() * 2.0 * M * Cc, run)   # algorithmic: one read + one write
+    _launch("groupnorm", 0.0, x.element_size() * 2.0 * M * Cc, run, tag=f"M={M} C={Cc}{' silu' if silu_ else ''}")   # algorithmic: one read + one write
     return y
+
+
+def group_norm_fold_linear(x: torch.Tensor, gamma, beta, n_inst: int, groups: int, eps: float, w: torch.Tensor, bias):
+    """GroupNorm (no activation) folded into the Linear / 1x1 conv behind it (emo_hip.h emo_groupnorm_fold_linear): one
+    statistics pass over x, then per-instance weights (n_inst, Cout, C) and a per-instance bias (n_inst, Cout) f32 for
+    gemm(x, w_n, bias_n, w_slab_rows=S) - the normalised tensor is never materialised."""
+    _need_cuda(x, w)
+    lib = _lib.load()
+    M, Cc = x.shape
+    S = M // n_inst
+    Cout = w.shape[0]
+    assert w.shape == (Cout, Cc) and w.is_contiguous() and w.dtype == x.dtype
+    px, ldx = _rows(x)
+    part = torch.empty(max(lib.emo_groupnorm_workspace_bytes(n_inst, S, Cc, groups) // 4, 1), device=x.device, dtype=torch.float32)
+    wn = torch.empty(n_inst, Cout, Cc, device=x.device, dtype=x.dtype)
+    rb = torch.empty(n_inst, Cout, device=x.device, dtype=torch.float32)
+
+    def run():
+        check(lib.emo_groupnorm_stats(px, ldx, _ptr(part), n_inst, S, Cc, groups, dt(x), _stream()), "emo_groupnorm_stats")
+        check(lib.emo_groupnorm_fold_linear(_ptr(part), _ptr(gamma), _ptr(beta), _ptr(w), _ptr(bias), _ptr(wn), _ptr(rb), n_inst, S, Cc, groups,
+                                            Cout, float(eps), dt(x), _stream()), "emo_groupnorm_fold_linear")
+    _launch("groupnorm_fold", 0.0, x.element_size() * 1.0 * M * Cc, run, tag=f"M={M} C={Cc}")   # algorithmic: one read
+    return wn, rb
 
 
 def layer_norm(x: torch.Tensor, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0) -> torch.Tensor:
@@ -215,7 +238,8 @@ GEMM_TILE = 0   # tuning hook for tools/bench: pins emo_gemm_params.tile of ever
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, geglu=False,
-         out_scale=1.0, out=None, transpose_rows=0, transpose_ld=0, conv=None, split_k=None, ln=None, tile=None) -> torch.Tensor:
+         out_scale=1.0, out=None, transpose_rows=0, transpose_ld=0, conv=None, split_k=None, ln=None, tile=None,
+         w_slab_rows=0) -> torch.Tensor:
     """out = epilogue(a @ w.T).  a (M, K) rows view; w (N, K) contiguous in the compute dtype.
     ln = (colsum f32 (N,), stats f32 (M, 2) from layer_norm_stats(a)): LayerNorm over K folded into the GEMM - a holds the RAW
     rows, w / bias carry the folded affine (emo_hip.h emo_gemm_params.ln_colsum).
@@ -225,7 +249,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
     _need_cuda(a, w)
     p = GemmParams()
     pa, lda = _rows(a)
-    N, K = w.shape
+    if w_slab_rows:     # per-instance weights (n_inst, N, K) and bias (n_inst, N): rows [i * w_slab_rows, ...) use slab i (group_norm_fold_linear)
+        assert w.dim() == 3 and conv is None and ln is None and a.shape[0] == w.shape[0] * w_slab_rows, (w.shape, a.shape, w_slab_rows)
+        assert bias is None or (bias.shape == w.shape[:2] and bias.is_contiguous()), bias.shape
+        p.w_slab_rows, p.w_slab_stride = w_slab_rows, w.stride(0)
+        split_k = 1
+    N, K = w.shape[-2:]
     assert w.is_contiguous() and w.dtype == a.dtype, (w.dtype, a.dtype)
     if conv is None:
         M = a.shape[0]
@@ -279,7 +308,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
             lambda: check(_lib.load().emo_gemm(C.byref(p), _stream()), "emo_gemm"),
             tag=f"M={M} N={N} K={K}" + (" geglu" if geglu else "") + (" T" if transpose_rows else "") +
                 (f" s{conv['stride']}{'u' if conv['upsample2x'] else ''}" if conv is not None else "") + (f" sk{sk}" if sk > 1 else "") +
-                (" ln" if ln is not None else ""))
+                (" ln" if ln is not None else "") + (" slab" if w_slab_rows else "") + (" rowbias" if rowbias is not None else ""))
     return out
 
 

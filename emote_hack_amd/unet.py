@@ -53,6 +53,12 @@ SHARE_CFG_PREFIX = True
 # concatenated operand is a plain row view: the (rows, C) intermediate is neither written nor re-read, one launch less per
 # transformer / motion module (attention.py:154-161,316-320, motion_module.py:215-227,322-334).
 FUSE_FF_TAIL = True
+# The per-frame GroupNorm in front of proj_in (attention.py:124,135-146; motion_module.py:147-151) has no activation behind it:
+# from this many pixels per frame on its scale / shift are folded into per-frame copies of the proj_in weights
+# (ops.group_norm_fold_linear: B*F x C x C elements) and the GEMM reads the RAW rows - the apply pass (one read + one write of the
+# activation) disappears: 81 -> 59 us per norm + proj_in at the 64x64 level, -0.25 ms per step.  Below it the weight copies
+# cost what the pass they replace costs (32x32: 58 vs 58 us; 16x16: 64 vs 46) - tools/bench/gn_fold_bench.py.  0 = off.
+GN_FOLD_MIN_HW = 4096
 
 
 class _Ctx:
@@ -423,8 +429,7 @@ class UNet3DConditionModel:
         nb_full = nb
         if shared_half:
             nb = nb // 2
-        h = ops.group_norm(x, w[p + ".norm.g"], w[p + ".norm.b"], nb, self.config["norm_num_groups"], 1e-6, False)
-        h = ops.gemm(h, w[p + ".proj_in.w"], w[p + ".proj_in.b"])
+        h = self._norm_proj_in(x, p, nb, HW, self.config["norm_num_groups"])
         # --- self attention (+ reference bank)
         fold = self._fold_ln and not a.gutted and not (c.bank_mode == "write" and p in c.active)
         LN_EPS = 1e-5   # nn.LayerNorm default (attention.py:240-252)
@@ -484,6 +489,15 @@ class UNet3DConditionModel:
         h = ops.gemm(g, w[tb + ".ff2.w"], w[tb + ".ff2.b"], residual=h)
         return ops.gemm(h, w[p + ".proj_out.w"], w[p + ".proj_out.b"], residual=x, out=out)
 
+    def _norm_proj_in(self, x, p, nb, HW, groups):
+        """GroupNorm(eps 1e-6, per frame) + proj_in; folded into per-frame weights where a frame is large (GN_FOLD_MIN_HW)."""
+        w = self._w
+        if GN_FOLD_MIN_HW and HW >= GN_FOLD_MIN_HW and HW % 256 == 0:
+            wn, rb = ops.group_norm_fold_linear(x, w[p + ".norm.g"], w[p + ".norm.b"], nb, groups, 1e-6, w[p + ".proj_in.w"], w[p + ".proj_in.b"])
+            return ops.gemm(x, wn, rb, w_slab_rows=HW)
+        h = ops.group_norm(x, w[p + ".norm.g"], w[p + ".norm.b"], nb, groups, 1e-6, False)
+        return ops.gemm(h, w[p + ".proj_in.w"], w[p + ".proj_in.b"])
+
     def _tail_buffer(self, h, C_):
         """(rows, 5C) buffer [g | h] of the fused ff.net.2 + proj_out GEMM and its two column views (FUSE_FF_TAIL); Nones when off."""
         if not self._fuse_tail:
@@ -501,8 +515,7 @@ class UNet3DConditionModel:
         HW, nb = H * W, c.B * c.F
         if mo.pe_len and c.F > mo.pe_len:
             raise ValueError(f"video_length {c.F} exceeds temporal_position_encoding_max_len {mo.pe_len}")
-        h = ops.group_norm(x, w[p + ".norm.g"], w[p + ".norm.b"], nb, 32, 1e-6, False)  # norm_num_groups=32 default (:104)
-        h = ops.gemm(h, w[p + ".proj_in.w"], w[p + ".proj_in.b"])
+        h = self._norm_proj_in(x, p, nb, HW, 32)  # norm_num_groups=32 default (:104)
         for k in range(mo.n_attn):
             ab = f"{tb}.attention_blocks.{k}"
             if self._fold_ln:   # LN folded into the q|k|v projection, the positional encoding into a per-frame row bias

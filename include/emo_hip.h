@@ -87,6 +87,17 @@ int emo_groupnorm_apply(const void* x, int ldx, const void* partials, const floa
                         void* y, int ldy, int N, int64_t S, int C, int G, float eps, int silu, int dtype,
                         void* stream);
 
+/* GroupNorm folded into the Linear / 1x1 conv that consumes it (attention.py:124,135-146 `norm` -> `proj_in`;
+ * motion_module.py:147-151): GN(x) W^T + b over an instance n = x W'_n^T + b'_n with
+ *   W'_n[o, c] = W[o, c] * gamma_c * rstd_{n, g(c)}      (rounded to the compute dtype, [N][Cout][C] -> `w_out`)
+ *   b'_n[o]    = b[o] + sum_c W[o, c] * beta_c - sum_c mean_{n, g(c)} * W'_n[o, c]   (f32, [N][Cout] -> `rowbias_out`)
+ * from the `partials` of emo_groupnorm_stats (same fixed-order f64 combine as emo_groupnorm_apply): the normalised tensor is
+ * never written or re-read; emo_gemm then runs with W = w_out, bias = rowbias_out, w_slab_rows = S, w_slab_stride = Cout * C.
+ * W is [Cout][C] in `dtype`, bias f32 [Cout] or NULL. */
+int emo_groupnorm_fold_linear(const void* partials, const float* gamma, const float* beta, const void* W, const float* bias,
+                              void* w_out, float* rowbias_out, int N, int64_t S, int C, int G, int Cout, float eps, int dtype,
+                              void* stream);
+
 /* LayerNorm over the last dim (attention.py:279-316, motion_module.py:216-224), eps 1e-5 default.
  * Optional fused temporal positional-encoding add (motion_module.py:246-248,282-283):
  * y[row] += pe[frame(row)] with frame(row) = (row / rows_per_frame) % frames, pe f32 [max_len][C]. */
@@ -140,6 +151,11 @@ typedef struct {
   int up_h; int up_w;  /* conv only: nearest upsampling to an EXPLICIT size folded into the loader (F.interpolate(size=...),
                       resnet.py:74-82 with `output_size`: inputs that are not a multiple of 2^num_upsamplers,
                       unet_controlnet.py:357-365,456-459); source pixel = floor(dst * H / up_h).  0 = off (upsample2x covers x2) */
+  int w_slab_rows; int64_t w_slab_stride;  /* dense only: per-instance weights - rows [i * w_slab_rows, (i+1) * w_slab_rows) of A
+                      multiply the weight slab W + i * w_slab_stride (elements); w_slab_rows must be a multiple of 256 (a tile never
+                      straddles two slabs).  `bias` is then per instance as well: f32 [M / w_slab_rows][N].  0 = one W (and one bias)
+                      for every row.  Made by emo_groupnorm_fold_linear (GroupNorm folded into proj_in); row-major output with
+                      N % 4 == 0 only, not with the LayerNorm fold, split-K or the conv loader. */
 } emo_gemm_params;
 int emo_gemm(const emo_gemm_params* p, void* stream);
 /* heuristic split factor for (M, N, K) and the workspace it needs */

@@ -86,6 +86,36 @@ def test_groupnorm(dtype, N, S, C, G, silu):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,S,C,G,Cout", [(6, 1024, 320, 32, 320), (3, 256, 64, 8, 96), (2, 4096, 640, 32, 640), (5, 256, 1280, 32, 128)])
+def test_groupnorm_folded_into_linear(dtype, N, S, C, G, Cout):
+    """emo_groupnorm_fold_linear + emo_gemm(w_slab_rows): per-frame GroupNorm (eps 1e-6, no activation) followed by proj_in
+    (attention.py:124,135-146) as per-instance weights over the RAW rows - against group_norm -> linear in f32.  The inputs have
+    a mean of the size of their spread (the mean term rides in the per-instance bias)."""
+    o = ops()
+    x = q(seeded_randn((N * S, C), 5) * (1 + torch.arange(N).repeat_interleave(S)[:, None] * 0.3) + 0.7, dtype)
+    g, b = 1 + 0.1 * seeded_randn((C,), 6), 0.1 * seeded_randn((C,), 7)
+    w, bias = q(seeded_randn((Cout, C), 8) / C ** 0.5, dtype), 0.1 * seeded_randn((Cout,), 9)
+    ref = F.linear(F.group_norm(x.reshape(N, S, C).permute(0, 2, 1), G, g, b, 1e-6).permute(0, 2, 1).reshape(N * S, C), w, bias)
+    xd = x.to(DEV).to(dtype)
+    wn, rb = o.group_norm_fold_linear(xd, g.to(DEV), b.to(DEV), N, G, 1e-6, w.to(DEV).to(dtype), bias.to(DEV))
+    assert tuple(wn.shape) == (N, Cout, C) and tuple(rb.shape) == (N, Cout)
+    got = o.gemm(xd, wn, rb, w_slab_rows=S)
+    close(got, ref, dtype, scale=2.0)
+    # the unfused pair is the same function
+    close(o.gemm(o.group_norm(xd, g.to(DEV), b.to(DEV), N, G, 1e-6, False), w.to(DEV).to(dtype), bias.to(DEV)), ref, dtype, scale=2.0)
+
+
+def test_gemm_weight_slab_geometry_is_checked():
+    from emote_hack_amd._lib import EmoHipError
+    o = ops()
+    a = torch.zeros(512, 64, device=DEV, dtype=torch.bfloat16)
+    w = torch.zeros(2, 64, 64, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(EmoHipError):
+        o.gemm(a[:384], w[:1].expand(3, 64, 64).contiguous(), None, w_slab_rows=128)     # slabs must be multiples of 256 rows
+    o.gemm(a, w, None, w_slab_rows=256)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,C,pe", [(100, 320, False), (2 * 3 * 16, 64, True), (77, 1280, False), (12 * 4, 640, True)])
 def test_layernorm(dtype, M, C, pe):
     o = ops()
