@@ -14,7 +14,7 @@ static constexpr int KBYTES = EMO_GEMM_KBYTES;   // bytes of K per ring stage an
 struct HaloGeom { static constexpr int PW = 16, BN = 128; };   // patch height: 8 or 16 rows (gemm_impl.h HaloT)
 
 enum { EMO_TILE_AUTO = 0, EMO_TILE_64x64 = 1, EMO_TILE_128x128 = 2, EMO_TILE_128x160 = 3, EMO_TILE_256x256 = 4,
-       EMO_TILE_256x160 = 5, EMO_TILE_256x320 = 6 };
+       EMO_TILE_256x160 = 5, EMO_TILE_256x320 = 6, EMO_TILE_256x256_PP = 7 };   // 7: the ping-pong main loop on the 256x256 tile (gemm_impl.h)
 // (measured and dropped: 4 waves of 128x128 with 512 registers - 880-900 TFLOP/s at 8192^3 against 1100 and 2-3x slower on short
 // K, hipcc spills ~220 VGPRs around the epilogue; a register-staged loader - tools/bench/patches/gemm_staged_loader.patch)
 struct GemmPlan { int tile, split_k; };
@@ -23,7 +23,7 @@ static inline void tile_dims(int tile, int& bm, int& bn) {
   switch (tile) {
     case EMO_TILE_64x64: bm = 64; bn = 64; break;
     case EMO_TILE_128x160: bm = 128; bn = 160; break;
-    case EMO_TILE_256x256: bm = 256; bn = 256; break;
+    case EMO_TILE_256x256: case EMO_TILE_256x256_PP: bm = 256; bn = 256; break;
     case EMO_TILE_256x160: bm = 256; bn = 160; break;
     case EMO_TILE_256x320: bm = 256; bn = 320; break;
     default: bm = 128; bn = 128; break;
@@ -64,6 +64,10 @@ static GemmPlan plan_gemm(int64_t M, int N, int K, int dtype, int geglu, int tra
   // (85 vs 105 us at Cin 1280, 132 vs 172 us at Cin 2560; M = 640, the ReferenceNet group: 55 vs 75)
   const bool deep = !big && !small && dtype != EMO_F32 && !ln && !geglu && !transpose_out && nk >= 128 && tiles256 * 4 <= 256 && N % 4 == 0;
   pl.tile = big || deep ? EMO_TILE_256x256 : (small ? EMO_TILE_64x64 : (nt5 ? EMO_TILE_128x160 : EMO_TILE_128x128));
+  // the ping-pong main loop (gemm_impl.h PP) for the single-pass 2-byte dense shapes: +1 % at 8192^3, +2.6 % at M=98304 N=2560
+  // K=320 GEGLU, +4.6 % at N=960 K=320, never behind (tools/bench/pp_bench.py); the conv loader / V^T / split-K dispatch of this
+  // id fall back to the lockstep loop
+  if (big && !transpose_out && K % bk == 0) pl.tile = EMO_TILE_256x256_PP;
   // (256x160 / 256x320 tiles exist behind the hint: on the UNet's shapes they measured SLOWER than the 128-row tiles - 342 /
   // 250 vs 351 TFLOP/s at M=98304 N=K=320, 576 / 732 vs 696-725 at M=24576 N=640 K=2560 - one block per CU leaves the
   // epilogue uncovered, which costs more than the lighter LDS-DMA stream saves; the planner does not pick them)
@@ -71,8 +75,9 @@ static GemmPlan plan_gemm(int64_t M, int N, int K, int dtype, int geglu, int tra
     pl.tile = hint;
     if ((hint == EMO_TILE_256x160 || hint == EMO_TILE_256x320) && (transpose_out || (hint == EMO_TILE_256x320 && dtype == EMO_F32))) pl.tile = EMO_TILE_128x160;
     // GEGLU pairs a value tile with its gate tile inside one wave: only the even-WTN shapes (128x128, 256x256) serve it
-    if (hint > EMO_TILE_256x320) pl.tile = EMO_TILE_128x128;
-    if (geglu && pl.tile != EMO_TILE_128x128 && pl.tile != EMO_TILE_256x256) pl.tile = EMO_TILE_128x128;
+    if (hint > EMO_TILE_256x256_PP) pl.tile = EMO_TILE_128x128;
+    if (hint == EMO_TILE_256x256_PP && (transpose_out || dtype == EMO_F32 || K % bk != 0)) pl.tile = EMO_TILE_256x256;
+    if (geglu && pl.tile != EMO_TILE_128x128 && pl.tile != EMO_TILE_256x256 && pl.tile != EMO_TILE_256x256_PP) pl.tile = EMO_TILE_128x128;
   }
   int bm, bn;
   tile_dims(pl.tile, bm, bn);

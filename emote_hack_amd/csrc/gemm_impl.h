@@ -386,9 +386,22 @@ __device__ __forceinline__ void init_acc_ln_trans(f32x16 (&acc)[WTM][WTN], const
 
 struct ConvRow { int img, iy0, ix0; };
 
-template <typename T, bool CONV, bool TRANS, int WTM, int WTN, int WVM, int WVN, int NS, bool LN = false>
+// PP ("ping-pong", 256x256 dense tiles only): the two wave rows of the block (waves 0-3 = group 0, 4-7 = group 1: one wave of
+// each per SIMD) run HALF A STAGE APART - while one group is in its 32-MFMA phase the other issues its LDS-DMA and waits, so
+// the matrix pipe of a SIMD is fed by one wave at a time and the DMA issue (~1000 cycles per stage and wave in the lockstep
+// loop, during which BOTH waves of a SIMD are off the pipe) hides behind the partner's MFMAs.  Two barriers per stage delimit
+// "epochs"; group 0 issues in even epochs and multiplies in odd ones, group 1 the other way round, one stage behind:
+//   epoch 2s   : G0 requests A0(s+1), then waits for A0(s)      | G1 multiplies stage s-1, then waits for B(s), A1(s)
+//   epoch 2s+1 : G0 multiplies stage s                          | G1 requests B(s+1), A1(s+1)
+// The A half-panels are private to a group (rows 0-127 / 128-255); the W panel is read by both, so it is loaded by the LAGGING
+// group only: B(s+1) overwrites B(s-1), which group 1 reads until the end of epoch 2s - nobody may write it before epoch 2s+1,
+// and that is group 1's request epoch.  A plain 2-deep ring (128 KB) therefore suffices.  Every wait is the issuing wave's
+// own vmcnt followed by a barrier the readers pass (LDS-DMA data is ordered by nothing else).  The offset collapses at a
+// tile's end (joint LDS-staged epilogue) - one half-idle epoch per group and tile.
+template <typename T, bool CONV, bool TRANS, int WTM, int WTN, int WVM, int WVN, int NS, bool LN = false, bool PP = false>
 __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::WPE)) void gemm_kernel(const emo_gemm_params p) {
   static_assert(!(LN && CONV), "the LayerNorm fold is for the dense loader");
+  static_assert(!PP || (!CONV && !TRANS && WTM == 4 && WTN == 2 && WVM == 2 && WVN == 4 && NS == 2), "ping-pong: dense 256x256 tiles, 2-deep ring");
   using Tile = GemmTile<WTM, WTN, WVM, WVN, NS>;
   constexpr int NW = Tile::NW;
   constexpr int V = TT<T>::VEC;          // elements per 16 B
@@ -562,8 +575,54 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
                            (p.ldc & 7) == 0 && (!R || (p.ldr & 7) == 0) && (!p.rowbias || (p.ld_rowbias & 3) == 0) &&
                            (!p.geglu || (WTN % 2 == 0 && !p.rowbias)) && (!p.rowbias || p.rows_per_batch > 0);
 
+  // ---- ping-pong loader (PP): group g's waves load A rows [g*128, g*128+128) of the tile, group 1's also the whole W panel;
+  // glds round i of wave wg covers LDS rows (i*4 + wg)*8 .. +8 of the (half-)panel.  Source pointers are formed per request
+  // from two per-lane row numbers (rows past M / N clamp to the last valid one, as in the lockstep loader).
+  const int pp_grp = wvm, pp_wg = wave & 3;
+  const int pp_klog = lchunk ^ swz(pp_wg * (64 / CPR) + lrow);
+  int64_t pp_arow = 0; int pp_brow = 0, pp_koff = 0;
+  auto pp_setup = [&](int iter) {
+    int ltm, ltn;
+    tile_mn(tile_of(iter), ltm, ltn);
+    pp_arow = (int64_t)ltm * BM + pp_grp * 128 + pp_wg * (64 / CPR) + lrow;
+    pp_brow = ltn * BN + pp_wg * (64 / CPR) + lrow;
+    pp_koff = pp_klog * V;
+  };
+  auto pp_issue = [&](int slot) {     // this wave's share of the loader's current stage into ring slot `slot`
+    unsigned char* sa = lds + slot * Tile::STAGE_BYTES;
+    static_for<4>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      int64_t m = pp_arow + i * 32;
+      if (m >= p.M) m = p.M - 1;
+      EMO_GLDS16(A + m * p.lda + pp_koff, sa + (pp_grp * 16 + i * 4 + pp_wg) * 1024);
+    });
+    if (pp_grp == 1) {
+      static_for<8>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        int n = pp_brow + i * 32;
+        if (n >= p.N) n = p.N - 1;
+        EMO_GLDS16(W + (int64_t)n * p.K + pp_koff, sa + Tile::A_BYTES + (i * 4 + pp_wg) * 1024);
+      });
+    }
+  };
+  auto pp_advance = [&]() {
+    pp_koff += BK;
+    if (++l_kt >= nk) {
+      l_kt = 0;
+      l_iter += G;
+      if (l_iter < tiles_all) pp_setup(l_iter);
+    }
+  };
+
   // stream prologue: NS-1 stages in flight
   int gs = 0;   // stream stage counter of the MFMA loop (ring slot = gs % NS)
+  if constexpr (PP) {
+    if (nk > 0 && l_iter < tiles_all) {
+      pp_setup(l_iter);
+      pp_issue(0);
+      pp_advance();
+    }
+  } else
   if (nk > 0) {
     setup_loader(l_iter);
 #pragma unroll
@@ -611,6 +670,58 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
   }
 
+  if constexpr (PP) {
+    // the 32 MFMAs of one stage (4 k-steps x 8), next k-step's fragment reads between them - the lockstep loop's cluster
+    auto pp_mma = [&](unsigned st) {
+      uint4 fa[2][WTM], fb[2][WTN];
+#pragma unroll
+      for (int i = 0; i < WTM; i++) fa[0][i] = lds_read16(st + fa0[i]);
+#pragma unroll
+      for (int j = 0; j < WTN; j++) fb[0][j] = lds_read16(st + fb0[j]);
+      constexpr int NMMA = WTM * WTN, NRD = WTM + WTN;
+      __builtin_amdgcn_s_setprio(1);
+      static_for<KSTEPS>([&](auto KK) {
+        constexpr int kk = decltype(KK)::value, cur = kk & 1, nxt = cur ^ 1;
+        wait_lgkmcnt<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int n_side = (kk + 1 < KSTEPS) ? NRD : 0;
+        static_for<NMMA>([&](auto Q) {
+          constexpr int q = decltype(Q)::value, i = q / WTN, j = q % WTN;
+          acc[i][j] = mma16<T>(fb[cur][j], fa[cur][i], acc[i][j]);
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<n_side>([&](auto O) {
+            constexpr int o = decltype(O)::value;
+            if constexpr ((o * NMMA) / n_side == q) {
+              if constexpr (o < WTM) fa[nxt][o] = lds_read16((st + fa0[o]) ^ (((kk + 1) % KSTEPS) << 5));
+              else fb[nxt][o - WTM] = lds_read16((st + fb0[o - WTM]) ^ (((kk + 1) % KSTEPS) << 5));
+            }
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+      __builtin_amdgcn_s_setprio(0);
+    };
+    // Both groups run the SAME loop body - [request, wait] barrier [multiply] [wait] barrier; group 1 takes one extra barrier
+    // in front of it (and group 0 one behind), which puts it exactly one epoch behind:
+    //   barrier #2j   : G0 leaves pre(j)    | G1 leaves mma(j-1) + its wait for stage j's B / A1 (-> published)
+    //   barrier #2j+1 : G0 leaves mma(j)    | G1 leaves pre(j) = request of B(j+1), A1(j+1)
+    wait_vmcnt<0>();                  // stage 0 of this tile (requested a tile ago) and the previous epilogue's stores
+    __builtin_amdgcn_s_barrier();     // ... visible to all; everyone is out of the previous epilogue's staging slot
+    if (pp_grp == 1) __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; kt++, gs++) {
+      const unsigned st = (gs & 1) * Tile::STAGE_BYTES;
+      const bool more = l_iter < tiles_all;
+      // G0: A0(kt+1) over A0(kt-1) (its own last read: epoch 2kt-1).  G1: B(kt+1), A1(kt+1) over stage kt-1 (last reads: G0 in
+      // epoch 2kt-1, G1 in epoch 2kt; this is epoch 2kt+1)
+      if (more) { pp_issue((gs + 1) & 1); pp_advance(); }
+      if (pp_grp == 0 && kt > 0) { if (more) wait_vmcnt<4>(); else wait_vmcnt<0>(); }   // A0(kt) landed (kt = 0: the tile's first wait)
+      __builtin_amdgcn_s_barrier();
+      pp_mma(st);
+      if (pp_grp == 1) wait_vmcnt<0>();   // B(kt+1), A1(kt+1) landed: the next barrier publishes them to G0's mma(kt+1)
+      __builtin_amdgcn_s_barrier();
+    }
+    if (pp_grp == 0) __builtin_amdgcn_s_barrier();   // realign: G1's last barrier
+  } else
   for (int kt = 0; kt < nk; kt++, gs++) {
     // stage gs must have landed; up to NS-2 younger stages may still be in flight - fewer at the end of the stream, and none
     // are counted on at a tile's first stage: the previous tile's epilogue stores sit in the same counter
@@ -1123,10 +1234,10 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(const emo_gem
 }
 
 // ------------------------------------------------------------------------------------------ host side
-template <typename T, bool CONV, bool TRANS, int WTM, int WTN, int WVM, int WVN, int NS, bool LN>
+template <typename T, bool CONV, bool TRANS, int WTM, int WTN, int WVM, int WVN, int NS, bool LN, bool PP = false>
 static int launch_gemm(const emo_gemm_params& p, int S, hipStream_t st) {
   using Tile = GemmTile<WTM, WTN, WVM, WVN, NS>;
-  auto kern = gemm_kernel<T, CONV, TRANS, WTM, WTN, WVM, WVN, NS, LN>;
+  auto kern = gemm_kernel<T, CONV, TRANS, WTM, WTN, WVM, WVN, NS, LN, PP>;
   if (Tile::LDS_BYTES > 64 * 1024) {
     static bool once = false;
     if (!once) {
@@ -1164,6 +1275,11 @@ static int dispatch_tile(const emo_gemm_params& p, const GemmPlan& pl, int S, hi
   constexpr int NS = EMO_GEMM_NS;
   constexpr int NS_BIG = (NS * 512 * KBYTES <= 160 * 1024) ? NS : 2;   // a 256x256 stage holds 512 rows of KBYTES
   switch (pl.tile) {
+    case EMO_TILE_256x256_PP:
+      if constexpr (!CONV && !TRANS && sizeof(T) == 2) {
+        if (S == 1 && p.K % (KBYTES / (int)sizeof(T)) == 0 && p.split_k <= 1) return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, 2, LN, true>(p, S, st);
+      }
+      return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, NS_BIG, LN>(p, S, st);
     case EMO_TILE_256x256: return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, NS_BIG, LN>(p, S, st);
     case EMO_TILE_64x64: return launch_gemm<T, CONV, TRANS, 1, 1, 2, 2, NS, LN>(p, S, st);
     case EMO_TILE_128x160: return launch_gemm<T, CONV, TRANS, 1, 5, 4, 1, NS, LN>(p, S, st);

@@ -169,6 +169,45 @@ def test_gemm_persistent_many_tiles(dtype, M, N, K, geglu, res):
     close(got, y.cpu(), dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,geglu,res,ln", [(8192 + 37, 2560, 320, True, False, True),   # GEGLU + LayerNorm fold, ragged last row panel
+                                                (140000, 512, 192, False, True, False),     # 1100 tiles: ~4 per persistent block, 3 stages each
+                                                (33000, 1280, 64, False, False, False),     # ONE stage per tile: every request crosses a tile boundary
+                                                (5000, 960, 1600, False, True, False),      # ragged last column panel, 25 stages
+                                                (6144, 3840, 1280, False, False, True)])
+def test_gemm_ping_pong_main_loop(dtype, M, N, K, geglu, res, ln):
+    """EMO_TILE_256x256_PP: the two wave rows of a block half a stage apart, the W panel requested by the lagging one only
+    (gemm_impl.h).  Every ordering rule of that loop is a data hazard when broken - checked on many tiles per block, one-stage
+    tiles, ragged edges, against the f32 matmul and BIT FOR BIT against the lockstep loop of the same tile (same MFMA order)."""
+    o = ops()
+    g = torch.Generator(device="cpu").manual_seed(321)
+    a = q(torch.randn(M, K, generator=g) * 1.5 + 0.2, dtype).to(DEV).to(dtype)
+    wf = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = 0.1 * torch.randn(N, generator=g)
+    kw = {}
+    if ln:
+        gamma, beta = 1 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+        wp, cs, bp = _ln_fold(wf, bias, gamma, beta, dtype)
+        y = F.linear(F.layer_norm(a.float().cpu(), (K,), gamma, beta), wf.to(dtype).float(), bias)
+        w, bias_d = wp.to(DEV).contiguous(), bp.to(DEV)
+        kw["ln"] = (cs.to(DEV).contiguous(), o.layer_norm_stats(a))
+    else:
+        w, bias_d = wf.to(dtype).to(DEV), bias.to(DEV)
+        y = a.float().cpu() @ w.float().cpu().t() + bias
+    n_out = N // 2 if geglu else N
+    r = q(torch.randn(M, n_out, generator=g), dtype).to(DEV).to(dtype) if res else None
+    if geglu:
+        y = y.reshape(M, N // 64, 2, 32)
+        y = (y[:, :, 0] * F.gelu(y[:, :, 1])).reshape(M, n_out)
+    if res:
+        y = y + r.float().cpu()
+    for rep in range(3):     # a race shows on some launches only
+        got = o.gemm(a, w, bias_d, geglu=geglu, residual=r, tile=7, split_k=1, **kw)
+        lock = o.gemm(a, w, bias_d, geglu=geglu, residual=r, tile=4, split_k=1, **kw)
+        assert torch.equal(got, lock), f"rep {rep}: {int((got != lock).sum())} elements differ from the lockstep loop"
+    close(got, y, dtype, scale=2.0 if ln else 1.0)
+
+
 @pytest.mark.parametrize("M,N,K,tile", [(128 * 13, 1920, 192, 2), (128 * 13 + 5, 2240, 128, 3), (256 * 5 + 37, 3584, 128, 4),
                                         (256 * 9, 4096, 64, 0), (64 * 21 + 3, 1024, 64, 1)])
 def test_gemm_grouped_tile_order_covers_every_tile(M, N, K, tile):
@@ -320,11 +359,11 @@ def test_conv3x3_halo_upsample(dtype, ph, n, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("M,N,K,res", [(1000, 320, 320, True), (700, 640, 192, False), (513, 960, 64, True)])
 def test_gemm_every_tile_shape(dtype, tile, M, N, K, res):
-    """emo_gemm_params.tile pins 64x64 / 128x128 / 128x160 / 256x256 / 256x160 / 256x320: every tile shape must produce the
-    same GEMM (ragged M and N edges, residual epilogue)."""
+    """emo_gemm_params.tile pins 64x64 / 128x128 / 128x160 / 256x256 / 256x160 / 256x320 / 256x256 with the ping-pong main loop:
+    every tile shape must produce the same GEMM (ragged M and N edges, residual epilogue)."""
     o = ops()
     a, w = q(seeded_randn((M, K), 112), dtype), q(seeded_randn((N, K), 113) / math.sqrt(K), dtype)
     bias, r = 0.1 * seeded_randn((N,), 114), q(seeded_randn((M, N), 115), dtype)
@@ -341,7 +380,7 @@ def _ln_fold(wt, bias, gamma, beta, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("M,N,K,mode", [(1000, 640, 320, "plain"), (520, 2560, 320, "geglu"), (768, 320, 320, "trans"),
                                         (2 * 3 * 64, 960, 320, "pe"), (300, 1280, 1280, "plain")])
 def test_gemm_layernorm_fold(dtype, tile, M, N, K, mode):
