@@ -69,8 +69,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
 // G = glds per wave per tile, NSR = ring depth, QT = 32-query tiles per wave (2 halves the LDS fragment traffic per MFMA)
-template <typename T, int DCH, int G, int NSR, int QT>
-__global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) void attention_kernel(const emo_attention_params p, int stage_bytes, int order_mode) {
+// RES = the resident-context variant (below): its own instantiation - the walk over q tiles costs ~20 registers, which the
+// self-attention launches (3 waves per SIMD at d = 40) do not have
+template <typename T, int DCH, int G, int NSR, int QT, bool RES>
+__global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) void attention_kernel(const emo_attention_params p, int stage_bytes, int order_mode, int q_rep_arg) {
+  const int q_rep = RES ? q_rep_arg : 1;
   using Cfg = AttCfg<T, DCH>;
   constexpr int V = Cfg::V, NT = Cfg::NT, KROW = Cfg::KROW, VROW = Cfg::VROW, STEPS = Cfg::STEPS;
   constexpr int DCHP = Cfg::DCHP, VCH = Cfg::VCH, VCHP = Cfg::VCHP, K_CHUNKS = Cfg::K_CHUNKS;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
   // two-segment launch).  Needs (B * heads) % 8 == 0, else the plain order.
   int qt, head, b;
   {
-    const int nqt = (p.Lq + BQ * QT - 1) / (BQ * QT);
+    const int nqt = ((p.Lq + BQ * QT - 1) / (BQ * QT) + q_rep - 1) / q_rep;   // q-tile GROUPS per (b, head): a block walks q_rep tiles
     const int chunks = p.B * p.heads, L = blockIdx.x;
     int hb;
     if ((chunks & 7) == 0 && order_mode >= 2) {
@@ -128,23 +131,6 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
       const int slot = i / pad_bytes, off = pad_begin + (i - slot * pad_bytes);
       const unsigned v = (ones_row && off < ones_end) ? one_bits : 0u;
       *(uint4*)(smem + slot * stage_bytes + off) = make_uint4(v, v, v, v);
-    }
-  }
-
-  // ---- Q fragments: QT tiles of 32 query rows per wave; row q, chunks (2*kk + half)
-  constexpr int BQW = 32 * QT;              // query rows per wave
-  int qrow_idx[QT];
-  bool q_ok[QT];
-  uint4 qf[QT][DCH / 2];
-#pragma unroll
-  for (int t = 0; t < QT; t++) {
-    qrow_idx[t] = qt * (4 * BQW) + wave * BQW + t * 32 + l31;
-    q_ok[t] = qrow_idx[t] < p.Lq;
-    const T* qrow = (const T*)p.q + ((int64_t)b * p.Lq + (q_ok[t] ? qrow_idx[t] : 0)) * p.ldq + head * d;
-#pragma unroll
-    for (int kk = 0; kk < DCH / 2; kk++) {
-      const int c = 2 * kk + half;
-      qf[t][kk] = (q_ok[t] && c < dch_real) ? *(const uint4*)(qrow + c * V) : make_uint4(0, 0, 0, 0);
     }
   }
 
@@ -215,6 +201,53 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
       }
     }
   };
+  const float c_exp = p.scale * 1.4426950408889634f;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+  __syncthreads();   // ring zeroed before the first async write lands (plain LDS stores: lgkmcnt drained by the barrier)
+#pragma unroll
+  for (int s = 0; s < NSR - 1; s++)
+    if (s < ntiles) issue(s, s);
+
+  // RESIDENT mode (q_rep > 1; the host picks it only when every KV tile of the launch fits the ring, i.e. ntiles <= NSR - the
+  // 77-key text / audio context): the K / V^T tiles are requested ONCE and stay in their slots while the block walks q_rep
+  // consecutive 128-query tiles of the same (b, head) - the ring fill, the pad clean-up and the barriers are paid by the first
+  // of them only (a q tile against 77 keys is 2 short MFMA rounds: the launch was all prologue).
+  const int qt_grp = qt;
+  // ---- Q fragments: QT tiles of 32 query rows per wave; row q, chunks (2*kk + half).  The NEXT q tile's fragments of a
+  // resident walk are requested while the current tile is multiplied (a tile against 77 keys is shorter than the load latency).
+  constexpr int BQW = 32 * QT;              // query rows per wave
+  uint4 qf_next[QT][DCH / 2];
+  auto load_q = [&](int qtile) {
+#pragma unroll
+    for (int t = 0; t < QT; t++) {
+      const int qr = qtile * (4 * BQW) + wave * BQW + t * 32 + l31;
+      const bool ok = qr < p.Lq;
+      const T* qrow = (const T*)p.q + ((int64_t)b * p.Lq + (ok ? qr : 0)) * p.ldq + head * d;
+#pragma unroll
+      for (int kk = 0; kk < DCH / 2; kk++) {
+        const int c = 2 * kk + half;
+        qf_next[t][kk] = (ok && c < dch_real) ? *(const uint4*)(qrow + c * V) : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  load_q(qt_grp * q_rep);
+#pragma unroll 1
+  for (int qi = 0; qi < q_rep; qi++) {
+  qt = qt_grp * q_rep + qi;
+  if (qi > 0 && qt * (4 * BQW) >= p.Lq) break;
+  const bool fill = qi == 0;               // this pass requests / waits for / cleans the tiles
+  int qrow_idx[QT];
+  bool q_ok[QT];
+  uint4 qf[QT][DCH / 2];
+#pragma unroll
+  for (int t = 0; t < QT; t++) {
+    qrow_idx[t] = qt * (4 * BQW) + wave * BQW + t * 32 + l31;
+    q_ok[t] = qrow_idx[t] < p.Lq;
+#pragma unroll
+    for (int kk = 0; kk < DCH / 2; kk++) qf[t][kk] = qf_next[t][kk];
+  }
+  if constexpr (RES) { if (qi + 1 < q_rep) load_q(qt + 1); }    // (rows past Lq read row 0 of the batch row: in range, never stored)
 
   f32x16 o[QT][NT];
 #pragma unroll
@@ -226,33 +259,28 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
   float m_run[QT], l_run[QT];
 #pragma unroll
   for (int t = 0; t < QT; t++) { m_run[t] = -1e30f; l_run[t] = 0.f; }
-  const float c_exp = p.scale * 1.4426950408889634f;
-  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-
-  __syncthreads();   // ring zeroed before the first async write lands (plain LDS stores: lgkmcnt drained by the barrier)
-#pragma unroll
-  for (int s = 0; s < NSR - 1; s++)
-    if (s < ntiles) issue(s, s);
 
   for (int t = 0; t < ntiles; t++) {
-    if constexpr (NSR == 1) issue(t, 0);
-    const int rem = ntiles - 1 - t;
-    if constexpr (NSR >= 3) {
-      if (rem >= NSR - 2) wait_vmcnt<(NSR - 2) * G>();
-      else wait_vmcnt<0>();
-    } else {
-      wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    if constexpr (NSR > 1) {
-      if (t + NSR - 1 < ntiles) issue(t + NSR - 1, (t + NSR - 1) % NSR);
+    if (fill) {
+      if constexpr (NSR == 1) issue(t, 0);
+      const int rem = ntiles - 1 - t;
+      if constexpr (NSR >= 3) {
+        if (rem >= NSR - 2) wait_vmcnt<(NSR - 2) * G>();
+        else wait_vmcnt<0>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      if constexpr (NSR > 1) {
+        if (t + NSR - 1 < ntiles) issue(t + NSR - 1, (t + NSR - 1) % NSR);
+      }
     }
     const bool s1 = t >= tiles0;
     const int k0 = (s1 ? t - tiles0 : t) * TK;
     const int Lk = s1 ? p.Lk1 : p.Lk0;
     const unsigned st_base = lds_base + (t % NSR) * stage_bytes;
     const unsigned ks_base = st_base, vs_base = st_base + K_CHUNKS * 16;
-    if (k0 + TK > Lk && (Lk % V) != 0) {
+    if (fill && k0 + TK > Lk && (Lk % V) != 0) {
       // ragged last tile whose final 16-byte V^T chunk straddles Lk: zero the columns >= Lk in LDS (their P is
       // exactly 0, but 0 * garbage must not become NaN).  Rare (context length 77); costs one extra barrier.
       const int cpart = (Lk - k0) / V, efirst = (Lk - k0) % V;
@@ -379,7 +407,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
             o[t][nt] = mma16<T>(vf[sp][nt], pf[t][st][sp], o[t][nt]);
           }
     }
-    if constexpr (NSR == 1) __builtin_amdgcn_s_barrier();   // synchronous ring: nobody may still read slot 0
+    if constexpr (NSR == 1) { if (q_rep == 1) __builtin_amdgcn_s_barrier(); }   // synchronous ring: nobody may still read slot 0 (resident: one tile, never rewritten)
   }
 
   // ---- normalise and store: lane holds O[q][n], n = nt*32 + 8*(r>>2) + 4*half + (r&3)
@@ -418,6 +446,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
         }
     }
   }
+  }   // q tiles of this block
 }
 
 template <typename T, int DCH, int G>
@@ -434,24 +463,39 @@ struct AttLaunch {
 template <typename T, int DCH, int G, int QT>
 static int launch_attention3(const emo_attention_params& p, hipStream_t st) {
   using L = AttLaunch<T, DCH, G>;
-  auto kern = attention_kernel<T, DCH, G, L::NSR, QT>;
+  auto kern = attention_kernel<T, DCH, G, L::NSR, QT, false>;
+  auto kern_res = attention_kernel<T, DCH, G, L::NSR, QT, true>;
   constexpr int lds = L::NSR * L::STAGE_BYTES;
   if (lds > 64 * 1024) {
     static bool once = false;  // idempotent attribute; benign race
     if (!once) {
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kern_res, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e != hipSuccess) return emo_fail(EMO_ERR_HIP, "emo_attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
       once = true;
     }
   }
-  const int64_t nblk = (int64_t)((p.Lq + BQ * QT - 1) / (BQ * QT)) * p.heads * p.B;
+  // resident mode (kernel comment): every KV tile of every batch row fits the ring - the text / audio context
+  const int nqt_all = (p.Lq + BQ * QT - 1) / (BQ * QT);
+  const int tiles_max = (p.Lk0 + TK - 1) / TK + (p.k1 ? (p.Lk1 + TK - 1) / TK : 0);
+  int q_rep = 1;
+  if (tiles_max <= L::NSR) {
+    static const int forced = getenv("EMO_ATT_QREP") ? atoi(getenv("EMO_ATT_QREP")) : 0;   // tools/bench sweep
+    const int64_t chunks = (int64_t)p.heads * p.B;
+    // up to 4 q tiles per block while that leaves >= 160 blocks (80 -> 66 us at B=24 Lq=4096 d=40, 37 -> 32 at Lq=1024 d=80,
+    // 32 -> 25 at Lq=256 d=160; 8 per block: equal / slower - tools/bench/xattn_bench.py)
+    for (q_rep = 4; q_rep > 1 && (q_rep > nqt_all || ((nqt_all + q_rep - 1) / q_rep) * chunks < 160); q_rep >>= 1) {}
+    if (forced > 0) q_rep = forced;
+  }
+  const int64_t nblk = (int64_t)((nqt_all + q_rep - 1) / q_rep) * p.heads * p.B;
   if (nblk >= (1ll << 31)) return emo_fail(EMO_ERR_BAD_SHAPE, "emo_attention: too many blocks");
   dim3 grid((unsigned)nblk);
   // order_mode 2: (b, head) chunks round-robin over the XCDs; 3: the same from the LAST batch row backwards - under CFG the cond
   // rows (second half of the batch) carry the bank segment and run twice as long as the uncond rows: started first, the short rows
   // fill the tail (1443 -> 1429 us at the 64x64 level, 143 -> 138.5 at 32x32; equal without a bank segment)
   const int order_mode = (p.k1 != nullptr && p.seg1_first_batch > 0) ? 3 : 2;
-  kern<<<grid, ATT_THREADS, lds, st>>>(p, L::STAGE_BYTES, order_mode);
+  if (q_rep > 1) kern_res<<<grid, ATT_THREADS, lds, st>>>(p, L::STAGE_BYTES, order_mode, q_rep);
+  else kern<<<grid, ATT_THREADS, lds, st>>>(p, L::STAGE_BYTES, order_mode, 1);
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }

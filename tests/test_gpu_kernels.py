@@ -476,6 +476,27 @@ def test_attention_single_segment(dtype, B, Lq, Lk, heads, d):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,Lq,Lk,heads,d,div", [(24, 4096 - 100, 77, 8, 40, 12), (48, 1024, 77, 8, 80, 1), (130, 256 + 17, 50, 8, 160, 1),
+                                                 (40, 1000, 128, 8, 40, 4)])
+def test_attention_resident_context(dtype, B, Lq, Lk, heads, d, div):
+    """Cross-attention to a short context (attention.py:300-305; 77 text keys): every KV tile fits the ring, so a block keeps
+    them and walks SEVERAL 128-query tiles of its (b, head) (attention.hip, resident mode - picked by the launch when there are
+    enough blocks left).  Ragged last q tile (a block's walk ends early), ragged key tile, context shared by `div` batch rows."""
+    o = ops()
+    C_ = heads * d
+    qq = q(seeded_randn((B, Lq, C_), 41), dtype)
+    kk, vv = (q(seeded_randn((B // div, Lk, C_), s_), dtype) for s_ in (42, 43))
+    sp = lambda t: t.reshape(t.shape[0], -1, heads, d).permute(0, 2, 1, 3)
+    ref = attn_ref(sp(qq), sp(kk).repeat_interleave(div, 0), sp(vv).repeat_interleave(div, 0), d ** -0.5).permute(0, 2, 1, 3).reshape(B * Lq, C_)
+    ld = (Lk + 7) // 8 * 8
+    vt = torch.full((B // div, C_, ld), float("nan"))
+    vt[:, :, :Lk] = vv.permute(0, 2, 1)
+    got = o.attention(qq.reshape(-1, C_).to(DEV).to(dtype), kk.reshape(-1, C_).to(DEV).to(dtype), vt.to(DEV).to(dtype), Lk, B=B,
+                      Lq=Lq, heads=heads, d=d, scale=d ** -0.5, seg0_div=div)
+    close(got, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_bank_segment_and_shared_context(dtype):
     """Reference read path: K/V = cat([x, bank repeated over F]) for c rows, plain self-attention for
     uc rows (mutual_self_attention.py:238-256); text context shared by the F frames (attention.py:118)."""
