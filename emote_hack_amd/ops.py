@@ -351,7 +351,9 @@ def attention(q, k0, v0t, Lk0, *, B, Lq, heads, d, scale, seg0_div=1, k1=None, v
     p.out, p.ldo = out.data_ptr(), out.stride(0)
     p.B, p.Lq, p.heads, p.d, p.scale, p.dtype = B, Lq, heads, d, float(scale), dt(q)
     esz = q.element_size()
-    _launch("attention", 4.0 * B * heads * Lq * (Lk0 + Lk1) * d, esz * float(B) * heads * d * (2 * Lq + 2 * (Lk0 + Lk1)),
+    # (only the batch rows from seg1_first_batch on read the second segment - under CFG the uncond half does not)
+    b1 = max(B - seg1_first_batch, 0) if k1 is not None else 0
+    _launch("attention", 4.0 * heads * Lq * d * (B * Lk0 + b1 * Lk1), esz * heads * d * (2.0 * B * Lq + 2.0 * (B * Lk0 + b1 * Lk1)),
             lambda: check(_lib.load().emo_attention(C.byref(p), _stream()), "emo_attention"),
             tag=f"B={B} Lq={Lq} Lk={Lk0}+{Lk1} h={heads} d={d}")
     return out
