@@ -569,6 +569,15 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
   const bool bias_in_acc = !LN && !TRANS && nsplit == 1 && p.bias != nullptr && (p.N & 3) == 0;
   emo_gemm_params pe = p;
   if (bias_in_acc || LN) pe.bias = nullptr;   // (LN: the folded bias enters the accumulator init scaled by 1 / rstd)
+  // the per-batch row bias (temb of a resnet, the positional-encoding term of a temporal q|k|v projection) is uniform over a tile
+  // whose rows lie inside one batch of rows_per_batch rows: it then starts the accumulators as well (under the LayerNorm fold
+  // divided by rstd_m like the bias) and the epilogue has no row-bias loads (per staged pass: one L2 round trip each)
+#ifndef EMO_GEMM_RB_IN_ACC
+#define EMO_GEMM_RB_IN_ACC 1   // (0: tools/bench A/B build)
+#endif
+  const bool rb_in_acc = EMO_GEMM_RB_IN_ACC && !CONV && !TRANS && nsplit == 1 && p.rowbias != nullptr && (p.N & 3) == 0 && (p.ld_rowbias & 3) == 0 &&
+                         p.rows_per_batch > 0 && (p.rows_per_batch % BM) == 0;
+  if (rb_in_acc) pe.rowbias = nullptr;
   // coalesced LDS-staged epilogue (bf16, row-major, single pass): needs whole 16-byte chunks everywhere
   const int n_out_all = p.geglu ? p.N / 2 : p.N;
   const bool use_lds_epi = !TRANS && sizeof(T) == 2 && nsplit == 1 && nk > 0 && (n_out_all & 7) == 0 && (p.N & 3) == 0 &&
@@ -668,6 +677,26 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
       for (int j = 0; j < WTN; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  }
+
+  if (rb_in_acc) {
+    const float* trb = p.rowbias + (bm / p.rows_per_batch) * (int64_t)p.ld_rowbias;
+    const int wnb = bn + wvn * 32 * WTN;
+#pragma unroll
+    for (int j = 0; j < WTN; j++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int n0 = wnb + j * 32 + 8 * g + 4 * half;
+        if (n0 < p.N) {
+          const float4 b4 = *(const float4*)(trb + n0);
+#pragma unroll
+          for (int i = 0; i < WTM; i++) {
+            const float sc = LN ? 1.0f / ln_rstd[i] : 1.0f;
+            acc[i][j][4 * g] = fmaf(b4.x, sc, acc[i][j][4 * g]); acc[i][j][4 * g + 1] = fmaf(b4.y, sc, acc[i][j][4 * g + 1]);
+            acc[i][j][4 * g + 2] = fmaf(b4.z, sc, acc[i][j][4 * g + 2]); acc[i][j][4 * g + 3] = fmaf(b4.w, sc, acc[i][j][4 * g + 3]);
+          }
+        }
+      }
   }
 
   if constexpr (PP) {
@@ -797,7 +826,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
       // next tile's prefetched first stage); it is rewritten by the loader only behind the next stage's barrier
       __builtin_amdgcn_s_barrier();
       const unsigned xbase = lds_base + ((gs + NS - 1) % NS) * Tile::STAGE_BYTES;
-      const bool res = R != nullptr || p.out_scale != 1.0f, rowb = p.rowbias != nullptr;
+      const bool res = R != nullptr || p.out_scale != 1.0f, rowb = pe.rowbias != nullptr;
       auto run = [&](auto GG, auto RS, auto RB) {
         epilogue_lds<T, WTM, WTN, NW, Tile::STAGE_BYTES, decltype(GG)::value, LN, decltype(RS)::value, decltype(RB)::value>(
             acc, pe, wm0, wn0, wave, lane, xbase, C, R, ln_rstd);

@@ -428,6 +428,35 @@ def test_gemm_layernorm_fold(dtype, tile, M, N, K, mode):
     torch.testing.assert_close(got.float().cpu(), y, rtol=tol["rtol"], atol=tol["atol"] * (2.0 if dtype != torch.float32 else 1.0))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ln", [False, True])
+@pytest.mark.parametrize("tile", [0, 2, 3, 4, 7])
+@pytest.mark.parametrize("M,rpb,N,K", [(3 * 512, 512, 960, 320), (5 * 256 + 100, 256, 320, 192), (4 * 384, 384, 640, 64)])
+def test_gemm_row_bias_uniform_over_a_tile(dtype, ln, tile, M, rpb, N, K):
+    """The per-batch row bias (temb, resnet.py:188; the positional-encoding term of the temporal q|k|v projection,
+    motion_module.py:246-248 folded to pe . W^T per frame) starts the accumulators when a tile's rows lie inside one batch
+    (rows_per_batch a multiple of the tile height) and goes through the epilogue otherwise (rpb = 384 against 256-row tiles,
+    a ragged last batch): both against bias + row bias in f32, with and without the LayerNorm fold (row bias divided by rstd)."""
+    o = ops()
+    x = q(seeded_randn((M, K), 190) * 1.3 + (1.5 * seeded_randn((M, 1), 191) if ln else 0), dtype)
+    wt, bias = seeded_randn((N, K), 192) / math.sqrt(K), 0.1 * seeded_randn((N,), 193)
+    nb = (M + rpb - 1) // rpb
+    rb = seeded_randn((nb, N), 194)
+    rows = torch.arange(M) // rpb
+    a = x.to(DEV).to(dtype)
+    if ln:
+        gamma, beta = 1 + 0.2 * seeded_randn((K,), 195), 0.2 * seeded_randn((K,), 196)
+        ref = F.linear(F.layer_norm(x, (K,), gamma, beta), q(wt, dtype), bias) + rb[rows]
+        wp, cs, bp = _ln_fold(wt, bias, gamma, beta, dtype)
+        got = o.gemm(a, wp.to(DEV).contiguous(), bp.to(DEV), ln=(cs.to(DEV).contiguous(), o.layer_norm_stats(a, 1e-5)), rowbias=rb.to(DEV),
+                     rows_per_batch=rpb, tile=tile)
+    else:
+        ref = F.linear(x, q(wt, dtype), bias) + rb[rows]
+        got = o.gemm(a, q(wt, dtype).to(DEV).to(dtype), bias.to(DEV), rowbias=rb.to(DEV), rows_per_batch=rpb, tile=tile, split_k=1)
+    tol = TOL[dtype]
+    torch.testing.assert_close(got.float().cpu(), ref, rtol=tol["rtol"], atol=tol["atol"] * (2.0 if ln and dtype != torch.float32 else 1.0))
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("ln", [False, True])
 @pytest.mark.parametrize("M,L,N,K", [(512, 128, 200, 96), (1088, 64, 320, 320), (4096 + 64, 4096 + 64, 64, 64)])
