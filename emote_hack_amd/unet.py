@@ -61,6 +61,14 @@ FUSE_FF_TAIL = True
 GN_FOLD_MIN_HW = 4096
 
 
+def ff_tail_weights(w_out, b_out, w2, b2):
+    """ff.net.2 followed by proj_out as ONE linear map over the side-by-side operand [g | h] (FUSE_FF_TAIL):
+    (g W2^T + b2 + h) Wo^T + bo = [g | h] [Wo W2 | Wo]^T + (Wo b2 + bo).  f32 in, f32 out ((C, 5C) weight, (C,) bias); proj_out may
+    be a 1x1 conv (C, C, 1, 1) or a Linear (attention.py:135-146,154-161)."""
+    wo = w_out.float().reshape(w_out.shape[0], -1)
+    return torch.cat([wo @ w2.float(), wo], 1), wo @ b2.float() + b_out.float()
+
+
 class _Ctx:
     """Per-forward geometry + reference-attention state."""
 
@@ -245,11 +253,8 @@ class UNet3DConditionModel:
         self._fuse_tail = bool(FUSE_FF_TAIL)
 
         def ff_tail(ff2, proj_out):
-            """([Wo W2 | Wo] in the compute dtype, Wo b2 + bo) - products formed in f32, rounded once."""
-            wo = m[proj_out + ".weight"].float()
-            wo = wo.reshape(wo.shape[0], -1)
-            w2, b2 = m[ff2 + ".weight"].float(), m[ff2 + ".bias"].float()
-            return torch.cat([wo @ w2, wo], 1).to(dtp).contiguous(), (wo @ b2 + m[proj_out + ".bias"].float()).contiguous()
+            wt, bt = ff_tail_weights(m[proj_out + ".weight"], m[proj_out + ".bias"], m[ff2 + ".weight"], m[ff2 + ".bias"])
+            return wt.to(dtp).contiguous(), bt.contiguous()
 
         def geglu(prefix):  # interleave (32 value, 32 gate)
             wt, b = m[prefix + ".weight"], m[prefix + ".bias"]
