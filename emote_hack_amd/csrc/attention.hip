@@ -24,6 +24,13 @@
 #include "common.h"
 
 static constexpr int ATT_THREADS = 256, BQ = 128, TK = 64;
+#ifdef EMO_ATT_PRIO   // experiment (tools/bench/build_variant.sh): raised wave priority around the MFMA clusters
+#define EMO_ATT_PRIO_UP() __builtin_amdgcn_s_setprio(1)
+#define EMO_ATT_PRIO_DOWN() __builtin_amdgcn_s_setprio(0)
+#else
+#define EMO_ATT_PRIO_UP() ((void)0)
+#define EMO_ATT_PRIO_DOWN() ((void)0)
+#endif
 
 __device__ __attribute__((aligned(16))) unsigned int g_att_zero_page[4] = {0, 0, 0, 0};
 __device__ __attribute__((aligned(16))) unsigned int g_att_ones_bf16[4] = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
@@ -232,6 +239,18 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
     }
   };
   load_q(qt_grp * q_rep);
+  // The Q fragments are ordinary global loads.  hipcc's wait-count pass cannot count past an LDS-DMA: with Q still "pending"
+  // at the head of the tile loop it put an `s_waitcnt vmcnt(0)` in front of the first Q.K^T MFMA of EVERY tile, i.e. every
+  // wave waited for the ring slot it had just requested (tile t+NSR-1) before touching tile t - the ring never ran ahead.
+  // Consuming the fragments here retires them once, next to the prologue requests the first tile needs anyway.
+  // (not in the resident variant: all of its tiles are requested by the prologue and waited for once)
+  if constexpr (!RES) {
+#pragma unroll
+    for (int t = 0; t < QT; t++)
+#pragma unroll
+      for (int kk = 0; kk < DCH / 2; kk++)
+        asm volatile("" : "+v"(qf_next[t][kk].x), "+v"(qf_next[t][kk].y), "+v"(qf_next[t][kk].z), "+v"(qf_next[t][kk].w));
+  }
 #pragma unroll 1
   for (int qi = 0; qi < q_rep; qi++) {
   qt = qt_grp * q_rep + qi;
@@ -299,7 +318,6 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
     // The whole 64-key tile is processed at once: S^T for both 32-key sub-tiles, ONE online-softmax update per query
     // row per tile (half the max/rescale work of per-sub-tile updates), then O^T += V^T P^T.  K and V^T fragments are
     // read once per wave and reused for the QT query tiles.
-    const bool two = k0 + 32 < Lk;                 // second sub-tile has at least one valid key (wave-uniform)
     uint4 kf[2][DCH / 2];
 #pragma unroll
     for (int st = 0; st < 2; st++) {
@@ -315,12 +333,15 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
       f32x16 s0, s1;
 #pragma unroll
       for (int r = 0; r < 16; r++) { s0[r] = 0.f; s1[r] = 0.f; }
+      // (both 32-key sub-tiles always: the keys of a ragged last tile past Lk are zero rows masked to -1e30 below, their V^T
+      // columns are zero - a branch here costs a 16-register zero fill of s1 through SGPRs in every tile)
+      EMO_ATT_PRIO_UP();
 #pragma unroll
-      for (int kk = 0; kk < DCH / 2; kk++) s0 = mma16<T>(kf[0][kk], qf[t][kk], s0);
-      if (two) {
-#pragma unroll
-        for (int kk = 0; kk < DCH / 2; kk++) s1 = mma16<T>(kf[1][kk], qf[t][kk], s1);
+      for (int kk = 0; kk < DCH / 2; kk++) {
+        s0 = mma16<T>(kf[0][kk], qf[t][kk], s0);
+        s1 = mma16<T>(kf[1][kk], qf[t][kk], s1);
       }
+      EMO_ATT_PRIO_DOWN();
       if (k0 + TK > Lk) {   // ragged last tile only (wave-uniform): mask keys >= Lk
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -380,7 +401,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
     // ---- O^T += V^T . P^T : per sub-tile the V^T fragments are read once and feed the QT query tiles
 #pragma unroll
     for (int st = 0; st < 2; st++) {
-      if (st == 1 && !two) break;
+      if (st == 1 && k0 + 32 >= Lk) break;         // ragged last tile (the 77-key context): the second sub-tile holds no key
       uint4 vf[STEPS][NT];
 #pragma unroll
       for (int sp = 0; sp < STEPS; sp++) {
@@ -398,6 +419,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
       }
       wait_lgkmcnt<0>();
       __builtin_amdgcn_sched_barrier(0);
+      EMO_ATT_PRIO_UP();
 #pragma unroll
       for (int sp = 0; sp < STEPS; sp++)
 #pragma unroll
@@ -406,6 +428,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
           for (int nt = 0; nt < NT; nt++) {
             o[t][nt] = mma16<T>(vf[sp][nt], pf[t][st][sp], o[t][nt]);
           }
+      EMO_ATT_PRIO_DOWN();
     }
     if constexpr (NSR == 1) { if (q_rep == 1) __builtin_amdgcn_s_barrier(); }   // synchronous ring: nobody may still read slot 0 (resident: one tile, never rewritten)
   }
@@ -480,7 +503,12 @@ static int launch_attention3(const emo_attention_params& p, hipStream_t st) {
   const int tiles_max = (p.Lk0 + TK - 1) / TK + (p.k1 ? (p.Lk1 + TK - 1) / TK : 0);
   int q_rep = 1;
   if (tiles_max <= L::NSR) {
-    static const int forced = getenv("EMO_ATT_QREP") ? atoi(getenv("EMO_ATT_QREP")) : 0;   // tools/bench sweep
+#ifdef EMO_ATT_QREP_ENV   // tools/bench/xattn_bench.py sweep builds only (build_variant.sh -DEMO_ATT_QREP_ENV): never in the product
+    static const int forced_env = getenv("EMO_ATT_QREP") ? atoi(getenv("EMO_ATT_QREP")) : 0;
+    const int forced = forced_env > nqt_all ? nqt_all : forced_env;
+#else
+    constexpr int forced = 0;
+#endif
     const int64_t chunks = (int64_t)p.heads * p.B;
     // up to 4 q tiles per block while that leaves >= 160 blocks (80 -> 66 us at B=24 Lq=4096 d=40, 37 -> 32 at Lq=1024 d=80,
     // 32 -> 25 at Lq=256 d=160; 8 per block: equal / slower - tools/bench/xattn_bench.py)

@@ -590,12 +590,14 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
   const int pp_grp = wvm, pp_wg = wave & 3;
   const int pp_klog = lchunk ^ swz(pp_wg * (64 / CPR) + lrow);
   int64_t pp_arow = 0; int pp_brow = 0, pp_koff = 0;
+  const T* pp_w = W;      // the tile's weight slab (per-instance weights, emo_gemm_params.w_slab_rows - as in setup_loader)
   auto pp_setup = [&](int iter) {
     int ltm, ltn;
     tile_mn(tile_of(iter), ltm, ltn);
     pp_arow = (int64_t)ltm * BM + pp_grp * 128 + pp_wg * (64 / CPR) + lrow;
     pp_brow = ltn * BN + pp_wg * (64 / CPR) + lrow;
     pp_koff = pp_klog * V;
+    pp_w = p.w_slab_rows > 0 ? W + (((int64_t)ltm * BM) / p.w_slab_rows) * p.w_slab_stride : W;
   };
   auto pp_issue = [&](int slot) {     // this wave's share of the loader's current stage into ring slot `slot`
     unsigned char* sa = lds + slot * Tile::STAGE_BYTES;
@@ -610,7 +612,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
         constexpr int i = decltype(I)::value;
         int n = pp_brow + i * 32;
         if (n >= p.N) n = p.N - 1;
-        EMO_GLDS16(W + (int64_t)n * p.K + pp_koff, sa + Tile::A_BYTES + (i * 4 + pp_wg) * 1024);
+        EMO_GLDS16(pp_w + (int64_t)n * p.K + pp_koff, sa + Tile::A_BYTES + (i * 4 + pp_wg) * 1024);
       });
     }
   };

@@ -56,6 +56,7 @@ class EMOAnimationPipeline:
         self.vae_scale_factor = 8
         self.device = unet.device
         self._bank_pg = {}     # world_size -> the ReferenceNet-bank communicator (created once: td.new_group is a collective + leaks)
+        self._plan_cache = None   # (plan key, prepared state) of the last `denoise(reuse_state=True)` / `__call__`
 
     @property
     def _execution_device(self):
@@ -74,12 +75,17 @@ class EMOAnimationPipeline:
     def prepare_denoise(self, latents, ref_image_latents, text_embeddings, *, appearance_encoder, num_inference_steps=50,
                         guidance_scale=7.5, eta=0.0, context_frames=16, context_stride=1, context_overlap=4,
                         context_batch_size=1, context_schedule="uniform", audio_features=None, speed_embeddings=None, seed=0,
-                        fusion_blocks="midup", dist=False, rank=0, world_size=1, return_eps=False, use_graphs=False,
+                        fusion_blocks="midup", dist=False, rank=0, world_size=1, return_eps=False, use_graphs=None,
                         controlnet=None, controlnet_cond=None, controlnet_conditioning_scale=1.0, reference_group=10,
                         reference_lookahead=None, motion_latents=None):
         """Set up the loop state (EMOAnimationPipeline.py:628-696).  latents f32 (1,4,F_tot,h,w);
         ref_image_latents (1,4,h,w); text_embeddings (2,L,D) = [uncond, cond].
         reference_group = T: ReferenceNet timesteps computed per batched pass (1 = the reference's per-step order).
+        use_graphs: None (default) = HIP-graph replay of the UNet / ReferenceNet passes whenever the model lives on a HIP device
+        (the path bench.py measures; ~1700 launches per step leave the host), False = every kernel launched from Python.
+        The state splits into a PLAN (geometry, buffers, captured graphs - everything above `_bind_inputs`) and the INPUTS
+        (latents, reference image, text / audio / speed conditioning, ControlNet images, guidance scale, seed), which are copied
+        into the plan's buffers in place: `reset_denoise` re-arms a prepared state for another clip of the same geometry.
         motion_latents (n_m, 4, h, w): latents of the previous clip's last frames - they go through the ReferenceNet next to the
         reference image and their LN1 features join the banks as extra tokens (see denoise_chained)."""
         unet, sch = self.unet, self.scheduler
@@ -89,23 +95,20 @@ class EMOAnimationPipeline:
         # reference's own lines do not run in that mode: `pred_uc, pred_c = pred.chunk(2)` (:790) unpacks a one-row batch, and its
         # reader is built with do_classifier_free_guidance=True (:634), which would mask half of the FRAMES off the bank; this
         # follows the evident intent, pinned by the `ddim_nocfg` loop golden.)
-        cfg = bool(guidance_scale > 1.0)
+        cfg = self._do_cfg(guidance_scale)
         if latents.shape[0] != 1:
             raise ValueError("batch_size must be 1 (EMOAnimationPipeline.py:641-642); run clips as separate calls")
-        if text_embeddings.shape[0] == 2 and not cfg:
-            text_embeddings = text_embeddings[1:]          # [uncond, cond] handed over anyway: the cond row is the prompt
-        if text_embeddings.shape[0] != (2 if cfg else 1):
-            raise ValueError("text_embeddings must be (2, L, D) = [uncond, cond] (:631), or (1, L, D) = [cond] without guidance")
+        text_embeddings = self._text_rows(text_embeddings, cfg)
         st = SimpleNamespace()
         st.cfg = cfg
         st.cbs = cbs = int(context_batch_size)
         if cbs < 1:
             raise ValueError("context_batch_size must be >= 1")
-        st.latents = latents.to(dev).float().contiguous()
+        st.latents = torch.empty(tuple(latents.shape), device=dev, dtype=torch.float32)
         _, st.C4, st.f_tot, st.h, st.w = st.latents.shape
         st.HW = st.h * st.w
         # text rows indexed by VARIANT: 0 = uncond, 1 = cond (without guidance both name the cond row)
-        st.text = text_embeddings.to(dev).float() if cfg else text_embeddings.to(dev).float().expand(2, -1, -1).contiguous()
+        st.text = torch.empty(2, *text_embeddings.shape[1:], device=dev, dtype=torch.float32)
         st.appearance_encoder = appearance_encoder
         st.writer = ReferenceAttentionControl(appearance_encoder, do_classifier_free_guidance=True, mode="write",
                                               batch_size=cbs, fusion_blocks=fusion_blocks)      # :633
@@ -114,15 +117,9 @@ class EMOAnimationPipeline:
         st.num_inference_steps = num_inference_steps
         st.timesteps = sch.set_timesteps(num_inference_steps)
         n_steps = len(st.timesteps)
-        st.ref_lat = ref_image_latents.to(dev).float().reshape(1, st.C4, st.h, st.w)
-        if motion_latents is not None:   # (Net.py:56-72 intent; junk/EMo-write-up.txt:104-110): ReferenceNet images = [reference, motion frames]
-            ml = motion_latents.to(dev).float()
-            if ml.dim() == 5:
-                ml = ml[0].permute(1, 0, 2, 3)
-            if tuple(ml.shape[1:]) != (st.C4, st.h, st.w):
-                raise ValueError(f"motion_latents must be (n, {st.C4}, {st.h}, {st.w}), got {tuple(ml.shape)}")
-            st.ref_lat = torch.cat([st.ref_lat, ml]).contiguous()
-        st.n_ref_images = st.ref_lat.shape[0]
+        # ReferenceNet images = [reference, motion frames] (Net.py:56-72 intent; junk/EMo-write-up.txt:104-110)
+        st.n_ref_images = 1 + (0 if motion_latents is None else self._motion_rows(motion_latents).shape[0])
+        st.ref_lat = torch.empty(st.n_ref_images, st.C4, st.h, st.w, device=dev, dtype=torch.float32)
         scheduler_fn = get_context_scheduler(context_schedule)
         # the reference recomputes the (step-independent: step arg is always 0) window list every step (:748-755)
         st.windows = [list(map(int, c)) for c in scheduler_fn(0, num_inference_steps, st.f_tot, context_frames, context_stride, context_overlap)]
@@ -196,40 +193,27 @@ class EMOAnimationPipeline:
                 st.calls.append(call)
         st.t_table = torch.tensor(st.timesteps, dtype=torch.int64, device=dev)   # INT timestep table, bit-exact
         st.t_buf = torch.zeros(1, dtype=torch.int64, device=dev)
-        st.use_graphs, st.graphs = bool(use_graphs), {}
+        if use_graphs is None:      # the measured path is the default one on a HIP device
+            use_graphs = dev.type == "cuda"
+        st.use_graphs, st.graphs = bool(use_graphs) and dev.type == "cuda", {}
         st.graph_pool = st.writer_pool = None
         if st.use_graphs:
             st.graph_pool = torch.cuda.graph_pool_handle()
             st.writer_pool = torch.cuda.graph_pool_handle()   # own pool: the ReferenceNet pass runs concurrently with the Backbone
-        # ---- contexts of the attn2 layers: their K / V^T projections depend on the context only -> once per clip
-        if audio_features is not None:
-            audio_features = audio_features.to(dev).float()
-        st.audio_features = audio_features
-        se = speed_embeddings
-        if se is not None:
-            se = se.to(dev).float()
-            if se.shape[0] not in (1, 2):
-                raise ValueError("speed_embeddings must have 1 row (shared) or 2 rows [uncond, cond]")
+        # ---- contexts of the attn2 layers: their K / V^T projections depend on the context only -> once per clip (_bind_inputs)
+        st.audio_features = None if audio_features is None else torch.empty(tuple(audio_features.shape), device=dev, dtype=torch.float32)
+        if speed_embeddings is not None and speed_embeddings.shape[0] not in (1, 2):
+            raise ValueError("speed_embeddings must have 1 row (shared) or 2 rows [uncond, cond]")
+        st.speed = None if speed_embeddings is None else torch.empty(tuple(speed_embeddings.shape), device=dev, dtype=torch.float32)
         for call in st.calls:
-            if audio_features is None:
-                call.ctx = torch.cat([st.text[st.unit_tv[u]:st.unit_tv[u] + 1] for u in call.units])    # (n, L, D)
-            else:   # per-frame audio context; uncond units get a zero context (design choice)
-                parts = []
-                for (w, br), ix in zip(call.units, call.idx):
-                    a = audio_features.index_select(0, ix)
-                    parts.append(a if br == 1 else torch.zeros_like(a))
-                call.ctx = torch.cat(parts)                                                              # (n*F, L_a, D)
-            call.ctx_kv = unet.context_kv(call.ctx)
-            call.speed = None if se is None else torch.cat([se[(br if se.shape[0] == 2 else 0):(br if se.shape[0] == 2 else 0) + 1]
-                                                            for _, br in call.units])
+            call.ctx = call.ctx_kv = call.speed = None
         st.text_c = st.text[1:2]
-        st.ref_ctx_kv = {tv: appearance_encoder.context_kv(st.text[tv:tv + 1]) for tv in st.bank_variants}
+        st.ref_ctx_kv = {}
         # ---- eps hand-off: every unit's rows (nf*HW, C4); slot = position in the rank's unit list
         st.send = torch.zeros(st.n_slots, nf * st.HW, st.C4, device=dev, dtype=unet.dtype)
         st.recv = torch.zeros(st.world_size, st.n_slots, nf * st.HW, st.C4, device=dev, dtype=unet.dtype) if st.dist else None
         st.noise_pred = torch.empty(len(st.branches), st.C4, st.f_tot, st.HW, device=dev, dtype=torch.float32)
         st.counter = torch.empty(st.f_tot, device=dev, dtype=torch.float32)
-        st.guidance_scale, st.eta, st.seed = guidance_scale, eta, seed
         st.return_eps, st.eps_trace = return_eps, []
         # ---- ReferenceNet groups: the banks depend on the timestep only (never on the latents): T timesteps per pass
         T = max(1, min(int(reference_group), n_steps))
@@ -250,9 +234,13 @@ class EMOAnimationPipeline:
         st.bank_C = [chan[p] for p in st.writer.order]
         if st.dist and st.world_size > 1:
             import torch.distributed as td
-            if st.world_size not in self._bank_pg:   # once per pipeline (denoise_chained prepares per clip; new_group leaks a communicator)
-                self._bank_pg[st.world_size] = td.new_group(ranks=list(range(st.world_size)))
-            st.bank_pg = self._bank_pg[st.world_size]
+            # once per pipeline AND default process group (denoise_chained prepares per clip; new_group leaks a communicator).  A
+            # communicator made under a default group that has since been destroyed / re-initialised is dead: keyed on its identity
+            world_pg = td.distributed_c10d._get_default_group()
+            entry = self._bank_pg.get(st.world_size)
+            if entry is None or entry[0] is not world_pg:
+                entry = self._bank_pg[st.world_size] = (world_pg, td.new_group(ranks=list(range(st.world_size))))
+            st.bank_pg = entry[1]
         # look-ahead = group g+1's ReferenceNet pass on a second stream under group g's Backbone steps.  With world_size > 1 that
         # pass carries an RCCL all_gather on its own communicator, concurrent with the per-step eps all_gather on the main
         # stream - two collectives whose device-side start order can differ between ranks.  Off by default there (the pass
@@ -266,8 +254,7 @@ class EMOAnimationPipeline:
         if controlnet is not None:
             if controlnet_cond is None or controlnet_cond.shape[0] != st.f_tot:
                 raise ValueError("controlnet_cond must hold one (3,H,W) conditioning image per frame")
-            st.cn_scale = float(controlnet_conditioning_scale)
-            st.cn_cond = controlnet_cond.to(dev).float()
+            st.cn_cond = torch.empty(tuple(controlnet_cond.shape), device=dev, dtype=torch.float32)
             # the frames this rank's units touch; residuals are computed once per frame and step, in chunks of
             # context_frames (the reference caches them per frame from overlap-0 windows: the network is per-frame, so
             # the chunking does not enter the result)
@@ -278,7 +265,129 @@ class EMOAnimationPipeline:
             for call in st.calls:
                 call.cn_sel = torch.tensor([st.cn_pos[k] for w, _ in call.units for k in st.windows[w]], dtype=torch.int64, device=dev)
             st.cn_down, st.cn_mid = None, None
+        self._bind_inputs(st, latents, ref_image_latents, text_embeddings, audio_features=audio_features, speed_embeddings=speed_embeddings,
+                          motion_latents=motion_latents, controlnet_cond=controlnet_cond,
+                          controlnet_conditioning_scale=controlnet_conditioning_scale, guidance_scale=guidance_scale, eta=eta, seed=seed)
         return st
+
+    # ---- the INPUTS of a prepared loop state, copied into its buffers in place (the captured graphs keep reading them)
+    @staticmethod
+    def _do_cfg(guidance_scale):
+        """`do_classifier_free_guidance = guidance_scale > 1.0` (:622), decided on the f32 value emo_cfg_step receives: a scale
+        in (1, 1 + 2^-24] would otherwise allocate two noise_pred planes for a kernel that reads one."""
+        import numpy as np
+        return bool(np.float32(guidance_scale) > np.float32(1.0))
+
+    @staticmethod
+    def _text_rows(text_embeddings, cfg):
+        if text_embeddings.shape[0] == 2 and not cfg:
+            text_embeddings = text_embeddings[1:]          # [uncond, cond] handed over anyway: the cond row is the prompt
+        if text_embeddings.shape[0] != (2 if cfg else 1):
+            raise ValueError("text_embeddings must be (2, L, D) = [uncond, cond] (:631), or (1, L, D) = [cond] without guidance")
+        return text_embeddings
+
+    @staticmethod
+    def _motion_rows(motion_latents):
+        ml = motion_latents
+        if ml.dim() == 5:
+            ml = ml[0].permute(1, 0, 2, 3)
+        return ml
+
+    def _bind_inputs(self, st, latents, ref_image_latents=None, text_embeddings=None, *, audio_features=None, speed_embeddings=None,
+                     motion_latents=None, controlnet_cond=None, controlnet_conditioning_scale=None, guidance_scale=None, eta=None,
+                     seed=None):
+        """Copy a clip's inputs into the buffers of a prepared state (None = keep what is bound).  Everything derived from them -
+        the attn2 K / V^T of the text / audio context per UNet call, the ReferenceNet's text K / V^T - is recomputed INTO the
+        tensors the captured graphs already read; the ReferenceNet groups are marked stale (the reference image and the motion
+        frames enter them)."""
+        unet, dev = self.unet, st.latents.device
+
+        def put(dst, src, what):
+            src = src.to(dev).float()
+            if tuple(src.shape) != tuple(dst.shape):
+                raise ValueError(f"{what} {tuple(src.shape)} != prepared {tuple(dst.shape)}")
+            dst.copy_(src)
+        if st.side is not None:   # nothing of the previous clip may still be writing the bank cache
+            torch.cuda.current_stream().wait_stream(st.side)
+        put(st.latents, latents, "latents")
+        if ref_image_latents is not None:
+            put(st.ref_lat[:1], ref_image_latents.reshape(1, st.C4, st.h, st.w), "ref_image_latents")
+        if motion_latents is not None:
+            ml = self._motion_rows(motion_latents)
+            if st.n_ref_images == 1 or tuple(ml.shape) != (st.n_ref_images - 1, st.C4, st.h, st.w):
+                raise ValueError(f"motion_latents must be ({st.n_ref_images - 1}, {st.C4}, {st.h}, {st.w}), got {tuple(ml.shape)}")
+            put(st.ref_lat[1:], ml, "motion_latents")
+        elif st.n_ref_images != 1 and ref_image_latents is not None:
+            raise ValueError("the state was prepared with motion frames: pass motion_latents")
+        if guidance_scale is not None:
+            if self._do_cfg(guidance_scale) != st.cfg:
+                raise ValueError("guidance_scale crosses 1.0: classifier-free guidance on / off is part of the plan (prepare again)")
+            st.guidance_scale = float(guidance_scale)
+        if eta is not None:
+            st.eta = eta
+        if seed is not None:
+            st.seed = seed
+        ctx_stale = False
+        if text_embeddings is not None:
+            t = self._text_rows(text_embeddings, st.cfg).to(dev).float()
+            put(st.text, t if st.cfg else t.expand(2, -1, -1), "text_embeddings")
+            ctx_stale = True
+            for tv in st.bank_variants:
+                for pr, kv in st.appearance_encoder.context_kv(st.text[tv:tv + 1]).items():
+                    self._put_kv(st.ref_ctx_kv.setdefault(tv, {}), pr, kv)
+        if audio_features is not None:
+            if st.audio_features is None:
+                raise ValueError("the state was prepared without audio_features")
+            put(st.audio_features, audio_features, "audio_features")
+            ctx_stale = True
+        if speed_embeddings is not None:
+            if st.speed is None:
+                raise ValueError("the state was prepared without speed_embeddings")
+            put(st.speed, speed_embeddings, "speed_embeddings")
+        for call in st.calls:
+            if ctx_stale:
+                if st.audio_features is None:
+                    ctx = torch.cat([st.text[st.unit_tv[u]:st.unit_tv[u] + 1] for u in call.units])    # (n, L, D)
+                else:   # per-frame audio context; uncond units get a zero context (design choice, SURVEY A17)
+                    parts = []
+                    for (w, br), ix in zip(call.units, call.idx):
+                        a = st.audio_features.index_select(0, ix)
+                        parts.append(a if br == 1 else torch.zeros_like(a))
+                    ctx = torch.cat(parts)                                                              # (n*F, L_a, D)
+                if call.ctx is None:
+                    call.ctx = ctx
+                else:
+                    call.ctx.copy_(ctx)
+                if call.ctx_kv is None:
+                    call.ctx_kv = {}
+                for pr, kv in unet.context_kv(call.ctx).items():
+                    self._put_kv(call.ctx_kv, pr, kv)
+            if speed_embeddings is not None:
+                se = st.speed
+                sp = torch.cat([se[(br if se.shape[0] == 2 else 0):(br if se.shape[0] == 2 else 0) + 1] for _, br in call.units])
+                if call.speed is None:
+                    call.speed = sp
+                else:
+                    call.speed.copy_(sp)
+        if controlnet_cond is not None:
+            if st.controlnet is None:
+                raise ValueError("the state was prepared without a ControlNet")
+            put(st.cn_cond, controlnet_cond, "controlnet_cond")
+        if controlnet_conditioning_scale is not None and st.controlnet is not None:
+            scale = float(controlnet_conditioning_scale)
+            if getattr(st, "cn_scale", scale) != scale and st.graphs.get("controlnet") not in (None, "warm"):
+                raise ValueError("controlnet_conditioning_scale is baked into the captured ControlNet pass (prepare again)")
+            st.cn_scale = scale
+        st.group_ready, st.group_pending, st.eps_trace = -1, -1, []
+
+    @staticmethod
+    def _put_kv(store, key, kv):
+        """store[key] = (K rows, V^T) - into the tensors already there, if any (captured graphs hold their addresses)"""
+        if key in store:
+            for dst, src in zip((store[key],) if torch.is_tensor(store[key]) else store[key], (kv,) if torch.is_tensor(kv) else kv):
+                dst.copy_(src)
+        else:
+            store[key] = kv
 
     # ---- ReferenceNet: one batched write pass per GROUP of timesteps, one group ahead of the Backbone on a second stream
     def _ref_sel(self, st, Tg):
@@ -298,6 +407,7 @@ class EMOAnimationPipeline:
         reader.update() does (:588) and packed for the exchange."""
         t = st.ref_t[:Tg] if st.world_size == 1 else st.ref_t.index_select(0, self._ref_sel(st, Tg))
         n, k = t.numel(), st.n_ref_images
+        st.appearance_encoder._reference_control = st.writer   # (another prepared state on the same models may have attached its own)
         st.writer.clear()
         # batch rows timestep-major: (t0: reference image, motion frames...), (t1: ...) - the k images of one timestep are
         # consecutive, so their LN1 rows (k, L, C) read as ONE bank of k*L tokens (the reference concatenates several bank
@@ -409,6 +519,7 @@ class EMOAnimationPipeline:
         x = self.scheduler.scale_model_input(x, None)
         # (a call of uncond units only names any resident cache: every one of its batches skips the bank segment)
         bank_tv = call.bank_tv if call.bank_tv is not None else st.bank_variants[0]
+        self.unet._reference_control = st.reader
         st.reader.set_projected_banks(st.kv_all[bank_tv], st.bank_idx, call.n_uc)               # replaces reader.update (:774)
         rows = self.unet(x, st.t_buf, encoder_hidden_states=call.ctx, speed_embeddings=call.speed, return_dict=False,
                          _return_rows=True, _ctx_kv=call.ctx_kv, _halves_identical=call.halves_identical,
@@ -483,30 +594,62 @@ class EMOAnimationPipeline:
 
     @torch.no_grad()
     def denoise(self, latents, ref_image_latents, text_embeddings, *, num_actual_inference_steps=None, callback=None,
-                callback_steps=1, **kw):
-        """The whole loop; returns the denoised latents f32 (1,4,F_tot,h,w) (and the eps trace if asked)."""
-        st = self.prepare_denoise(latents, ref_image_latents, text_embeddings, **kw)
-        return self._run_loop(st, num_actual_inference_steps, callback, callback_steps)
+                callback_steps=1, reuse_state=False, **kw):
+        """The whole loop; returns the denoised latents f32 (1,4,F_tot,h,w) (and the eps trace if asked).
+        reuse_state: keep the prepared state (plan + captured HIP graphs) on the pipeline and re-arm it when the next call has the
+        same plan - same shapes, step count, window / guidance / distribution settings and the same loaded weights; only the
+        inputs are copied in (`_bind_inputs`).  `__call__` turns it on: a second clip costs the loop and nothing else."""
+        if not reuse_state:
+            st = self.prepare_denoise(latents, ref_image_latents, text_embeddings, **kw)
+            return self._run_loop(st, num_actual_inference_steps, callback, callback_steps)
+        key = self._plan_key(latents, ref_image_latents, text_embeddings, kw)
+        cached = self._plan_cache
+        if cached is not None and cached[0] == key:
+            st = cached[1]
+            bind = {k: kw[k] for k in ("audio_features", "speed_embeddings", "motion_latents", "controlnet_cond",
+                                       "controlnet_conditioning_scale", "guidance_scale", "eta", "seed") if kw.get(k) is not None}
+            self._bind_inputs(st, latents, ref_image_latents, text_embeddings, **bind)
+        else:
+            self._plan_cache = None          # drop the old graphs before the new plan allocates
+            st = self.prepare_denoise(latents, ref_image_latents, text_embeddings, **kw)
+            self._plan_cache = (key, st)
+        res = self._run_loop(st, num_actual_inference_steps, callback, callback_steps)
+        # (the state's latents are overwritten by the next clip)
+        return (res[0].clone(), list(res[1])) if isinstance(res, tuple) else res.clone()
 
-    def reset_denoise(self, st, latents, motion_latents=None):
-        """Re-arm a prepared loop state for another clip of the SAME geometry: new noisy latents (and motion frames) are copied
-        IN PLACE, so the captured HIP graphs, the resident bank cache, the context K / V^T and the communicators are reused -
-        only the ReferenceNet groups are recomputed (the motion frames enter them)."""
+    def _plan_key(self, latents, ref_image_latents, text_embeddings, kw):
+        """Everything a prepared state's PLAN depends on (prepare_denoise above `_bind_inputs`): tensor shapes, the settings that
+        shape windows / units / groups / graphs, and the identity of the packed weights the graphs were captured over."""
+        from . import unet as unet_mod
+
+        def shp(t):
+            return None if t is None else tuple(t.shape)
+
+        def wid(m):   # a re-pack (load_state_dict / .to) builds a new dict of packed tensors: captured graphs are stale
+            return None if m is None else (id(m), id(getattr(m, "_w", None)), str(getattr(m, "dtype", None)))
+        plan = {k: v for k, v in kw.items() if k not in ("audio_features", "speed_embeddings", "motion_latents", "controlnet_cond",
+                                                            "controlnet_conditioning_scale", "guidance_scale", "eta", "seed",
+                                                            "appearance_encoder", "controlnet")}
+        return (shp(latents), shp(ref_image_latents), shp(text_embeddings), shp(kw.get("audio_features")), shp(kw.get("speed_embeddings")),
+                shp(kw.get("motion_latents")), shp(kw.get("controlnet_cond")), kw.get("controlnet_conditioning_scale", 1.0),
+                self._do_cfg(kw.get("guidance_scale", 7.5)), wid(self.unet), wid(kw.get("appearance_encoder")), wid(kw.get("controlnet")),
+                type(self.scheduler).__name__, unet_mod.SHARE_CFG_PREFIX, unet_mod.GN_FOLD_MIN_HW,
+                tuple(sorted((k, repr(v)) for k, v in plan.items())))
+
+    def reset_denoise(self, st, latents, motion_latents=None, **inputs):
+        """Re-arm a prepared loop state for another clip of the SAME geometry: new noisy latents (and motion frames; optionally
+        ref_image_latents / text_embeddings / audio_features / speed_embeddings / controlnet_cond / guidance_scale / eta / seed)
+        are copied IN PLACE, so the captured HIP graphs, the resident bank cache and the communicators are reused - only the
+        context K / V^T and the ReferenceNet groups are recomputed (the reference image and the motion frames enter them)."""
         if tuple(latents.shape) != tuple(st.latents.shape):
             raise ValueError(f"reset_denoise: latents {tuple(latents.shape)} != prepared {tuple(st.latents.shape)}")
-        st.latents.copy_(latents.to(st.latents.device).float())
+        if motion_latents is None and st.n_ref_images != 1:
+            raise ValueError("reset_denoise: the state was prepared with motion frames")
         if motion_latents is not None:
-            ml = motion_latents.to(st.latents.device).float()
-            if ml.dim() == 5:
-                ml = ml[0].permute(1, 0, 2, 3)
+            ml = self._motion_rows(motion_latents)
             if ml.shape[0] != st.n_ref_images - 1 or tuple(ml.shape[1:]) != (st.C4, st.h, st.w):
                 raise ValueError(f"reset_denoise: motion_latents must be ({st.n_ref_images - 1}, {st.C4}, {st.h}, {st.w}), got {tuple(ml.shape)}")
-            st.ref_lat[1:].copy_(ml)
-        elif st.n_ref_images != 1:
-            raise ValueError("reset_denoise: the state was prepared with motion frames")
-        if st.side is not None:   # nothing of the previous clip may still be writing the bank cache
-            torch.cuda.current_stream().wait_stream(st.side)
-        st.group_ready, st.group_pending, st.eps_trace = -1, -1, []
+        self._bind_inputs(st, latents, motion_latents=motion_latents, **inputs)
         return st
 
     @torch.no_grad()
@@ -582,7 +725,10 @@ class EMOAnimationPipeline:
                  decoder_consistency=None, audio=None, head_rotation_speeds=None, **kwargs):
         """Signature = EMOAnimationPipeline.py:544-578.  Extra keyword inputs for the parts that are out of
         scope here: text_embeddings=(2,L,D), ref_image_latents=(1,4,h,w), audio_features=(F,L_a,D),
-        speed_embeddings=(1,4*C0), seed=int; dist/rank/world_size as in the reference (:636-638)."""
+        speed_embeddings=(1,4*C0), seed=int; dist/rank/world_size as in the reference (:636-638).  Execution knobs (all
+        optional): use_graphs (default: HIP-graph replay on a HIP device - the path bench.py measures), reference_group
+        (ReferenceNet timesteps per batched pass, default 10), reference_lookahead, fusion_blocks, motion_latents, reuse_state
+        (default True: a second call with the same geometry reuses the prepared plan and its captured graphs)."""
         height = height or self.unet.config.sample_size * self.vae_scale_factor
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         self.check_inputs(prompt, height, width, callback_steps)
@@ -636,7 +782,12 @@ class EMOAnimationPipeline:
                            seed=kwargs.get("seed", 0), dist=kwargs.get("dist", False), rank=kwargs.get("rank", 0),
                            world_size=kwargs.get("world_size", 1), num_actual_inference_steps=num_actual_inference_steps,
                            callback=callback, callback_steps=callback_steps, controlnet=self.controlnet, controlnet_cond=cn_cond,
-                           controlnet_conditioning_scale=controlnet_conditioning_scale)
+                           controlnet_conditioning_scale=controlnet_conditioning_scale,
+                           # the measured path: HIP-graph replay (default on a HIP device), batched ReferenceNet groups, and the
+                           # prepared state kept for the next clip of the same geometry
+                           use_graphs=kwargs.get("use_graphs"), reference_group=kwargs.get("reference_group", 10),
+                           reference_lookahead=kwargs.get("reference_lookahead"), fusion_blocks=kwargs.get("fusion_blocks", "midup"),
+                           motion_latents=kwargs.get("motion_latents"), reuse_state=kwargs.get("reuse_state", True))
         if self.vae is not None and output_type != "latent":
             video = self.vae.decode_video(lat)   # caller-supplied (:291-307)
         else:

@@ -105,6 +105,23 @@ def test_groupnorm_folded_into_linear(dtype, N, S, C, G, Cout):
     close(o.gemm(o.group_norm(xd, g.to(DEV), b.to(DEV), N, G, 1e-6, False), w.to(DEV).to(dtype), bias.to(DEV)), ref, dtype, scale=2.0)
 
 
+@pytest.mark.parametrize("tile", [None, 7, 4])
+@pytest.mark.parametrize("N,S,C,Cout", [(14, 4096, 64, 256), (8, 4096, 128, 512)])
+def test_weight_slabs_on_the_ping_pong_tile(N, S, C, Cout, tile):
+    """Per-instance weight slabs on the 256x256 tiles the planner picks for BIG outputs (N % 256 == 0, >= 224 tiles: widths 256 / 512
+    at 64x64 latents) - the ping-pong loader formed its W addresses from the base pointer, i.e. every frame was multiplied by
+    frame 0's folded weights (and got its own bias).  Also with the tile pinned (7 = ping-pong, 4 = lockstep 256x256).  bf16
+    against per-slab f32 linears; the slabs differ by construction."""
+    o = ops()
+    dtype = torch.bfloat16
+    x = q(seeded_randn((N * S, C), 5), dtype)
+    w = q(seeded_randn((N, Cout, C), 8) / C ** 0.5 * (1 + torch.arange(N)[:, None, None] * 0.25), dtype)
+    bias = 0.1 * seeded_randn((N, Cout), 9)
+    ref = torch.cat([F.linear(x[i * S:(i + 1) * S], w[i], bias[i]) for i in range(N)])
+    got = o.gemm(x.to(DEV).to(dtype), w.to(DEV).to(dtype), bias.to(DEV), w_slab_rows=S, tile=tile)
+    close(got, ref, dtype, scale=2.0)
+
+
 def test_gemm_weight_slab_geometry_is_checked():
     from emote_hack_amd._lib import EmoHipError
     o = ops()

@@ -446,3 +446,42 @@ def test_denoise_loop_wrapped_window_with_repeated_frames():
     assert any(int((fi < 0).sum()) > 0 for fi in st.frame_idx), "the wrapped window must carry dropped duplicates"
     got = pipe.denoise(lat.to(DEV), refl, text, appearance_encoder=ref, **kw)
     torch.testing.assert_close(got.cpu(), want, rtol=1e-3, atol=1e-4)
+
+
+def test_call_entry_runs_the_graph_path_and_reuses_its_plan():
+    """EMOAnimationPipeline.__call__ (EMOAnimationPipeline.py:544-578) must run what bench.py measures: HIP-graph replay by
+    default, the prepared plan kept for the next clip.  (1) `pipe(...)` == `denoise(use_graphs=True)` bit for bit and both match
+    the reference loop golden; (2) a second call with OTHER inputs of the same geometry re-arms the cached plan (same state
+    object, graphs not re-captured) and equals a freshly prepared eager run bit for bit; (3) a different geometry re-plans."""
+    from emote_hack_amd import DDIMScheduler
+    from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
+    from emote_hack_amd.pipeline import EMOAnimationPipeline
+    g = load_file(os.path.join(G, "loop_tiny.safetensors"))
+    ref = build(cases.TINY, torch.float32, cases.REF_PREFIX, cls=AppearanceEncoderModel, has_out=False)
+    unet = build(cases.TINY_MOTION, torch.float32)
+    pipe = EMOAnimationPipeline(unet=unet, scheduler=DDIMScheduler())
+    lat, refl, text = seeded_randn((1, 4, 8, 16, 16), 5), seeded_randn((1, 4, 16, 16), 3), seeded_randn((2, 5, 32), 2)
+    kw = dict(num_inference_steps=3, guidance_scale=7.5, context_frames=4, context_stride=1, context_overlap=2)
+    call_kw = dict(video_length=8, height=128, width=128, output_type="latent", appearance_encoder=ref, seed=0, **kw)
+    out = pipe("a prompt", latents=lat.to(DEV), text_embeddings=text, ref_image_latents=refl, **call_kw).videos
+    st1 = pipe._plan_cache[1]
+    assert st1.use_graphs and any(not isinstance(v, str) for v in st1.graphs.values()), "__call__ must capture and replay HIP graphs"
+    want = pipe.denoise(lat.to(DEV), refl, text, appearance_encoder=ref, seed=0, use_graphs=True, **kw)
+    assert torch.equal(out, want)
+    torch.testing.assert_close(out.cpu(), g["ddim/latents"], rtol=1e-3, atol=1e-4)
+    # (2) other inputs, same geometry: the plan and its graphs are reused
+    lat2, refl2, text2 = seeded_randn((1, 4, 8, 16, 16), 15), seeded_randn((1, 4, 16, 16), 13), seeded_randn((2, 5, 32), 12)
+    n_graphs = len(st1.graphs)
+    out2 = pipe("a prompt", latents=lat2.to(DEV), text_embeddings=text2, ref_image_latents=refl2, **dict(call_kw, seed=3, guidance_scale=5.0))
+    assert pipe._plan_cache[1] is st1 and len(st1.graphs) == n_graphs
+    fresh = pipe.denoise(lat2.to(DEV), refl2, text2, appearance_encoder=ref, seed=3, use_graphs=False, **dict(kw, guidance_scale=5.0))
+    assert torch.equal(out2.videos, fresh)
+    assert not torch.equal(out2.videos, out)
+    # and the first clip again through the re-armed plan
+    out3 = pipe("a prompt", latents=lat.to(DEV), text_embeddings=text, ref_image_latents=refl, **call_kw).videos
+    assert pipe._plan_cache[1] is st1 and torch.equal(out3, out)
+    # (3) another geometry (4 frames = one window) prepares afresh
+    out4 = pipe("a prompt", latents=lat[:, :, :4].to(DEV), text_embeddings=text, ref_image_latents=refl, **dict(call_kw, video_length=4)).videos
+    assert pipe._plan_cache[1] is not st1
+    want4 = pipe.denoise(lat[:, :, :4].to(DEV), refl, text, appearance_encoder=ref, seed=0, use_graphs=False, **kw)
+    assert torch.equal(out4, want4)

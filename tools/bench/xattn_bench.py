@@ -1,4 +1,5 @@
-"""Cross-attention to the 77-key text context: q tiles per block (EMO_ATT_QREP = 1 is the one-tile-per-block launch)."""
+"""Cross-attention to the 77-key text context: q tiles per block (EMO_ATT_QREP = 1 is the one-tile-per-block launch; the override
+exists only in a sweep build: TUS=attention tools/bench/build_variant.sh att_qrep -DEMO_ATT_QREP_ENV, EMO_HIP_LIB=.../att_qrep.so)."""
 import os
 import sys
 import torch
