@@ -65,7 +65,7 @@ def build_models(dev, dtype):
     return unet, ref
 
 
-def cpu_baseline(unet, ref):
+def cpu_baseline(unet, ref, full=False):
     """The oracle (kind 'port': plain-PyTorch fp32 CPU restatement, pinned by the reference's goldens) on the host cores,
     bounded sample (~25 s): WARM timings (second of two runs) of one uncond Backbone forward on a 2-frame 512^2 window and
     of one ReferenceNet forward, extrapolated like the reference would run cfg2: per step one uncond + one cond forward of
@@ -100,6 +100,12 @@ def cpu_baseline(unet, ref):
         torch.set_num_threads(cores)
     F_WIN = 12
     t_uncond = t_unet * F_WIN / Fs
+    t_full = None
+    if full:   # ONE whole 12-frame cfg2 uncond forward (temporal attention ~ F^2, the 5-D GroupNorm working set)
+        xf = seeded_randn((1, 4, F_WIN, 64, 64), 1)
+        with torch.no_grad():
+            t_full = timed(lambda: U.unet_forward(sd_u, cases.SD15_MOTION, xf, 981, ctx), warm=False)
+        t_uncond = t_full
     t_cond = t_uncond * TFLOP_COND / TFLOP_UNCOND
     t_step = t_uncond + t_cond + 2 * t_ref
     t_step8 = (t_unet8 * F_WIN) * (1 + TFLOP_COND / TFLOP_UNCOND) + 2 * t_ref * (t_unet8 / (t_unet / Fs))
@@ -108,6 +114,7 @@ def cpu_baseline(unet, ref):
                       f"({t_ref:.1f}s); 12-frame step = 6 x uncond + 6.48 x (cond) + 2 x refnet = {t_step:.0f}s, x{NUM_INFERENCE_STEPS} steps",
             "value_8_threads": F_WIN / (NUM_INFERENCE_STEPS * t_step8),
             "sample_8_threads": f"1 cold 1-frame uncond fwd on 8 threads ({t_unet8:.1f}s), same extrapolation",
+            "full_12_frame_uncond_forward_s": t_full,
             "cfg1_seconds_per_forward": t_cfg1, "cfg1": "BASELINE configs[0]: (1,4,1,32,32), t=981, ctx 77x768, no motion module, full forward"}
 
 
@@ -173,6 +180,59 @@ def spawn_check(rank, world):
         print(json.dumps({"spawned_ranks": int(t.item()), "world_size": world}))
     td.barrier()
     td.destroy_process_group()
+
+
+def bench_vae(a, dev, dtype):
+    """--stage vae: decode_latents (EMOAnimationPipeline.py:291-307) of one denoised 12-frame 512x512 clip on the HIP AutoencoderKL
+    (SD-1.x geometry, 83.7 M parameters, name-keyed random weights): latents / 0.18215 -> per-frame decoder -> (x / 2 + 0.5).clamp
+    -> (1, 3, 12, 512, 512) f32.  A "step" = one whole decode_video call; value = decoded frames/s."""
+    from emote_hack_amd import ops
+    from emote_hack_amd.synth import seeded_randn, synth_state_dict
+    from emote_hack_amd.vae import AutoencoderKL, VAE_DEFAULTS, vae_param_shapes
+    vae = AutoencoderKL()
+    vae.load_state_dict(synth_state_dict(vae_param_shapes(dict(VAE_DEFAULTS)), prefix="vae.", device=dev))
+    vae.to(dev, dtype)
+    F = 12
+    lat = (0.18215 * seeded_randn((1, 4, F, 64, 64), 9)).to(dev)
+    for _ in range(max(1, a.warmup if a.warmup < 3 else 2)):
+        out = vae.decode_video(lat)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = max(1, min(a.steps, 10))
+    for _ in range(steps):
+        out = vae.decode_video(lat)
+    torch.cuda.synchronize()
+    dt_s = (time.perf_counter() - t0) / steps
+    res = {"metric": "VAE-decoded frames/s (512x512, decode_latents)", "value": F / dt_s, "unit": "frames/s", "n_gpus": 1, "steps": steps,
+           "warmup": 2, "ms_per_step": dt_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
+           "data": "synthetic",
+           "config": {"workload": "SURVEY 8(f) row 2: AutoencoderKL.decode_video of a (1,4,12,64,64) latent clip -> (1,3,12,512,512), "
+                                  "4 frames per decoder call, eager launches", "ms_per_frame": dt_s * 1e3 / F,
+                      "output_finite": bool(torch.isfinite(out).all())}}
+    if not a.no_profile:
+        prof = ops.KernelProfiler()
+        ops.PROFILER = prof
+        vae.decode_video(lat)
+        summ = prof.summary()
+        ops.PROFILER = None
+        dom = max((k for k in summ if summ[k]["flops"] > 0), key=lambda k: summ[k]["ms"])
+        d = summ[dom]
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / MFMA_PEAK_BF16_TFLOPS, "traffic": None, "launches_per_step": d["launches"],
+                           "avg_launch_us": d["ms"] * 1e3 / d["launches"]}
+        res["kernels"] = {k: {"launches_per_step": v["launches"], "ms_per_step": v["ms"],
+                              "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None,
+                              "gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in sorted(summ.items())}
+        res["config"]["executed_tflop_per_frame"] = sum(v["flops"] for v in summ.values()) / 1e12 / F
+        if os.environ.get("EMO_BENCH_SHAPES"):
+            rows = sorted(prof.by_shape().items(), key=lambda kv: -kv[1]["ms"])
+            with open(os.environ["EMO_BENCH_SHAPES"], "w") as f:
+                f.write("| kernel | shape | launches/clip | ms/clip | TFLOP/s | GB/s (algorithmic) |\n|---|---|---|---|---|---|\n")
+                for (name, tag), v in rows[:40]:
+                    tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["flops"] else 0.0
+                    f.write(f"| {name} | {tag} | {v['launches']:.1f} | {v['ms']:.3f} | {tf:.0f} | {v['bytes'] / (v['ms'] * 1e-3) / 1e9:.0f} |\n")
+    print(json.dumps(res))
 
 
 def bench_call(a, pipe, ref, dev, rank, world, dist, F_WIN, f_tot):
@@ -244,6 +304,15 @@ def main():
                          "entry point EMOAnimationPipeline.__call__ end to end for WHOLE 50-step clips (output_type='latent'): one "
                          "cold call (plan + graph capture), then --calls timed calls that reuse the prepared plan")
     ap.add_argument("--calls", type=int, default=2, help="--entry call: timed calls after the cold one")
+    ap.add_argument("--stage", default="loop", choices=["loop", "vae"],
+                    help="loop: the sampling loop (the headline metric); vae: the step right behind it - decode_latents of the 12-frame "
+                         "512x512 clip (EMOAnimationPipeline.py:291-307) on the HIP AutoencoderKL, ms per frame (SURVEY 8f row 2)")
+    ap.add_argument("--controlnet", action="store_true",
+                    help="the loop with the ControlNet branch on (EMOAnimationPipeline.py:718-746, SURVEY 8f row 1): SD-1.5-sized "
+                         "ControlNetModel on 512x512 conditioning images, residuals cached per frame and step")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="cpu_baseline from ONE full 12-frame cfg2 uncond forward of the oracle (BASELINE.md section 4) instead of the "
+                         "2-frame sample scaled x6: minutes of CPU time")
     ap.add_argument("--share-gpu", action="store_true", help="validation on a 1-GPU box: every rank on cuda:0, exchange through gloo "
                                                              "(RCCL takes one device per rank) - the number is NOT a multi-GPU measurement")
     a = ap.parse_args()
@@ -293,16 +362,29 @@ def main():
     if a.gn_fold_min_hw is not None:
         from emote_hack_amd import unet as unet_mod
         unet_mod.GN_FOLD_MIN_HW = a.gn_fold_min_hw
+    if a.stage == "vae":
+        return bench_vae(a, dev, dtype)
     unet, ref = build_models(dev, dtype)
     F_WIN = 12
     f_tot = F_WIN * world if a.mode == "weak" else 4 * F_WIN       # strong: BASELINE configs[3] - 48 frames = 4 windows
     pipe = EMOAnimationPipeline(unet=unet, scheduler=DDPMScheduler())
     if a.entry == "call":
         return bench_call(a, pipe, ref, dev, rank, world, dist, F_WIN, f_tot)
+    cn_kw = {}
+    if a.controlnet:   # SD-1.5-sized ControlNet (the Backbone's encoder geometry, magicanimate/models/controlnet.py:94-243)
+        from emote_hack_amd import ControlNetModel
+        from emote_hack_amd.spec import param_shapes
+        from emote_hack_amd.synth import synth_state_dict
+        from tests import cases
+        cn = ControlNetModel(**dict(cases.SD15, down_block_types=("CrossAttnDownBlock2D",) * 3 + ("DownBlock2D",)))
+        cn.load_state_dict(synth_state_dict(param_shapes(cn.spec), prefix="controlnet.", device=dev))
+        cn.to(dev, dtype)
+        cn_kw = dict(controlnet=cn, controlnet_cond=seeded_randn((f_tot, 3, 512, 512), 77).clamp(-1, 1) * 0.5 + 0.5,
+                     controlnet_conditioning_scale=1.0)
     st = pipe.prepare_denoise(seeded_randn((1, 4, f_tot, 64, 64), 1).to(dev), seeded_randn((1, 4, 64, 64), 3),
                               seeded_randn((2, 77, 768), 2), appearance_encoder=ref, num_inference_steps=NUM_INFERENCE_STEPS,
                               guidance_scale=7.5, context_frames=F_WIN, context_stride=1, context_overlap=0, seed=0,
-                              dist=dist, rank=rank, world_size=world, use_graphs=not a.no_graphs, reference_group=a.ref_group)
+                              dist=dist, rank=rank, world_size=world, use_graphs=not a.no_graphs, reference_group=a.ref_group, **cn_kw)
     n_win = world if a.mode == "weak" else 4
     assert len(st.windows) == n_win and len(st.units) == 2 * n_win
     assert sum(len(c.units) for c in st.calls) == (2 if a.mode == "weak" else len(st.units[rank::world]))
@@ -362,6 +444,7 @@ def main():
                                     if a.mode == "weak" else
                                     "cfg4 (BASELINE configs[3]): 512x512 latents 64x64, ONE 48-frame clip = 4 windows of 12 x 2 CFG branches "
                                     f"= 8 units over {world} GPU(s), 50-step DDPM, CFG 7.5, ") +
+                                   ("ControlNet branch ON (SD-1.5-sized, 512x512 conditioning images, per-frame residual cache), " if a.controlnet else "") +
                                    "ReferenceNet on (midup), motion modules res 1/2/4/8, ctx 77x768; 1 step = 1 loop iteration "
                                    f"+ 1/{st.T} of a {st.T}-timestep ReferenceNet pass",
                        "frames_total": f_tot, "num_inference_steps": NUM_INFERENCE_STEPS,
@@ -425,7 +508,7 @@ def main():
                             f"{v['bytes'] / (v['ms'] * 1e-3) / 1e9:.0f} |\n")
         if world == 1 and not a.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(unet, ref)
+                out["cpu_baseline"] = cpu_baseline(unet, ref, full=a.cpu_baseline_full)
             except Exception as ex:   # the baseline leg must never cost the measurement
                 out["cpu_baseline"] = {"error": f"{type(ex).__name__}: {ex}"}
         print(json.dumps(out))

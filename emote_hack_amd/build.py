@@ -59,6 +59,9 @@ def build_extension(force: bool = False, verbose: bool = True) -> str:
         with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
             list(ex.map(run, jobs))
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
+        # every kernel stub must resolve NOW (RTLD_NOW): a kernel template the host pass dropped links fine and fails at load time
+        import ctypes
+        ctypes.CDLL(LIB, mode=getattr(os, "RTLD_NOW", 2))
     return LIB
 
 

@@ -11,10 +11,10 @@
 //                    GEMM's epilogue), B = P straight from the S^T accumulator registers - no LDS round
 //                    trip, no cross-lane traffic: the K tile is stored with row bits 2<->3 swapped so that
 //                    a lane's 8 consecutive P registers are 8 consecutive keys.
-//   KV tiles stream through an LDS RING filled by asynchronous global_load_lds_dwordx4 (no VGPR staging):
+//   KV tiles stream through an LDS RING filled by asynchronous LDS-DMA (buffer_load_dwordx4 ... lds, no VGPR staging):
 //   tiles t+1 (and t+2) are in flight while tile t is consumed; counted `s_waitcnt vmcnt`, one raw s_barrier
-//   per tile.  The LDS image is lane-linear, so K rows are padded to an ODD number of 16-byte chunks by sourcing
-//   the pad chunk from a zero page, V^T rows are XOR-swizzled (conflict-free ds_read_b128 either way); fragment reads
+//   per tile.  The LDS image is lane-linear, so K rows are padded to an ODD number of 16-byte chunks (the pad chunk
+//   reads out of range = 0), V^T rows are XOR-swizzled (conflict-free ds_read_b128 either way); fragment reads
 //   are inline-asm ds_read_b128 with hand-counted lgkmcnt (hipcc would drain vmcnt(0) before every C++ LDS
 //   read while a glds is in flight).
 // Two KV segments: [self / context keys of the batch row] ++ [a bank shared by seg1_div consecutive
@@ -32,7 +32,6 @@ static constexpr int ATT_THREADS = 256, BQ = 128, TK = 64;
 #define EMO_ATT_PRIO_DOWN() ((void)0)
 #endif
 
-__device__ __attribute__((aligned(16))) unsigned int g_att_zero_page[4] = {0, 0, 0, 0};
 __device__ __attribute__((aligned(16))) unsigned int g_att_ones_bf16[4] = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
 __device__ __attribute__((aligned(16))) unsigned int g_att_ones_f32[4] = {0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u};
 __device__ __attribute__((aligned(16))) unsigned int g_att_ones_f16[4] = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
@@ -58,8 +57,11 @@ struct AttCfg {
   static constexpr int STEPS = 32 / (2 * V);                   // mma16 steps per 32-key sub-tile
 };
 
-#define EMO_GLDS16(gptr, lptr) \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+// (a __device__ function, not a call inside the kernel's lambdas: with the builtin in the kernel template's own body the HOST pass
+// silently drops the kernel's stub - every launch then fails to link)
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, __attribute__((address_space(3))) unsigned char* lds_dst, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds_dst, 16, voff, 0, 0, 0);
+}
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ uint4 lds_read16(unsigned addr) {
@@ -67,9 +69,20 @@ __device__ __forceinline__ uint4 lds_read16(unsigned addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
   return v;
 }
+template <int OFF> __device__ __forceinline__ uint4 lds_read16_at(unsigned addr) {   // addr + OFF with OFF in the instruction (16-bit field)
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+  uint4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
 __device__ __forceinline__ float max3f(float a, float b, float c) {   // no NaNs in play: skip fmaxf's canonicalisation
   float r;
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float max2f(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -78,6 +91,7 @@ __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1)
 // G = glds per wave per tile, NSR = ring depth, QT = 32-query tiles per wave (2 halves the LDS fragment traffic per MFMA)
 // RES = the resident-context variant (below): its own instantiation - the walk over q tiles costs ~20 registers, which the
 // self-attention launches (3 waves per SIMD at d = 40) do not have
+// (four blocks per CU at d <= 48 - 128 registers, 2-deep ring - spills 32-130 bytes per lane: not offered)
 template <typename T, int DCH, int G, int NSR, int QT, bool RES>
 __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) void attention_kernel(const emo_attention_params p, int stage_bytes, int order_mode, int q_rep_arg) {
   const int q_rep = RES ? q_rep_arg : 1;
@@ -119,9 +133,6 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
   }
   const int d = p.d;
   const int dch_real = d / V;  // d*sizeof(T) % 16 == 0 checked on the host
-  const T* zero = (const T*)g_att_zero_page;
-  const T* ones = std::is_same<T, float>::value ? (const T*)g_att_ones_f32
-                  : (std::is_same<T, bf16_t>::value ? (const T*)g_att_ones_bf16 : (const T*)g_att_ones_f16);
 
   // ---- zero the whole ring once: V^T pad rows (n >= d) are never written by the loader and must be 0
   // ... except V^T row d, which is all ONES when the head dim leaves a pad row (d < NT*32: 40, 80): row d of O^T = V^T P^T
@@ -141,24 +152,24 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
     }
   }
 
-  // ---- loader geometry: glds #g of this wave writes LDS chunk positions (g*4 + wave)*64 + lane of the stage
-  //      [0, K_CHUNKS): K rows (row = pos / DCHP holds key (row&32)|swap23(row&31));  then d V^T rows of VCHP chunks
-  int ld_kind[G];     // 0 = zero page, 1 = K chunk, 2 = V^T chunk
-  int ld_a[G], ld_c[G];
+  // ---- loader: LDS-DMA through BUFFER descriptors (buffer_load_dwordx4 ... offen lds).  Request #g of this wave writes the LDS
+  // chunk positions (g*4 + wave)*64 + lane of the stage: [0, K_CHUNKS) = K rows (row = pos / DCHP holds key (row&32)|swap23(row&31)),
+  // then d V^T rows of VCHP chunks, then pad rows.  K_CHUNKS and d * VCHP are multiples of 64, so one wave-level request lies
+  // entirely in K rows, in V^T rows, or behind them: its descriptor (K slab | V^T slab of this (batch row, head) | the 16-byte
+  // ones constant) and its per-tile advance are WAVE-UNIFORM (SGPRs); a lane carries one 32-bit byte offset per request, bumped by
+  // one v_add per tile.  What the 64-bit-pointer loader did with per-lane pointer selects now falls out of the hardware range
+  // check (it applies to the vector offset): pad chunks and pad rows carry an offset beyond every slab and read 0; K rows
+  // >= Lk of a ragged last tile lie behind the descriptor's extent ((Lk-1) * ldk + d elements) and read 0 without a special path.
+  constexpr unsigned OOB = 0xC0000000u;       // stays out of range under < 1 GB of per-tile advances
+  constexpr int SZ = (int)sizeof(T);
+  int ld_kind[G];                             // wave-uniform: 0 = K rows, 1 = V^T rows, 2 = behind them (ones row / zero pad)
+  unsigned ld_off[G];                         // this lane's running byte offset into the request's slab
 #pragma unroll
   for (int g = 0; g < G; g++) {
-    const int pos = (g * 4 + wave) * 64 + lane;
-    ld_kind[g] = 0; ld_a[g] = 0; ld_c[g] = 0;
-    if (pos < K_CHUNKS) {
-      const int row = pos / DCHP, c = pos % DCHP;
-      if (c < dch_real) { ld_kind[g] = 1; ld_a[g] = (row & 32) | swap23(row & 31); ld_c[g] = c; }
-    } else {
-      const int qv = pos - K_CHUNKS, n = qv / VCHP, c = (qv % VCHP) ^ Cfg::vkey(n);
-      if (n < d) { ld_kind[g] = 2; ld_a[g] = n; ld_c[g] = c; }
-      else if (ones_row && n == d) ld_kind[g] = 3;   // the all-ones row (the loader rewrites the part its rounds cover)
-    }
+    const int p0 = (g * 4 + wave) * 64;
+    ld_kind[g] = p0 < K_CHUNKS ? 0 : (p0 - K_CHUNKS < d * VCHP ? 1 : 2);
   }
-
+  const unsigned* ones_u = std::is_same<T, float>::value ? g_att_ones_f32 : (std::is_same<T, bf16_t>::value ? g_att_ones_bf16 : g_att_ones_f16);
   // ---- tile list over the (up to two) KV segments
   const int nseg = (p.k1 != nullptr && b >= p.seg1_first_batch) ? 2 : 1;
   const int tiles0 = (p.Lk0 + TK - 1) / TK;
@@ -170,19 +181,33 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
   const T* kbase1 = nseg == 2 ? (const T*)p.k1 + (int64_t)kb1 * p.Lk1 * p.ldk1 + head * d : nullptr;
   const T* vbase1 = nseg == 2 ? (const T*)p.v1t + ((int64_t)kb1 * p.heads * d + (int64_t)head * d) * p.ldv1t : nullptr;
 
-  // per-glds source pointers, advanced by a constant per tile (K chunk: TK rows, V^T chunk: TK keys); only the last tile
-  // of a segment (it may run past Lk) recomputes addresses with bounds checks.  Tiles are issued strictly in order.
-  const T* ld_ptr[G];
-  int64_t ld_inc[G];
+  __amdgpu_buffer_rsrc_t ld_rsrc[G];
+  int ld_inc[G];
   auto setup_segment = [&](bool s1) {
     const int64_t ldk = s1 ? p.ldk1 : p.ldk0, ldvt = s1 ? p.ldv1t : p.ldv0t;
+    const int Lk = s1 ? p.Lk1 : p.Lk0;
     const T* kbase = s1 ? kbase1 : kbase0;
     const T* vbase = s1 ? vbase1 : vbase0;
+    // (extents < 2^31 bytes: checked on the host)
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)(((int64_t)(Lk - 1) * ldk + d) * SZ), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)((int64_t)d * ldvt * SZ), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)ones_u, 0, 16, 0x00020000);
 #pragma unroll
     for (int g = 0; g < G; g++) {
-      if (ld_kind[g] == 1) { ld_ptr[g] = kbase + (int64_t)ld_a[g] * ldk + ld_c[g] * V; ld_inc[g] = (int64_t)TK * ldk; }
-      else if (ld_kind[g] == 2) { ld_ptr[g] = vbase + (int64_t)ld_a[g] * ldvt + ld_c[g] * V; ld_inc[g] = TK; }
-      else { ld_ptr[g] = ld_kind[g] == 3 ? ones : zero; ld_inc[g] = 0; }
+      const int pos = (g * 4 + wave) * 64 + lane;
+      if (ld_kind[g] == 0) {
+        const int row = pos / DCHP, c = pos % DCHP;
+        ld_rsrc[g] = rk; ld_inc[g] = (int)(TK * ldk * SZ);
+        ld_off[g] = c < dch_real ? (unsigned)((((row & 32) | swap23(row & 31)) * ldk + c * V) * SZ) : OOB;
+      } else if (ld_kind[g] == 1) {
+        const int qv = pos - K_CHUNKS, n = qv / VCHP, c = (qv % VCHP) ^ Cfg::vkey(n);
+        ld_rsrc[g] = rv; ld_inc[g] = TK * SZ;
+        ld_off[g] = (unsigned)((n * ldvt + c * V) * SZ);
+      } else {
+        const int n = (pos - K_CHUNKS) / VCHP;
+        ld_rsrc[g] = ro; ld_inc[g] = 0;
+        ld_off[g] = (ones_row && n == d) ? 0u : OOB;     // the all-ones row (rewritten where the rounds cover it), zeros behind it
+      }
     }
   };
   setup_segment(false);
@@ -191,25 +216,61 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
     if (s1 && t == tiles0) setup_segment(true);
     const int k0 = (s1 ? t - tiles0 : t) * TK;
     const int Lk = s1 ? p.Lk1 : p.Lk0;
-    unsigned char* st = smem + slot * stage_bytes;
+    __attribute__((address_space(3))) unsigned char* st = (__attribute__((address_space(3))) unsigned char*)smem + slot * stage_bytes + wave * 1024;
     if (k0 + TK <= Lk) {
 #pragma unroll
       for (int g = 0; g < G; g++) {
-        EMO_GLDS16(ld_ptr[g], st + (g * 4 + wave) * 1024);
-        ld_ptr[g] += ld_inc[g];
+        lds_dma16(ld_rsrc[g], st + g * 4096, ld_off[g]);
+        ld_off[g] += ld_inc[g];
       }
-    } else {   // last tile of the segment
+    } else {   // last tile of the segment: V^T chunks wholly past Lk read 0 (the chunk straddling Lk is cleaned in LDS below)
 #pragma unroll
       for (int g = 0; g < G; g++) {
-        const T* src = ld_ptr[g];
-        if (ld_kind[g] == 1) { if (k0 + ld_a[g] >= Lk) src = zero; }
-        else if (ld_kind[g] == 2) { if (k0 + ld_c[g] * V >= Lk) src = zero; }   // a chunk straddling Lk is cleaned in LDS below
-        EMO_GLDS16(src, st + (g * 4 + wave) * 1024);
+        unsigned off = ld_off[g];
+        if (ld_kind[g] == 1) {
+          const int qv = (g * 4 + wave) * 64 + lane - K_CHUNKS, n = qv / VCHP, c = (qv % VCHP) ^ Cfg::vkey(n);
+          if (k0 + c * V >= Lk) off = OOB;
+        }
+        lds_dma16(ld_rsrc[g], st + g * 4096, off);
       }
     }
   };
   const float c_exp = p.scale * 1.4426950408889634f;
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+  // ---- fragment reads: one address per lane and tile, everything else rides in the instructions' offset fields
+  //   K  : row (st*32 + l31), chunks 2*kk + half            -> base + st*32*KROW + kk*32
+  //   V^T: row (nt*32 + l31), chunk ((st*4 + 2*sp [+ half]) scaled to the element size) ^ vkey(row); vkey repeats every 32 rows and
+  //        the chunk field of the address is XORed in place (rows and stages are multiples of the 16 * VCH byte row)
+  static_assert((K_CHUNKS * 16) % (VCH * 16) == 0 && (32 / Cfg::VRPB) % VCH == 0, "V^T read addressing");
+  const unsigned k_lane = l31 * KROW + half * 16;
+  const unsigned v_lane = l31 * VROW + ((((8 * half * SZ) >> 4) ^ Cfg::vkey(l31)) * 16);
+  auto read_k_frags = [&](unsigned ks, uint4 (&kf)[2][DCH / 2]) {
+    const unsigned a = ks + k_lane;
+    static_for<2>([&](auto ST) {
+      static_for<DCH / 2>([&](auto KK) {
+        constexpr int st = decltype(ST)::value, kk = decltype(KK)::value;
+        kf[st][kk] = lds_read16_at<st * 32 * KROW + kk * 32>(a);
+      });
+    });
+  };
+  auto read_v_frags = [&](unsigned vs, auto ST, uint4 (&vf)[STEPS][NT]) {
+    constexpr int st = decltype(ST)::value;
+    static_for<STEPS>([&](auto SP) {
+      constexpr int sp = decltype(SP)::value;
+      constexpr int key0 = st * 32 + 16 * ((sp * V) >> 3) + ((sp * V) & 7);     // + 8 * half: in v_lane
+      const unsigned a = (vs + v_lane) ^ (unsigned)(((key0 * SZ) >> 4) * 16);
+      static_for<NT>([&](auto N) {
+        constexpr int nt = decltype(N)::value;
+        vf[sp][nt] = lds_read16_at<nt * 32 * VROW>(a);
+      });
+      if constexpr (STEPS * NT > 15) {           // lgkmcnt is a 4-bit counter: drain per step for the widest heads
+        wait_lgkmcnt<0>();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+  };
+  if ((lds_base & (VROW - 1)) != 0) __builtin_trap();   // the XOR above needs the dynamic LDS base on a V^T row boundary (no static LDS in front)
 
   __syncthreads();   // ring zeroed before the first async write lands (plain LDS stores: lgkmcnt drained by the barrier)
 #pragma unroll
@@ -279,62 +340,45 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
 #pragma unroll
   for (int t = 0; t < QT; t++) { m_run[t] = -1e30f; l_run[t] = 0.f; }
 
-  for (int t = 0; t < ntiles; t++) {
-    if (fill) {
-      if constexpr (NSR == 1) issue(t, 0);
-      const int rem = ntiles - 1 - t;
-      if constexpr (NSR >= 3) {
-        if (rem >= NSR - 2) wait_vmcnt<(NSR - 2) * G>();
-        else wait_vmcnt<0>();
-      } else {
-        wait_vmcnt<0>();
-      }
-      __builtin_amdgcn_s_barrier();
-      if constexpr (NSR > 1) {
-        if (t + NSR - 1 < ntiles) issue(t + NSR - 1, (t + NSR - 1) % NSR);
-      }
-    }
-    const bool s1 = t >= tiles0;
-    const int k0 = (s1 ? t - tiles0 : t) * TK;
-    const int Lk = s1 ? p.Lk1 : p.Lk0;
-    const unsigned st_base = lds_base + (t % NSR) * stage_bytes;
-    const unsigned ks_base = st_base, vs_base = st_base + K_CHUNKS * 16;
-    if (fill && k0 + TK > Lk && (Lk % V) != 0) {
-      // ragged last tile whose final 16-byte V^T chunk straddles Lk: zero the columns >= Lk in LDS (their P is
-      // exactly 0, but 0 * garbage must not become NaN).  Rare (context length 77); costs one extra barrier.
-      const int cpart = (Lk - k0) / V, efirst = (Lk - k0) % V;
-      unsigned char* vs = smem + (t % NSR) * stage_bytes + K_CHUNKS * 16;
-      for (int n = tid; n < d; n += ATT_THREADS) {
-        uint4* ptr = (uint4*)(vs + n * VROW + (cpart ^ Cfg::vkey(n)) * 16);
-        float f[V];
-        unpack16<T>(*ptr, f);
+  // ---- one 64-key tile (ring slot at byte offset st_off) against the wave's query rows: S^T for both 32-key sub-tiles, ONE
+  // online-softmax update per query row per tile, then O^T += V^T P^T.  FAST = an interior tile of its segment: no key mask,
+  // no V^T clean-up, both sub-tiles; (k0, Lk) matter to the other tiles only.  The V^T fragment reads of the first sub-tile go
+  // out right behind the Q.K^T MFMAs (they fill the MFMA result latency the max chain would otherwise wait out in s_nops).
+  auto tile = [&](unsigned st_off, int k0, int Lk, auto FAST) {
+    constexpr bool fast = decltype(FAST)::value;
+    const unsigned ks_base = lds_base + st_off, vs_base = ks_base + K_CHUNKS * 16;
+    bool ragged = false, second = true;
+    if constexpr (!fast) {
+      ragged = k0 + TK > Lk;               // wave-uniform
+      second = k0 + 32 < Lk;               // ragged last tile (the 77-key context): the second sub-tile may hold no key
+      if (fill && ragged && (Lk % V) != 0) {
+        // ragged last tile whose final 16-byte V^T chunk straddles Lk: zero the columns >= Lk in LDS (their P is
+        // exactly 0, but 0 * garbage must not become NaN).  Rare (context length 77); costs one extra barrier.
+        const int cpart = (Lk - k0) / V, efirst = (Lk - k0) % V;
+        unsigned char* vs = smem + st_off + K_CHUNKS * 16;
+        for (int n = tid; n < d; n += ATT_THREADS) {
+          uint4* ptr = (uint4*)(vs + n * VROW + (cpart ^ Cfg::vkey(n)) * 16);
+          float f[V];
+          unpack16<T>(*ptr, f);
 #pragma unroll
-        for (int e = 0; e < V; e++) if (e >= efirst) f[e] = 0.f;
-        *ptr = pack16<T>(f);
+          for (int e = 0; e < V; e++) if (e >= efirst) f[e] = 0.f;
+          *ptr = pack16<T>(f);
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
-
-    // The whole 64-key tile is processed at once: S^T for both 32-key sub-tiles, ONE online-softmax update per query
-    // row per tile (half the max/rescale work of per-sub-tile updates), then O^T += V^T P^T.  K and V^T fragments are
-    // read once per wave and reused for the QT query tiles.
     uint4 kf[2][DCH / 2];
-#pragma unroll
-    for (int st = 0; st < 2; st++) {
-      const unsigned krow = ks_base + (st * 32 + l31) * KROW + half * 16;
-#pragma unroll
-      for (int kk = 0; kk < DCH / 2; kk++) kf[st][kk] = lds_read16(krow + kk * 32);
-    }
+    read_k_frags(ks_base, kf);
     wait_lgkmcnt<0>();
     __builtin_amdgcn_sched_barrier(0);
     uint4 pf[QT][2][STEPS];                        // P^T fragments (B operand of the PV MFMAs)
+    uint4 vf0[STEPS][NT];
+    constexpr bool early_v = STEPS * NT <= 8;      // (the widest heads drain lgkmcnt per step and keep their reads next to the MFMAs)
 #pragma unroll
     for (int t = 0; t < QT; t++) {
       f32x16 s0, s1;
 #pragma unroll
       for (int r = 0; r < 16; r++) { s0[r] = 0.f; s1[r] = 0.f; }
-      // (both 32-key sub-tiles always: the keys of a ragged last tile past Lk are zero rows masked to -1e30 below, their V^T
-      // columns are zero - a branch here costs a 16-register zero fill of s1 through SGPRs in every tile)
       EMO_ATT_PRIO_UP();
 #pragma unroll
       for (int kk = 0; kk < DCH / 2; kk++) {
@@ -342,22 +386,41 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
         s1 = mma16<T>(kf[1][kk], qf[t][kk], s1);
       }
       EMO_ATT_PRIO_DOWN();
-      if (k0 + TK > Lk) {   // ragged last tile only (wave-uniform): mask keys >= Lk
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int key = k0 + 16 * (r >> 3) + 8 * half + (r & 7);
-          if (key >= Lk) s0[r] = -1e30f;
-          if (key + 32 >= Lk) s1[r] = -1e30f;
+      if constexpr (early_v) {
+        if (t == QT - 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          read_v_frags(vs_base, std::integral_constant<int, 0>{}, vf0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-      float mx = max3f(s0[0], s1[0], s0[1]);
-      mx = max3f(mx, s1[1], s0[2]);
-      mx = max3f(mx, s1[2], s0[3]);
-      mx = fmaxf(mx, s1[3]);
+      if constexpr (!fast) {
+        if (ragged) {   // keys >= Lk
 #pragma unroll
-      for (int r = 4; r < 16; r += 2) { mx = max3f(mx, s0[r], s1[r]); mx = max3f(mx, s0[r + 1], s1[r + 1]); }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[t], mx);
+          for (int r = 0; r < 16; r++) {
+            const int key = k0 + 16 * (r >> 3) + 8 * half + (r & 7);
+            if (key >= Lk) s0[r] = -1e30f;
+            if (key + 32 >= Lk) s1[r] = -1e30f;
+          }
+        }
+      }
+      // The max chain below is inline asm (v_max3_f32 has no builtin), and hipcc pads no hazard whose consumer sits inside an asm
+      // string: an MFMA result read too early by a VALU instruction is stale, silently (with one k-step - d = 8 - the chain read
+      // the accumulators 4 instructions behind their MFMAs and the output changed from run to run).  One compiler-visible VALU
+      // read of the LAST accumulator written makes the hazard recogniser wait out the MFMA; everything behind it is safe.
+      // (an identity v_mov_b32_dpp - quad_perm [0,1,2,3] - the optimiser cannot fold away)
+      s1[0] = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(s1[0]), 0xE4, 0xF, 0xF, true));
+      // row maximum over the lane's 32 scores: two chains (half the dependent latency), then the other half-wave's 32 keys of the
+      // same query row through v_permlane32_swap (VALU; __shfl_xor is an LDS round trip + 6 address instructions)
+      float mxa = max3f(s0[0], s1[0], s0[1]), mxb = max3f(s0[8], s1[8], s0[9]);
+#pragma unroll
+      for (int r = 1; r < 7; r++) { mxa = max3f(mxa, s1[r], s0[r + 1]); mxb = max3f(mxb, s1[r + 8], s0[r + 9]); }
+      float mx = max3f(mxa, mxb, s1[7]);
+      mx = max2f(mx, s1[15]);
+      {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = max2f(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      }
+      const float m_new = max2f(m_run[t], mx);
       const float alpha = __builtin_amdgcn_exp2f((m_run[t] - m_new) * c_exp);   // raw v_exp_f32: arguments are <= 0, no denormal care
       m_run[t] = m_new;
       const float m_sc = m_new * c_exp;
@@ -398,25 +461,26 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
         }
       }
     }
-    // ---- O^T += V^T . P^T : per sub-tile the V^T fragments are read once and feed the QT query tiles
+    // ---- O^T += V^T . P^T : per sub-tile the V^T fragments are read once and feed the QT query tiles; the second sub-tile's reads
+    // go out in front of the first one's MFMAs
+    uint4 vf1[STEPS][NT];
+    if constexpr (!early_v) read_v_frags(vs_base, std::integral_constant<int, 0>{}, vf0);
+    wait_lgkmcnt<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (early_v) {
+      if (fast || second) read_v_frags(vs_base, std::integral_constant<int, 1>{}, vf1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    EMO_ATT_PRIO_UP();
 #pragma unroll
-    for (int st = 0; st < 2; st++) {
-      if (st == 1 && k0 + 32 >= Lk) break;         // ragged last tile (the 77-key context): the second sub-tile holds no key
-      uint4 vf[STEPS][NT];
+    for (int sp = 0; sp < STEPS; sp++)
 #pragma unroll
-      for (int sp = 0; sp < STEPS; sp++) {
-        const int r0 = sp * V;
-        const int key_off = st * 32 + 16 * (r0 >> 3) + 8 * half + (r0 & 7);
+      for (int t = 0; t < QT; t++)
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-          const int n = nt * 32 + l31;
-          vf[sp][nt] = lds_read16(vs_base + n * VROW + (((key_off * (int)sizeof(T)) >> 4) ^ Cfg::vkey(n)) * 16);
-        }
-        if constexpr (STEPS * NT > 15) {           // lgkmcnt is a 4-bit counter: drain per step for the widest heads
-          wait_lgkmcnt<0>();
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
+        for (int nt = 0; nt < NT; nt++) o[t][nt] = mma16<T>(vf0[sp][nt], pf[t][0][sp], o[t][nt]);
+    EMO_ATT_PRIO_DOWN();
+    if (fast || second) {
+      if constexpr (!early_v) read_v_frags(vs_base, std::integral_constant<int, 1>{}, vf1);
       wait_lgkmcnt<0>();
       __builtin_amdgcn_sched_barrier(0);
       EMO_ATT_PRIO_UP();
@@ -425,12 +489,70 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
 #pragma unroll
         for (int t = 0; t < QT; t++)
 #pragma unroll
-          for (int nt = 0; nt < NT; nt++) {
-            o[t][nt] = mma16<T>(vf[sp][nt], pf[t][st][sp], o[t][nt]);
-          }
+          for (int nt = 0; nt < NT; nt++) o[t][nt] = mma16<T>(vf1[sp][nt], pf[t][1][sp], o[t][nt]);
       EMO_ATT_PRIO_DOWN();
     }
+  };
+
+  // ---- the tile loop.  Interior tiles run the FAST body with the ring position and the loader state kept INCREMENTALLY: the
+  // general body recomputed slot, segment, key range and request geometry per tile (~55 scalar instructions, among them a
+  // kernel-argument load and two divisions by the ring depth), and on this kernel every instruction counts: the SIMD's issue
+  // time is the sum of its waves' instructions (profiles/r04*_attention_pmc.txt: MFMA + VALU + SALU + LDS + s_nop active cycles
+  // add up to ~90 % of the SIMD cycles whatever the schedule).  A tile is SPECIAL when it is the last of its segment (mask /
+  // clean-up) or when the tile it requests (NSR-1 ahead) is the last of a segment, the first of the bank segment (new
+  // descriptors) or does not exist; at most 2 * NSR + 1 tiles of a launch.
+  constexpr int AHEAD = NSR - 1;
+  const unsigned ring_bytes = (unsigned)NSR * (unsigned)stage_bytes;
+  unsigned c_off = 0, i_off = (unsigned)(AHEAD % NSR) * (unsigned)stage_bytes;      // consumer / request slot (byte offsets)
+  auto next_special = [&](int t) {
+    int c = ntiles - 1 - AHEAD;
+    const int cand[3] = {tiles0 - 1 - AHEAD, tiles0 - AHEAD, tiles0 - 1};
+#pragma unroll
+    for (int i = 0; i < 3; i++) if (cand[i] >= t && cand[i] < c) c = cand[i];
+    return c > t ? c : t;
+  };
+  for (int t = 0; t < ntiles;) {
+    if constexpr (NSR >= 2 && !RES) {
+      const int fast_end = next_special(t);
+      for (; t < fast_end; t++) {
+        wait_vmcnt<(NSR - 2) * G>();
+        __builtin_amdgcn_s_barrier();
+        {   // request tile t + AHEAD: an interior tile of the segment being streamed
+          __attribute__((address_space(3))) unsigned char* st = (__attribute__((address_space(3))) unsigned char*)smem + i_off + wave * 1024;
+#pragma unroll
+          for (int g = 0; g < G; g++) {
+            lds_dma16(ld_rsrc[g], st + g * 4096, ld_off[g]);
+            ld_off[g] += ld_inc[g];
+          }
+        }
+        tile(c_off, 0, 0, std::true_type{});
+        c_off += stage_bytes; if (c_off == ring_bytes) c_off = 0;
+        i_off += stage_bytes; if (i_off == ring_bytes) i_off = 0;
+      }
+      if (t >= ntiles) break;
+    }
+    if (fill) {
+      if constexpr (NSR == 1) issue(t, 0);
+      const int rem = ntiles - 1 - t;
+      if constexpr (NSR >= 3) {
+        if (rem >= NSR - 2) wait_vmcnt<(NSR - 2) * G>();
+        else wait_vmcnt<0>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      if constexpr (NSR > 1) {
+        if (t + AHEAD < ntiles) issue(t + AHEAD, (t + AHEAD) % NSR);
+      }
+    }
+    {
+      const bool s1 = t >= tiles0;
+      tile(c_off, (s1 ? t - tiles0 : t) * TK, s1 ? p.Lk1 : p.Lk0, std::false_type{});
+    }
     if constexpr (NSR == 1) { if (q_rep == 1) __builtin_amdgcn_s_barrier(); }   // synchronous ring: nobody may still read slot 0 (resident: one tile, never rewritten)
+    c_off += stage_bytes; if (c_off == ring_bytes) c_off = 0;
+    i_off += stage_bytes; if (i_off == ring_bytes) i_off = 0;
+    t++;
   }
 
   // ---- normalise and store: lane holds O[q][n], n = nt*32 + 8*(r>>2) + 4*half + (r&3)
@@ -594,6 +716,14 @@ extern "C" int emo_attention(const emo_attention_params* pp, void* stream) {
   if (p.k1) {
     EMO_CHECK(p.v1t && p.Lk1 > 0 && (p.seg1_div > 0 || p.seg1_row) && p.ldk1 % V == 0 && p.ldv1t % V == 0 && p.ldv1t >= p.Lk1, EMO_ERR_BAD_SHAPE,
               "emo_attention: segment-1 geometry");
+  }
+  {   // the loader addresses one (batch row, head) slab of K and of V^T through 32-bit buffer offsets
+    const int64_t sz = p.dtype == EMO_F32 ? 4 : 2, lim = (int64_t)1 << 30;
+    EMO_CHECK(((int64_t)p.Lk0 + 64) * p.ldk0 * sz < lim && (int64_t)p.d * p.ldv0t * sz < lim, EMO_ERR_BAD_SHAPE,
+              "emo_attention: a K / V^T slab of segment 0 exceeds 1 GB (Lk0 %d, ldk0 %lld, ldv0t %lld)", p.Lk0, (long long)p.ldk0, (long long)p.ldv0t);
+    if (p.k1)
+      EMO_CHECK(((int64_t)p.Lk1 + 64) * p.ldk1 * sz < lim && (int64_t)p.d * p.ldv1t * sz < lim, EMO_ERR_BAD_SHAPE,
+                "emo_attention: a K / V^T slab of segment 1 exceeds 1 GB (Lk1 %d, ldk1 %lld, ldv1t %lld)", p.Lk1, (long long)p.ldk1, (long long)p.ldv1t);
   }
   hipStream_t st = as_stream(stream);
   EMO_DISPATCH(p.dtype, "emo_attention", return dispatch_attention<T>(p, st));

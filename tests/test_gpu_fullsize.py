@@ -172,3 +172,44 @@ def test_cfg4_48_frames_four_windows_full_size(cfg2_models):
     lat_48, _ = _run_loop(unet, ref, 2, graphs=True, ref_group=2, frames=48, ddim=True)
     lat_12, _ = _run_loop(unet, ref, 2, graphs=True, ref_group=2, frames=48, ddim=True, frame_slice=slice(36, 48))
     assert torch.equal(lat_48[:, :, 36:], lat_12)                          # the LAST window: the fourth UNet call of a step
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_level0_transformer_and_motion_block_at_bench_size_vs_oracle(dtype):
+    """One level-0 Transformer3DModel block (attention.py:112-161,276-320) + its motion module (motion_module.py:139-334) at the size
+    bench.py runs them - 12 frames x 64 x 64 tokens x 320 channels, 8 heads of 40, 77 text keys - against the reference-pinned CPU
+    oracle (oracle/unet_ref.py), not HIP-vs-HIP: f32 at north_star's rtol 1e-3 / atol 1e-4; bf16 (the run that takes the
+    full-size-only plans: 256x256 ping-pong tiles, GroupNorm folded into per-frame proj_in slabs at HW >= 4096, LayerNorm-folded
+    projections, the fused ff.net.2 + proj_out tail, the pipelined d = 40 attention) within the low-precision yard-stick."""
+    from oracle import unet_ref as U
+    from emote_hack_amd import ops
+    from emote_hack_amd.spec import build_spec, param_shapes
+    from emote_hack_amd.unet import UNet3DConditionModel, _Ctx
+    # the first down level only: same level-0 blocks, a fraction of the weights
+    cfg = dict(cases.SD15_MOTION, block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock3D", "DownBlock3D"),
+               up_block_types=("UpBlock3D", "CrossAttnUpBlock3D"), layers_per_block=1)
+    m = UNet3DConditionModel(**cfg)
+    sd = synth_state_dict(param_shapes(m.spec))
+    m.load_state_dict(sd)
+    m.to(DEV, dtype)
+    a, mo = m.spec.down[0].attentions[0], m.spec.down[0].motions[0]
+    assert a.channels == 320 and a.heads == 8 and mo is not None
+    Fr, H, W = 12, 64, 64
+    x = seeded_randn((1, 320, Fr, H, W), 21)
+    ctx = seeded_randn((1, 77, 768), 22)
+    # ---- oracle, frame by frame for the spatial transformer (per-frame GroupNorm, per-frame attention: 2 x 8 x 4096^2 f32 scores a go)
+    with torch.no_grad():
+        parts = [U.transformer3d(sd, a.prefix, x[:, :, f0:f0 + 2], ctx, 8, 32) for f0 in range(0, Fr, 2)]
+        ref_t = torch.cat(parts, 2)
+        ref_m = U.motion_module(sd, mo.prefix, ref_t, 8)
+    # ---- HIP
+    c = _Ctx(1, Fr, H, W)
+    rows = ops.ncfhw_to_rows(x.to(DEV), dtype)
+    ctx_rows = ops.convert(ctx.to(DEV).float().reshape(-1, 768), dtype)
+    yt = m._transformer(a, rows, ctx_rows, 77, Fr, c, H, W)
+    got_t = ops.rows_to_ncfhw(yt, 1, 320, Fr, H, W)
+    check(got_t, ref_t, dtype)
+    # the motion module on the ORACLE's transformer output: each block is pinned on its own
+    rows_m = ops.ncfhw_to_rows(ref_t.to(DEV), dtype)
+    got_m = ops.rows_to_ncfhw(m._motion(mo, rows_m, c, H, W), 1, 320, Fr, H, W)
+    check(got_m, ref_m, dtype)

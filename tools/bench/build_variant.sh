@@ -27,4 +27,5 @@ for o in elementwise norm gemm gemm_f32 gemm_bf16 gemm_f16 attention temporal co
 done
 mkdir -p $L/variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $L/variants/$N.so
+python3 -c "import ctypes,os; ctypes.CDLL(os.path.abspath('$L/variants/$N.so'), mode=os.RTLD_NOW)"   # every kernel stub resolves
 echo built $L/variants/$N.so
