@@ -80,22 +80,30 @@ class ControlNetModel(UNet3DConditionModel):
         x, h, w_ = ops.conv3x3(x, w[ce + ".conv_out.w"], w[ce + ".conv_out.b"], N, h, w_)
         return x, h, w_
 
-    def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0, class_labels=None,
-                timestep_cond=None, attention_mask=None, cross_attention_kwargs=None, return_dict=True):
-        """controlnet.py:450-567.  sample (N,4,h,w); controlnet_cond (N,3,8h,8w); returns the 12 down residuals (N,C,h',w')
-        and the mid residual, each multiplied by `conditioning_scale`."""
-        if attention_mask is not None or class_labels is not None or timestep_cond is not None:
-            raise NotImplementedError("attention_mask / class_labels / timestep_cond are outside the hot path (always None in the pipeline)")
+    def cond_embedding(self, controlnet_cond):
+        """controlnet_cond_embedding(controlnet_cond) (controlnet.py:523) as NHWC rows + its (h, w): a function of the conditioning
+        image only - not of the timestep or the latents - so a sampling loop computes it ONCE per clip and hands it to every step
+        (`forward(..., _cond_rows=)`); the reference recomputes it inside every forward."""
         order = self.controlnet_conditioning_channel_order
         if order == "bgr":
             controlnet_cond = torch.flip(controlnet_cond, dims=[1])
         elif order != "rgb":
             raise ValueError(f"unknown `controlnet_conditioning_channel_order`: {order}")
-        if sample.dim() != 4 or controlnet_cond.dim() != 4:
+        if controlnet_cond.dim() != 4:
+            raise ValueError("controlnet_cond must be (N,3,H,W)")
+        return self._cond_embedding(controlnet_cond.to(self.device).float(), controlnet_cond.shape[0], controlnet_cond.shape[2], controlnet_cond.shape[3])
+
+    def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0, class_labels=None,
+                timestep_cond=None, attention_mask=None, cross_attention_kwargs=None, return_dict=True, _cond_rows=None):
+        """controlnet.py:450-567.  sample (N,4,h,w); controlnet_cond (N,3,8h,8w); returns the 12 down residuals (N,C,h',w')
+        and the mid residual, each multiplied by `conditioning_scale`.  `_cond_rows` = a precomputed `cond_embedding()` of
+        controlnet_cond (which may then be None)."""
+        if attention_mask is not None or class_labels is not None or timestep_cond is not None:
+            raise NotImplementedError("attention_mask / class_labels / timestep_cond are outside the hot path (always None in the pipeline)")
+        if sample.dim() != 4:
             raise ValueError("ControlNetModel works on 2-D batches: sample (N,C,h,w), controlnet_cond (N,3,H,W)")
         N, _, h, w_ = sample.shape
-        dev = self.device
-        cond_rows, ch, cw = self._cond_embedding(controlnet_cond.to(dev).float(), N, controlnet_cond.shape[2], controlnet_cond.shape[3])
+        cond_rows, ch, cw = _cond_rows if _cond_rows is not None else self.cond_embedding(controlnet_cond)
         if (ch, cw) != (h, w_):
             raise ValueError(f"conditioning image maps to {ch}x{cw} but the latent is {h}x{w_}")
         s = self._begin(sample.unsqueeze(2), timestep, encoder_hidden_states, add_after_conv_in=cond_rows)

@@ -5,9 +5,9 @@
 extern template int gemm_run<float>(const emo_gemm_params&, const GemmPlan&, int, hipStream_t);
 extern template int gemm_run<bf16_t>(const emo_gemm_params&, const GemmPlan&, int, hipStream_t);
 extern template int gemm_run<f16_t>(const emo_gemm_params&, const GemmPlan&, int, hipStream_t);
-extern template int gemm_run_halo<float>(const emo_gemm_params&, int, int64_t, hipStream_t);
-extern template int gemm_run_halo<bf16_t>(const emo_gemm_params&, int, int64_t, hipStream_t);
-extern template int gemm_run_halo<f16_t>(const emo_gemm_params&, int, int64_t, hipStream_t);
+extern template int gemm_run_halo<float>(const emo_gemm_params&, int, int, int64_t, hipStream_t);
+extern template int gemm_run_halo<bf16_t>(const emo_gemm_params&, int, int, int64_t, hipStream_t);
+extern template int gemm_run_halo<f16_t>(const emo_gemm_params&, int, int, int64_t, hipStream_t);
 
 extern "C" int emo_gemm_suggest_split_k(int64_t M, int N, int K, int dtype, int geglu, int transpose_out) {
   return plan_gemm(M, N, K, dtype, geglu, transpose_out).split_k;
@@ -67,12 +67,31 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
       const int64_t nt = (p.N + HaloGeom::BN - 1) / HaloGeom::BN;
       // 16-row patches (8 waves, one block per CU) when they still give (nearly) every CU a block; p.tile 1 / 2 pins 8 / 16
       const int64_t tiles16 = (p.M / 256) * nt;
-      const bool ph16 = He % 16 == 0 && (p.tile == 2 || (p.tile != 1 && tiles16 >= 200));
-      const int64_t tiles = ph16 ? tiles16 : (p.M / 128) * nt, slots = ph16 ? 256 : 512;
-      const int64_t gx = tiles > slots ? slots : tiles;
-      int rc_h = EMO_OK;
-      EMO_DISPATCH(p.dtype, "emo_gemm", rc_h = gemm_run_halo<T>(p, ph16 ? 16 : 8, gx, as_stream(stream)));
-      return rc_h;
+      const bool ph16 = He % 16 == 0 && ((p.tile & 3) == 2 || ((p.tile & 3) != 1 && tiles16 >= 200));
+      // A width that is an odd multiple of 64 (N = 320 = 128 + 128 + 64): the last 128-column tile would multiply 64 columns of
+      // zeros - 17 % of the launch at N = 320.  The 64 remainder columns get their own launch of 64-channel blocks instead
+      // (same patches, half the weight tile, half the MFMAs per stage); p.tile bit 2 (4) keeps the single launch (tools/bench A/B).
+      const int n_rem = (p.N > HaloGeom::BN && p.N % HaloGeom::BN == 64 && !(p.tile & 4)) ? 64 : 0;
+      auto launch = [&](const emo_gemm_params& q, int bn) {
+        const int64_t ntq = (q.N + bn - 1) / bn;
+        const int64_t tiles = (ph16 ? q.M / 256 : q.M / 128) * ntq, slots = ph16 ? 256 : 512;
+        const int64_t gx = tiles > slots ? slots : tiles;
+        int rc_h = EMO_OK;
+        EMO_DISPATCH(q.dtype, "emo_gemm", rc_h = gemm_run_halo<T>(q, ph16 ? 16 : 8, bn, gx, as_stream(stream)));
+        return rc_h;
+      };
+      if (!n_rem) return launch(p, p.N == 64 ? 64 : HaloGeom::BN);
+      const int esz = p.dtype == EMO_F32 ? 4 : 2;
+      emo_gemm_params a = p, b = p;
+      a.N = p.N - n_rem;
+      b.N = n_rem;
+      b.W = (const char*)p.W + (int64_t)a.N * p.K * esz;
+      b.C = (char*)p.C + (int64_t)a.N * esz;
+      if (p.bias) b.bias = p.bias + a.N;
+      if (p.residual) b.residual = (const char*)p.residual + (int64_t)a.N * esz;
+      if (p.rowbias) b.rowbias = p.rowbias + a.N;
+      const int rc_a = launch(a, HaloGeom::BN);
+      return rc_a ? rc_a : launch(b, 64);
     }
   }
   GemmPlan pl = plan_gemm(p.M, p.N, p.K, p.dtype, p.geglu, p.transpose_out, p.tile & 15, p.ln_colsum != nullptr);   // (tile >> 4: tile-order override, gemm_impl.h)

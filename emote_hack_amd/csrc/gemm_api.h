@@ -101,4 +101,4 @@ static GemmPlan plan_gemm(int64_t M, int N, int K, int dtype, int geglu, int tra
 
 // per-dtype entry points (defined in gemm_impl.h, explicitly instantiated in gemm_<dtype>.hip)
 template <typename T> int gemm_run(const emo_gemm_params& p, const GemmPlan& pl, int S, hipStream_t st);        // tiles (+ split-K reduce)
-template <typename T> int gemm_run_halo(const emo_gemm_params& p, int ph, int64_t gx, hipStream_t st);                   // conv3x3_halo_kernel
+template <typename T> int gemm_run_halo(const emo_gemm_params& p, int ph, int bn, int64_t gx, hipStream_t st);                   // conv3x3_halo_kernel

@@ -942,23 +942,26 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
 // 1 block per CU).  The weight tile is the larger stream: 16 KB per tap-stage against 2.6 KB of halo (PH 8) - the 16-row
 // patch feeds twice the MFMAs from the same weights, 4.9 KB of LDS-DMA traffic per MFLOP instead of 8.9 (the direct-to-LDS
 // path, ~9 TB/s chip-wide, is what the 8-row kernel sits on at 1000-1050 TFLOP/s).
-template <int PH_> struct HaloT {
+// BN_ = output channels per block: 128, or 64 for the REMAINDER columns of a width that is an odd multiple of 64 (N = 320: two
+// 128-column tiles + one of 64 - a third 128-column tile computed 64 columns of zeros, 17 % of the launch; host side: gemm.hip)
+template <int PH_, int BN_ = HaloGeom::BN> struct HaloT {
   static constexpr int PH = PH_, PW = HaloGeom::PW, NW = PH_ / 2, HW_ = PW + 2, HPIX = (PH + 2) * (PW + 2);   // 180 / 324 halo pixels
   static constexpr int PIECES = (HPIX + 7) / 8;                 // 1 KB glds pieces of 8 pixels: 23 / 41
   static constexpr int LH = (PIECES + NW - 1) / NW;             // pieces per wave: 6 (the last round is partial)
   static constexpr int HALO_BYTES = PIECES * 1024;              // 23 / 41 KB
-  static constexpr int BN = HaloGeom::BN, LB = BN / (8 * NW);   // weight tile rows, glds per wave per stage
+  static constexpr int BN = BN_, LB = BN / (8 * NW);            // weight tile rows, glds per wave per stage
+  static_assert(BN_ == 128 || BN_ == 64, "halo conv: 128 or 64 output channels per block");
   static constexpr int B_BYTES = BN * KBYTES;                   // 16 KB
   static constexpr int B_OFF = 2 * HALO_BYTES;
   static constexpr int LDS_BYTES = 2 * HALO_BYTES + 2 * B_BYTES;   // 79872 / 116736
   static_assert(LH == 6, "the halo pieces ride on taps 0..5");
 };
 
-template <typename T, int PH_>
+template <typename T, int PH_, int BN_ = HaloGeom::BN>
 __global__ __launch_bounds__(32 * PH_, 2) void conv3x3_halo_kernel(const emo_gemm_params p) {
-  using Halo = HaloT<PH_>;
+  using Halo = HaloT<PH_, BN_>;
   constexpr int V = TT<T>::VEC, BK = KBYTES / (int)sizeof(T);
-  constexpr int WTM = 2, WTN = 2, NW = Halo::NW, LH = Halo::LH, LB = Halo::LB, BN = Halo::BN;
+  constexpr int WTM = 2, WTN = BN_ / 64, NW = Halo::NW, LH = Halo::LH, LB = Halo::LB, BN = Halo::BN;   // two wave columns of WTN x 32 channels
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1163,6 +1166,13 @@ __global__ __launch_bounds__(32 * PH_, 2) void conv3x3_halo_kernel(const emo_gem
             }
             __builtin_amdgcn_sched_barrier(0);
           });
+          // (64-channel blocks: 2 MFMAs per k-step carry 2 of the 3 fragment reads of the next one)
+          static_for<(n_rd > NMMA ? n_rd - NMMA : 0)>([&](auto Q) {
+            constexpr int q = decltype(Q)::value + NMMA;
+            if constexpr (q < WTM) fa[nxt][q] = lds_read16(fa_base[q] + ((((kk + 1) * 2 + half) ^ fa_key[q]) << 4));
+            else fb[nxt][q - WTM] = lds_read16(stB + fb_off[q - WTM][kk + 1]);
+          });
+          __builtin_amdgcn_sched_barrier(0);
         });
       }
     }
@@ -1346,19 +1356,21 @@ template <typename T> int gemm_run(const emo_gemm_params& p, const GemmPlan& pl,
   return EMO_OK;
 }
 
-template <typename T, int PH_> static int launch_halo(const emo_gemm_params& p, int64_t gx, hipStream_t st) {
-  using Halo = HaloT<PH_>;
+template <typename T, int PH_, int BN_> static int launch_halo(const emo_gemm_params& p, int64_t gx, hipStream_t st) {
+  using Halo = HaloT<PH_, BN_>;
   static bool once = false;
   if (!once) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, PH_>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, PH_, BN_>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo::LDS_BYTES);
     if (e != hipSuccess) return emo_fail(EMO_ERR_HIP, "emo_gemm: hipFuncSetAttribute(halo conv): %s", hipGetErrorString(e));
     once = true;
   }
-  conv3x3_halo_kernel<T, PH_><<<(unsigned)gx, 64 * Halo::NW, Halo::LDS_BYTES, st>>>(p);
+  conv3x3_halo_kernel<T, PH_, BN_><<<(unsigned)gx, 64 * Halo::NW, Halo::LDS_BYTES, st>>>(p);
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }
 
-template <typename T> int gemm_run_halo(const emo_gemm_params& p, int ph, int64_t gx, hipStream_t st) {
-  return ph == 16 ? launch_halo<T, 16>(p, gx, st) : launch_halo<T, 8>(p, gx, st);
+// bn = output channels per block (128, or 64: the remainder launch of a width that is an odd multiple of 64)
+template <typename T> int gemm_run_halo(const emo_gemm_params& p, int ph, int bn, int64_t gx, hipStream_t st) {
+  if (bn == 64) return ph == 16 ? launch_halo<T, 16, 64>(p, gx, st) : launch_halo<T, 8, 64>(p, gx, st);
+  return ph == 16 ? launch_halo<T, 16, 128>(p, gx, st) : launch_halo<T, 8, 128>(p, gx, st);
 }

@@ -216,12 +216,7 @@ class EMOAnimationPipeline:
         st.counter = torch.empty(st.f_tot, device=dev, dtype=torch.float32)
         st.return_eps, st.eps_trace = return_eps, []
         # ---- ReferenceNet groups: the banks depend on the timestep only (never on the latents): T timesteps per pass
-        T = max(1, min(int(reference_group), n_steps))
-        if st.dist and st.world_size > 1:
-            # the ranks deal a group's timesteps among themselves: a group size that is not a multiple of world_size pads every
-            # rank to ceil(T / world) timesteps (10 over 8 ranks: 16 computed and shipped, 10 used) - round T up instead
-            T = min(-(-T // st.world_size) * st.world_size, n_steps)
-        st.T = T
+        st.T = T = self.reference_group_size(reference_group, n_steps, st.world_size if st.dist else 1)
         st.groups = [list(range(i, min(i + T, n_steps))) for i in range(0, n_steps, T)]
         st.ref_t = torch.zeros(T, dtype=torch.int64, device=dev)
         st.row_table = torch.tensor([((s_ // T) % 2) * T + s_ % T for s_ in range(n_steps)], dtype=torch.int32, device=dev)
@@ -264,11 +259,22 @@ class EMOAnimationPipeline:
             st.cn_text = st.text_c                                   # cond text embedding (:678-679)
             for call in st.calls:
                 call.cn_sel = torch.tensor([st.cn_pos[k] for w, _ in call.units for k in st.windows[w]], dtype=torch.int64, device=dev)
-            st.cn_down, st.cn_mid = None, None
+            st.cn_down, st.cn_mid, st.cn_embed = None, None, None
         self._bind_inputs(st, latents, ref_image_latents, text_embeddings, audio_features=audio_features, speed_embeddings=speed_embeddings,
                           motion_latents=motion_latents, controlnet_cond=controlnet_cond,
                           controlnet_conditioning_scale=controlnet_conditioning_scale, guidance_scale=guidance_scale, eta=eta, seed=seed)
         return st
+
+    @staticmethod
+    def reference_group_size(reference_group, n_steps, world_size=1):
+        """ReferenceNet timesteps per batched pass: at least 1, never more than the loop has steps; with world_size > 1 the ranks
+        deal a group's timesteps among themselves, and a size that is not a multiple of world_size would pad every rank to
+        ceil(T / world) timesteps (10 over 8 ranks: 16 computed and shipped, 10 used) - rounded up to a multiple instead, still
+        capped by the step count."""
+        T = max(1, min(int(reference_group), int(n_steps)))
+        if world_size > 1:
+            T = min(-(-T // world_size) * world_size, int(n_steps))
+        return T
 
     # ---- the INPUTS of a prepared loop state, copied into its buffers in place (the captured graphs keep reading them)
     @staticmethod
@@ -373,6 +379,13 @@ class EMOAnimationPipeline:
             if st.controlnet is None:
                 raise ValueError("the state was prepared without a ControlNet")
             put(st.cn_cond, controlnet_cond, "controlnet_cond")
+            # the conditioning embedding (controlnet.py:523) depends on the conditioning images only: once per clip, not per step
+            embeds = [st.controlnet.cond_embedding(st.cn_cond.index_select(0, idx)) for idx in st.cn_chunks]
+            if getattr(st, "cn_embed", None) is None:
+                st.cn_embed = embeds
+            else:
+                for (dst, _, _), (src, _, _) in zip(st.cn_embed, embeds):
+                    dst.copy_(src)
         if controlnet_conditioning_scale is not None and st.controlnet is not None:
             scale = float(controlnet_conditioning_scale)
             if getattr(st, "cn_scale", scale) != scale and st.graphs.get("controlnet") not in (None, "warm"):
@@ -490,10 +503,10 @@ class EMOAnimationPipeline:
     # ---- ControlNet (per-frame residual cache of the step, :718-746)
     def _part_controlnet(self, st):
         downs, mids = [], []
-        for idx in st.cn_chunks:
+        for i, idx in enumerate(st.cn_chunks):
             x = self.scheduler.scale_model_input(st.latents.index_select(2, idx), None)[0].permute(1, 0, 2, 3).contiguous()
-            d, m = st.controlnet(x, st.t_buf, encoder_hidden_states=st.cn_text.repeat(idx.numel(), 1, 1),
-                                 controlnet_cond=st.cn_cond.index_select(0, idx), conditioning_scale=st.cn_scale, return_dict=False)
+            d, m = st.controlnet(x, st.t_buf, encoder_hidden_states=st.cn_text.repeat(idx.numel(), 1, 1), controlnet_cond=None,
+                                 conditioning_scale=st.cn_scale, return_dict=False, _cond_rows=st.cn_embed[i])
             downs.append(d)
             mids.append(m)
         st.cn_down = [torch.cat([d[i] for d in downs]) for i in range(len(downs[0]))]

@@ -356,6 +356,31 @@ def test_conv3x3_halo_patch_heights(dtype, ph, n, H, W, Cin, Cout):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("ph", [8, 16])
+@pytest.mark.parametrize("n,H,W,Cin,Cout", [(3, 16, 32, 128, 320), (2, 16, 16, 64, 192), (2, 16, 16, 64, 64), (4, 16, 16, 128, 576)])
+def test_conv3x3_halo_remainder_launch_is_the_same_conv(dtype, ph, n, H, W, Cin, Cout):
+    """A width that is an odd multiple of 64 (320 = 128 + 128 + 64) runs as two launches: the 128-column tiles and a launch of
+    64-channel blocks for the remainder columns (emo_gemm_params.tile bit 2 keeps the single launch whose last tile multiplies 64
+    columns of zeros).  Same arithmetic per output element: bit-identical to the single launch, and equal to the f32 conv with
+    bias + temb row bias + residual; N = 64 alone takes the 64-channel blocks directly."""
+    o = ops()
+    x = q(seeded_randn((n, Cin, H, W), 231), dtype)
+    wt, bias = q(seeded_randn((Cout, Cin, 3, 3), 232) / math.sqrt(9 * Cin), dtype), 0.1 * seeded_randn((Cout,), 233)
+    res = q(seeded_randn((n, Cout, H, W), 234), dtype)
+    rb = seeded_randn((n, Cout), 235)
+    ref = F.conv2d(x, wt, bias, padding=1) + rb[:, :, None, None] + res
+    rows = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().to(DEV).to(dtype)
+    wp = wt.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).to(DEV).to(dtype).contiguous()
+    rrows = res.permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().to(DEV).to(dtype)
+    pin = 1 if ph == 8 else 2
+    kw = dict(rowbias=rb.to(DEV), rows_per_batch=H * W, residual=rrows, split_k=1)
+    got, _, _ = o.conv3x3(rows, wp, bias.to(DEV), n, H, W, tile=pin, **kw)
+    one, _, _ = o.conv3x3(rows, wp, bias.to(DEV), n, H, W, tile=pin | 4, **kw)
+    close(got, ref.permute(0, 2, 3, 1).reshape(-1, Cout), dtype)
+    assert torch.equal(got, one)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ph", [8, 16])
 @pytest.mark.parametrize("n,H,W,Cin,Cout", [(3, 8, 8, 128, 192), (2, 16, 8, 64, 320), (5, 4, 16, 192, 132)])
 def test_conv3x3_halo_upsample(dtype, ph, n, H, W, Cin, Cout):
     """Upsample3D (resnet.py:74-82: F.interpolate(scale_factor=2, mode="nearest") -> conv 3x3) on the halo-reuse kernel: the

@@ -68,3 +68,34 @@ def test_groupnorm_fold_algebra():
     bn = b[None] + (w @ beta)[None] - torch.einsum("nc,noc->no", mean_c, wn)
     got = torch.einsum("nsc,noc->nso", x, wn) + bn[:, None, :]
     torch.testing.assert_close(got, ref, rtol=1e-9, atol=1e-9)
+
+
+def test_reference_group_size_never_exceeds_the_step_count():
+    """ReferenceNet timesteps per batched pass (pipeline.reference_group_size): 1 <= T <= n_steps always; on several ranks a
+    multiple of the world size whenever the step count allows it (10 over 8 ranks -> 16, never 16 of a 12-step loop), so no
+    rank computes a padded timestep; and the groups tile the loop exactly."""
+    from emote_hack_amd.pipeline import EMOAnimationPipeline as P
+    for n_steps in (1, 2, 3, 7, 12, 20, 25, 50, 1000):
+        for world in (1, 2, 3, 4, 8, 16):
+            for want in (0, 1, 2, 5, 10, 25, 50, 10**6):
+                T = P.reference_group_size(want, n_steps, world)
+                assert 1 <= T <= n_steps, (want, n_steps, world, T)
+                if world > 1 and T < n_steps:
+                    assert T % world == 0, (want, n_steps, world, T)
+                groups = [list(range(i, min(i + T, n_steps))) for i in range(0, n_steps, T)]
+                assert sum(len(g) for g in groups) == n_steps and all(len(g) <= T for g in groups)
+    assert P.reference_group_size(10, 50, 8) == 16 and P.reference_group_size(10, 12, 8) == 12 and P.reference_group_size(10, 50, 1) == 10
+
+
+def test_strong_mode_deals_one_unit_per_rank_at_eight_gpus():
+    """bench.py --mode strong = BASELINE configs[3]: one 48-frame clip = 4 windows x 2 CFG branches = 8 units; U[r::8] hands every
+    rank exactly one, U[r::4] a [uncond, cond] pair of ONE window (shared prefix), U[r::2] two such pairs."""
+    units = [(w, br) for br in (0, 1) for w in range(4)]
+    assert all(len(units[r::8]) == 1 for r in range(8))
+    for world in (4, 2, 1):
+        for r in range(world):
+            mine = units[r::world]
+            byw = {}
+            for w, br in mine:
+                byw.setdefault(w, set()).add(br)
+            assert all(v == {0, 1} for v in byw.values()), (world, r, mine)

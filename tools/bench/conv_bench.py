@@ -1,4 +1,5 @@
-import sys, torch
+import os, sys, torch
+TILE = int(os.environ.get('CONV_TILE', '0')) or None   # emo_gemm_params.tile: 1 / 2 pin the 8 / 16-row patch, +4 keeps one launch at N % 128 == 64
 sys.path.insert(0, '.')
 from emote_hack_amd import ops as o
 dev='cuda'; dt=torch.bfloat16
@@ -8,7 +9,7 @@ def run(n,H,W,Cin,N,nrot=4,up=False):
     w = torch.randn(N, 9*Cin, device=dev, dtype=dt)/50; b=torch.randn(N,device=dev)
     k = 4 if up else 1
     rs=[torch.randn(k*n*H*W, N, device=dev, dtype=dt) for _ in range(nrot)]
-    def f(i): return o.conv3x3(xs[i%nrot],w,b,n,H,W,residual=None if up else rs[i%nrot],upsample2x=up)
+    def f(i): return o.conv3x3(xs[i%nrot],w,b,n,H,W,residual=None if up else rs[i%nrot],upsample2x=up,tile=TILE)
     for i in range(3): f(i)
     g = torch.cuda.CUDAGraph(); s = torch.cuda.Stream()
     with torch.cuda.stream(s):
