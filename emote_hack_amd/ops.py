@@ -365,7 +365,8 @@ def temporal_attention(qkv: torch.Tensor, B, F, HW, heads, d, scale) -> torch.Te
     out = torch.empty(B * F * HW, heads * d, device=qkv.device, dtype=qkv.dtype)
     _launch("temporal_attention", 4.0 * B * HW * heads * F * F * d, qkv.element_size() * 4.0 * B * F * HW * heads * d,
             lambda: check(_lib.load().emo_temporal_attention(pq, ld, _ptr(out), out.stride(0), B, F, HW, heads, d, float(scale),
-                                                             dt(qkv), _stream()), "emo_temporal_attention"))
+                                                             dt(qkv), _stream()), "emo_temporal_attention"),
+            tag=f"B={B} F={F} HW={HW} h={heads} d={d}")
     return out
 
 
