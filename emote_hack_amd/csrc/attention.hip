@@ -93,7 +93,7 @@ __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1)
 // self-attention launches (3 waves per SIMD at d = 40) do not have
 // (four blocks per CU at d <= 48 - 128 registers, 2-deep ring - spills 32-130 bytes per lane: not offered)
 template <typename T, int DCH, int G, int NSR, int QT, bool RES>
-__global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) void attention_kernel(const emo_attention_params p, int stage_bytes, int order_mode, int q_rep_arg) {
+__global__ __launch_bounds__(ATT_THREADS, (QT == 2 ? 2 : (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1)))) void attention_kernel(const emo_attention_params p, int stage_bytes, int order_mode, int q_rep_arg) {
   const int q_rep = RES ? q_rep_arg : 1;
   using Cfg = AttCfg<T, DCH>;
   constexpr int V = Cfg::V, NT = Cfg::NT, KROW = Cfg::KROW, VROW = Cfg::VROW, STEPS = Cfg::STEPS;
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DCH <= 6 ? 3 : (DCH <= 10 ? 2 : 1))) 
     __builtin_amdgcn_sched_barrier(0);
     uint4 pf[QT][2][STEPS];                        // P^T fragments (B operand of the PV MFMAs)
     uint4 vf0[STEPS][NT];
-    constexpr bool early_v = STEPS * NT <= 8;      // (the widest heads drain lgkmcnt per step and keep their reads next to the MFMAs)
+    constexpr bool early_v = STEPS * NT <= 8 && QT == 1;   // (the widest heads drain lgkmcnt per step and keep their reads next to the MFMAs; two query tiles per wave have no registers to spare)
 #pragma unroll
     for (int t = 0; t < QT; t++) {
       f32x16 s0, s1;
@@ -652,11 +652,10 @@ static int launch_attention3(const emo_attention_params& p, hipStream_t st) {
 
 template <typename T, int DCH, int G>
 static int launch_attention2(const emo_attention_params& p, hipStream_t st) {
-  // two 32-query tiles per wave (K / V^T fragments reused, half the LDS traffic per MFMA) when the head dim leaves
-  // the registers for it and there are enough query rows to still fill the chip
-  // QT = 2 (two 32-query tiles per wave: K / V^T fragments reused, half the LDS fragment traffic per MFMA) was measured
-  // 1.7x SLOWER at d=40 (201 vs 341 TFLOP/s): 318 registers -> 1 wave per SIMD.  Occupancy beats LDS traffic here,
-  // so every head dim runs one query tile per wave; the QT template parameter stays for a leaner register budget.
+  // QT = 2 (two 32-query tiles per wave: K / V^T fragments, requests and loop overhead shared by 64 query rows - ~136 instead of
+  // ~170 instructions per query tile and KV tile) needs 256 registers at d = 40 (+ 20 bytes of scratch) = two waves per SIMD:
+  // round 3 measured it 1.7x slower on the old instruction stream, round 4 on the lean one 1.5-3.5 % FASTER (1294 -> 1275 us,
+  // 775 -> 748 us, profiles/r04m_attention_qt2.txt) - inside the run-to-run spread of a whole step, with a spill; not enabled.
   return launch_attention3<T, DCH, G, 1>(p, st);
 }
 
