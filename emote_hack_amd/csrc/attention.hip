@@ -24,13 +24,6 @@
 #include "common.h"
 
 static constexpr int ATT_THREADS = 256, BQ = 128, TK = 64;
-#ifdef EMO_ATT_PRIO   // experiment (tools/bench/build_variant.sh): raised wave priority around the MFMA clusters
-#define EMO_ATT_PRIO_UP() __builtin_amdgcn_s_setprio(1)
-#define EMO_ATT_PRIO_DOWN() __builtin_amdgcn_s_setprio(0)
-#else
-#define EMO_ATT_PRIO_UP() ((void)0)
-#define EMO_ATT_PRIO_DOWN() ((void)0)
-#endif
 
 __device__ __attribute__((aligned(16))) unsigned int g_att_ones_bf16[4] = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
 __device__ __attribute__((aligned(16))) unsigned int g_att_ones_f32[4] = {0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u};
@@ -379,13 +372,11 @@ __global__ __launch_bounds__(ATT_THREADS, (QT == 2 ? 2 : (DCH <= 6 ? 3 : (DCH <=
       f32x16 s0, s1;
 #pragma unroll
       for (int r = 0; r < 16; r++) { s0[r] = 0.f; s1[r] = 0.f; }
-      EMO_ATT_PRIO_UP();
 #pragma unroll
       for (int kk = 0; kk < DCH / 2; kk++) {
         s0 = mma16<T>(kf[0][kk], qf[t][kk], s0);
         s1 = mma16<T>(kf[1][kk], qf[t][kk], s1);
       }
-      EMO_ATT_PRIO_DOWN();
       if constexpr (early_v) {
         if (t == QT - 1) {
           __builtin_amdgcn_sched_barrier(0);
@@ -471,26 +462,22 @@ __global__ __launch_bounds__(ATT_THREADS, (QT == 2 ? 2 : (DCH <= 6 ? 3 : (DCH <=
       if (fast || second) read_v_frags(vs_base, std::integral_constant<int, 1>{}, vf1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    EMO_ATT_PRIO_UP();
 #pragma unroll
     for (int sp = 0; sp < STEPS; sp++)
 #pragma unroll
       for (int t = 0; t < QT; t++)
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) o[t][nt] = mma16<T>(vf0[sp][nt], pf[t][0][sp], o[t][nt]);
-    EMO_ATT_PRIO_DOWN();
     if (fast || second) {
       if constexpr (!early_v) read_v_frags(vs_base, std::integral_constant<int, 1>{}, vf1);
       wait_lgkmcnt<0>();
       __builtin_amdgcn_sched_barrier(0);
-      EMO_ATT_PRIO_UP();
 #pragma unroll
       for (int sp = 0; sp < STEPS; sp++)
 #pragma unroll
         for (int t = 0; t < QT; t++)
 #pragma unroll
           for (int nt = 0; nt < NT; nt++) o[t][nt] = mma16<T>(vf1[sp][nt], pf[t][1][sp], o[t][nt]);
-      EMO_ATT_PRIO_DOWN();
     }
   };
 

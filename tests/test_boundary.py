@@ -278,3 +278,30 @@ def test_scheduler_matches_oracle(kind):
     assert mine2.coefficients(41)[0] == pytest.approx(ref2.coefficients(41)[0], rel=1e-12)
     with pytest.raises(ValueError):
         DDIMScheduler(clip_sample=True)
+
+
+def test_attention_argument_checks_run_before_any_launch():
+    """emo_attention validates its geometry on the host (no GPU needed: the pointers are never dereferenced there): null pointers,
+    a head dim that is not a multiple of the 16-byte vector, and - since the K / V^T tiles are addressed through 32-bit buffer offsets
+    (csrc/attention.hip loader) - a (batch row, head) slab beyond 1 GB are refused with an error string, never launched."""
+    import ctypes as C
+    from emote_hack_amd import _lib
+    lib = _lib.load()
+    fake = 0x1000          # any non-null address: argument checks only
+    def params(**kw):
+        p = _lib.AttentionParams()
+        base = dict(q=fake, ldq=320, k0=fake, ldk0=640, v0t=fake, ldv0t=4096, Lk0=4096, k1=None, ldk1=0, v1t=None, ldv1t=0, Lk1=0, seg0_div=1,
+                    seg1_div=1, seg1_first_batch=0, seg1_skip=0, out=fake, ldo=320, B=2, Lq=4096, heads=8, d=40, scale=0.158, dtype=_lib.EMO_BF16,
+                    seg1_row=None)
+        base.update(kw)
+        for k, v in base.items():
+            setattr(p, k, v)
+        return p
+    rc = lib.emo_attention(C.byref(params(q=None)), None)
+    assert rc == -5 and b"null" in lib.emo_last_error_string()
+    rc = lib.emo_attention(C.byref(params(d=44)), None)
+    assert rc == -1 and b"head dim" in lib.emo_last_error_string()
+    rc = lib.emo_attention(C.byref(params(Lk0=1 << 20, ldk0=640, ldv0t=1 << 20)), None)       # 2^20 keys x 1280 B rows = 1.3 GB of K per batch row
+    assert rc == -1 and b"exceeds 1 GB" in lib.emo_last_error_string()
+    rc = lib.emo_attention(C.byref(params(k1=fake, v1t=fake, Lk1=1 << 20, ldk1=640, ldv1t=1 << 20, seg1_div=2)), None)
+    assert rc == -1 and b"segment 1" in lib.emo_last_error_string()
