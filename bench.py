@@ -478,7 +478,7 @@ def main():
             d = merged[dom]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             out["roofline"] = {"kernel": {"gemm_dense": "gemm_kernel<bf16,false>", "gemm_conv3x3": "gemm_kernel<bf16,true>",
-                                          "attention": "attention_kernel", "temporal_attention": "temporal_attention_kernel"}[dom],
+                                          "attention": "attention_kernel", "temporal_attention": "temporal_attention_mfma_kernel"}[dom],
                                "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / MFMA_PEAK_BF16_TFLOPS, "traffic": pmc_traffic(dom),
                                "launches_per_step": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],

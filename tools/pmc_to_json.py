@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from emote_hack_amd.build import csrc_digest  # noqa: E402  (the build the counters belong to)
 
 FAMILY = [("layernorm_stats_kernel", "layernorm_stats"), ("softmax_rows_kernel", "softmax_rows"), ("conv3x3_halo_kernel", "gemm_conv3x3"), (r"gemm_kernel<[^>]*?(unsigned short|float), true", "gemm_conv3x3"),
-          ("gemm_kernel", "gemm_dense"), ("gemm_splitk_epilogue", "gemm_splitk_epilogue"), ("temporal_attention_kernel", "temporal_attention"),
+          ("gemm_kernel", "gemm_dense"), ("gemm_splitk_epilogue", "gemm_splitk_epilogue"), ("temporal_attention_mfma_kernel", "temporal_attention"), ("temporal_attention_kernel", "temporal_attention"),
           ("attention_kernel", "attention"), ("layernorm_kernel", "layernorm"), ("gn_stats_kernel", "groupnorm"), ("gn_apply_kernel", "groupnorm"), ("gn_fold_linear_kernel", "groupnorm")]
 
 
