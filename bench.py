@@ -110,8 +110,10 @@ def cpu_baseline(unet, ref, full=False):
     t_step = t_uncond + t_cond + 2 * t_ref
     t_step8 = (t_unet8 * F_WIN) * (1 + TFLOP_COND / TFLOP_UNCOND) + 2 * t_ref * (t_unet8 / (t_unet / Fs))
     return {"value": F_WIN / (NUM_INFERENCE_STEPS * t_step), "unit": "denoised frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32, warm: 1 uncond UNet fwd on a {Fs}-frame 512x512 window ({t_unet:.1f}s) + 1 ReferenceNet fwd "
-                      f"({t_ref:.1f}s); 12-frame step = 6 x uncond + 6.48 x (cond) + 2 x refnet = {t_step:.0f}s, x{NUM_INFERENCE_STEPS} steps",
+            "sample": (f"oracle fp32: ONE full 12-frame 512x512 uncond UNet fwd ({t_full:.1f}s, cold) + 1 ReferenceNet fwd ({t_ref:.1f}s, warm); step = uncond + "
+                       f"1.08 x uncond (cond, by FLOPs) + 2 x refnet = {t_step:.0f}s, x{NUM_INFERENCE_STEPS} steps" if full else
+                       f"oracle fp32, warm: 1 uncond UNet fwd on a {Fs}-frame 512x512 window ({t_unet:.1f}s) + 1 ReferenceNet fwd "
+                       f"({t_ref:.1f}s); 12-frame step = 6 x uncond + 6.48 x (cond) + 2 x refnet = {t_step:.0f}s, x{NUM_INFERENCE_STEPS} steps"),
             "value_8_threads": F_WIN / (NUM_INFERENCE_STEPS * t_step8),
             "sample_8_threads": f"1 cold 1-frame uncond fwd on 8 threads ({t_unet8:.1f}s), same extrapolation",
             "full_12_frame_uncond_forward_s": t_full,
