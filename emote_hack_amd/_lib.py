@@ -71,6 +71,8 @@ SIGNATURES = {
     "emo_groupnorm_workspace_bytes": (C.c_size_t, [_i, _i64, _i, _i]),
     "emo_groupnorm_stats": (_i, [_p, _i, _p, _i, _i64, _i, _i, _i, _p]),
     "emo_groupnorm_apply": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _f, _i, _i, _p]),
+    "emo_groupnorm_one_launch_ok": (_i, [_i, _i64, _i, _i, _i]),
+    "emo_groupnorm": (_i, [_p, _i, _p, _p, _p, _i, _i, _i64, _i, _i, _f, _i, _i, _p]),
     "emo_groupnorm_fold_linear": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _i, _f, _i, _p]),
     "emo_layernorm": (_i, [_p, _i, _p, _p, _p, _i, _i64, _i, _f, _p, _i, _i, _i, _p]),
     "emo_layernorm_stats": (_i, [_p, _i, _p, _i64, _i, _f, _i, _p]),

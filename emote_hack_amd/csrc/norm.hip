@@ -317,6 +317,165 @@ extern "C" int emo_groupnorm_apply(const void* x, int ldx, const void* partials,
   return EMO_OK;
 }
 
+// ------------------------------------------------------------------------------------------ GroupNorm in one launch
+// Instances small enough that one block holds (instance, slab of whole groups) in registers: one read, statistics through
+// LDS in the same fixed order as the two-pass path (f32 per-thread partials, f64 mean / variance), normalise from the
+// registers, one write.  The 8x8 / 16x16 / 32x32 levels' norms are all of this kind (M <= 24576 rows per-frame or
+// M <= 6144 joint): two dependent launches and a second read of x become one launch.
+static constexpr int GN1_MAXR = 16, GN1_MAXT = 1024, GN1_MAXGPB = 16, GN1_MINBLOCKS = 32, GN1_MAXELEMS = 32768;
+struct Gn1Geom { int ok, GPB, Wc, NT, R; };
+static inline Gn1Geom gn1_geom(int N, int64_t S, int C, int G, int V) {
+  Gn1Geom g{0, 0, 0, 0, 0};
+  if (N <= 0 || S <= 0 || G <= 0 || C % G) return g;
+  const int cpg = C / G;
+  int gpb = 1;
+  while (gpb <= GN1_MAXGPB && ((gpb * cpg) % V || G % gpb)) gpb++;
+  if (gpb > GN1_MAXGPB) return g;
+  g.GPB = gpb; g.Wc = gpb * cpg;
+  const int CVW = g.Wc / V;
+  if (CVW > 256 || (int64_t)N * (G / gpb) < GN1_MINBLOCKS) return g;
+  // measured (profiles/r04n_groupnorm_one_launch.txt): a slab is Wc * sizeof(T) contiguous bytes per row, so a block's loads are
+  // short row segments; past ~32 K elements per block the two coalesced passes are faster again
+  if (S * g.Wc > GN1_MAXELEMS) return g;
+  for (int nt = 256; nt <= GN1_MAXT; nt *= 2) {   // short load chains: <= 4 rows per thread if any block size gives that
+    const int64_t rows = (S + nt / CVW - 1) / (nt / CVW);
+    const int64_t lim = nt == GN1_MAXT ? GN1_MAXR : 4;
+    if (rows <= lim) {
+      g.NT = nt; g.R = rows <= 2 ? 2 : rows <= 4 ? 4 : rows <= 8 ? 8 : 16; g.ok = 1;
+      return g;
+    }
+  }
+  return g;
+}
+
+template <typename T, int R>
+__global__ __launch_bounds__(GN1_MAXT) void gn_one_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, T* __restrict__ y, int ldy, int S, int Wc,
+                                                          int GPB, int slabs, double count, float eps, int silu) {
+  constexpr int V = TT<T>::VEC;
+  extern __shared__ float lds[];   // [RP][Wc][2]
+  __shared__ float s_stats[GN1_MAXGPB * 2];
+  __shared__ float s_wave[GN1_MAXGPB * 16 * 2];
+  const int n = blockIdx.x / slabs, sl = blockIdx.x % slabs;
+  const int CVW = Wc / V, NT = blockDim.x, RP = NT / CVW;
+  const int tid = threadIdx.x, r = tid / CVW, cv = tid % CVW;
+  const bool active = r < RP;
+  const int c0 = sl * Wc + cv * V;
+  const T* xc = x + (int64_t)n * S * ldx + c0;
+  T* yc = y + (int64_t)n * S * ldy + c0;
+  uint4 v[R];
+  float gm[V], bt[V];
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      const int s = r + k * RP;
+      v[k] = s < S ? *(const uint4*)(xc + (int64_t)s * ldx) : make_uint4(0u, 0u, 0u, 0u);   // zeros add nothing to the sums
+    }
+#pragma unroll
+    for (int e = 0; e < V; e += 4) {
+      *(float4*)(gm + e) = *(const float4*)(gamma + c0 + e);
+      *(float4*)(bt + e) = *(const float4*)(beta + c0 + e);
+    }
+    float sum[V], sq[V];
+#pragma unroll
+    for (int e = 0; e < V; e++) { sum[e] = 0.f; sq[e] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      float f[V];
+      unpack16<T>(v[k], f);
+#pragma unroll
+      for (int e = 0; e < V; e++) { sum[e] += f[e]; sq[e] += f[e] * f[e]; }
+    }
+    float* dst = lds + ((int64_t)r * Wc + cv * V) * 2;
+#pragma unroll
+    for (int e = 0; e < V; e += 2) *(float4*)(dst + 2 * e) = make_float4(sum[e], sq[e], sum[e + 1], sq[e + 1]);
+  }
+  __syncthreads();
+  // per group: every thread sums a strided share of the [RP][cpg] partials, shuffle tree per wave, wave results through
+  // LDS, one thread finishes in f64 - the same order on every launch
+  {
+    const int cpg = Wc / GPB, ne = RP * cpg, nw = NT / 64, wv = tid / 64, ln = tid % 64;
+    for (int g = 0; g < GPB; g++) {
+      float a = 0.f, b = 0.f;
+      for (int e = tid; e < ne; e += NT) {
+        const int rr = e / cpg, c = g * cpg + e % cpg;
+        const float2 p = *(const float2*)(lds + ((int64_t)rr * Wc + c) * 2);
+        a += p.x; b += p.y;
+      }
+      for (int d = 32; d > 0; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+      if (ln == 0) { s_wave[(g * 16 + wv) * 2] = a; s_wave[(g * 16 + wv) * 2 + 1] = b; }
+    }
+    __syncthreads();
+    if (tid < GPB) {
+      double sa = 0.0, sb = 0.0;
+      for (int w = 0; w < nw; w++) { sa += (double)s_wave[(tid * 16 + w) * 2]; sb += (double)s_wave[(tid * 16 + w) * 2 + 1]; }
+      const double mean = sa / count;
+      double var = sb / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_stats[2 * tid] = (float)mean;
+      s_stats[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  float a[V], b[V];
+  {
+    const int cpg = Wc / GPB;
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+      const int g = (cv * V + e) / cpg;
+      const float mean = s_stats[2 * g], rstd = s_stats[2 * g + 1];
+      a[e] = rstd * gm[e]; b[e] = bt[e] - mean * a[e];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < R; k++) {
+    const int s = r + k * RP;
+    if (s < S) {
+      float f[V];
+      unpack16<T>(v[k], f);
+#pragma unroll
+      for (int e = 0; e < V; e++) { const float t = f[e] * a[e] + b[e]; f[e] = silu ? silu_f(t) : t; }
+      *(uint4*)(yc + (int64_t)s * ldy) = pack16<T>(f);
+    }
+  }
+}
+
+extern "C" int emo_groupnorm_one_launch_ok(int N, int64_t S, int C, int G, int dtype) {
+  if (!emo_dtype_ok(dtype)) return 0;
+  return gn1_geom(N, S, C, G, emo_dtype_vec(dtype)).ok;
+}
+
+extern "C" int emo_groupnorm(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, int N, int64_t S, int C,
+                             int G, float eps, int silu, int dtype, void* stream) {
+  EMO_CHECK(x && gamma && beta && y, EMO_ERR_NULL, "emo_groupnorm: null pointer");
+  int rc = gn_check("emo_groupnorm", N, S, C, G, ldx, dtype);
+  if (rc) return rc;
+  rc = gn_check("emo_groupnorm", N, S, C, G, ldy, dtype);
+  if (rc) return rc;
+  EMO_CHECK(((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0, EMO_ERR_BAD_SHAPE, "emo_groupnorm: gamma/beta alignment");
+  const int V = emo_dtype_vec(dtype);
+  const Gn1Geom gg = gn1_geom(N, S, C, G, V);
+  EMO_CHECK(gg.ok, EMO_ERR_UNSUPPORTED, "emo_groupnorm: N=%d S=%lld C=%d G=%d does not fit one block per (instance, group slab); "
+            "use emo_groupnorm_stats + emo_groupnorm_apply", N, (long long)S, C, G);
+  const int RP = gg.NT / (gg.Wc / V);
+  const size_t lds = (size_t)RP * gg.Wc * 2 * sizeof(float);
+  const int slabs = G / gg.GPB;
+  const double count = (double)S * (C / G);
+  hipStream_t st = as_stream(stream);
+  const dim3 grid((unsigned)(N * slabs));
+#define GN1_LAUNCH(RR) \
+  EMO_DISPATCH(dtype, "emo_groupnorm", (gn_one_kernel<T, RR><<<grid, gg.NT, lds, st>>>((const T*)x, ldx, gamma, beta, (T*)y, ldy, (int)S, \
+                                                                                       gg.Wc, gg.GPB, slabs, count, eps, silu)))
+  if (gg.R == 2) { GN1_LAUNCH(2); }
+  else if (gg.R == 4) { GN1_LAUNCH(4); }
+  else if (gg.R == 8) { GN1_LAUNCH(8); }
+  else { GN1_LAUNCH(16); }
+#undef GN1_LAUNCH
+  EMO_LAUNCH_CHECK();
+  return EMO_OK;
+}
+
 // ------------------------------------------------------------------------------------------ GroupNorm folded into a Linear
 // GN(x) W^T + b = x W'_n^T + b'_n per instance n (emo_hip.h emo_groupnorm_fold_linear): the per-frame GroupNorm in front of
 // proj_in (attention.py:124,135-146; motion_module.py:147-151) has no activation behind it, so its scale / shift move into a

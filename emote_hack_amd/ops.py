@@ -167,6 +167,9 @@ def timestep_embedding(timesteps: torch.Tensor, freqs: torch.Tensor, dim: int, f
 
 
 # ----------------------------------------------------------------------------- norms
+GN_ONE_LAUNCH = True   # A/B hook (bench.py --gn-two-launch): False keeps every GroupNorm on the stats + apply pair
+
+
 def group_norm(x: torch.Tensor, gamma, beta, n_inst: int, groups: int, eps: float, silu_: bool, out=None) -> torch.Tensor:
     """GroupNorm over NHWC rows; x (n_inst*S, C).  n_inst=B -> joint 5-D statistics (resnet.py:180),
     n_inst=B*F -> per frame (attention.py:124)."""
@@ -175,10 +178,15 @@ def group_norm(x: torch.Tensor, gamma, beta, n_inst: int, groups: int, eps: floa
     M, Cc = x.shape
     S = M // n_inst
     px, ldx = _rows(x)
-    ws = lib.emo_groupnorm_workspace_bytes(n_inst, S, Cc, groups)
-    part = torch.empty(max(ws // 4, 1), device=x.device, dtype=torch.float32)
     y = torch.empty(M, Cc, device=x.device, dtype=x.dtype) if out is None else out
     py, ldy = _rows(y)
+    if GN_ONE_LAUNCH and lib.emo_groupnorm_one_launch_ok(n_inst, S, Cc, groups, dt(x)):   # small instances: one launch, one read
+        _launch("groupnorm", 0.0, x.element_size() * 2.0 * M * Cc,
+                lambda: check(lib.emo_groupnorm(px, ldx, _ptr(gamma), _ptr(beta), py, ldy, n_inst, S, Cc, groups, float(eps), int(silu_),
+                                                dt(x), _stream()), "emo_groupnorm"), tag=f"M={M} C={Cc}{' silu' if silu_ else ''} 1L")
+        return y
+    ws = lib.emo_groupnorm_workspace_bytes(n_inst, S, Cc, groups)
+    part = torch.empty(max(ws // 4, 1), device=x.device, dtype=torch.float32)
 
     def run():
         check(lib.emo_groupnorm_stats(px, ldx, _ptr(part), n_inst, S, Cc, groups, dt(x), _stream()), "emo_groupnorm_stats")

@@ -87,6 +87,14 @@ int emo_groupnorm_apply(const void* x, int ldx, const void* partials, const floa
                         void* y, int ldy, int N, int64_t S, int C, int G, float eps, int silu, int dtype,
                         void* stream);
 
+/* The same GroupNorm in ONE launch, for instances small enough that one workgroup holds (instance, slab of whole groups)
+ * in registers (<= 32 K elements per workgroup: the 8x8 level and the per-frame 16x16 norms at the bench size): one read of x, statistics in the same fixed
+ * order (f32 partials, f64 mean / variance), one write.  emo_groupnorm_one_launch_ok returns 1 when the geometry fits;
+ * emo_groupnorm returns EMO_ERR_UNSUPPORTED otherwise (the caller then uses the two launches above). */
+int emo_groupnorm_one_launch_ok(int N, int64_t S, int C, int G, int dtype);
+int emo_groupnorm(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, int N, int64_t S,
+                  int C, int G, float eps, int silu, int dtype, void* stream);
+
 /* GroupNorm folded into the Linear / 1x1 conv that consumes it (attention.py:124,135-146 `norm` -> `proj_in`;
  * motion_module.py:147-151): GN(x) W^T + b over an instance n = x W'_n^T + b'_n with
  *   W'_n[o, c] = W[o, c] * gamma_c * rstd_{n, g(c)}      (rounded to the compute dtype, [N][Cout][C] -> `w_out`)

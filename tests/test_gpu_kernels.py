@@ -86,6 +86,44 @@ def test_groupnorm(dtype, N, S, C, G, silu):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,S,C,G,silu", [(2, 12 * 8 * 8, 1280, 32, True), (24, 16 * 16, 1280, 32, False), (24, 8 * 8, 1280, 32, True),
+                                          (2, 12 * 8 * 8, 640, 32, True), (5, 37, 320, 32, True), (4, 250, 960, 32, False),
+                                          (3, 400, 2560, 32, True), (40, 1000, 64, 8, False)])
+def test_groupnorm_one_launch(dtype, N, S, C, G, silu):
+    """emo_groupnorm (one workgroup per (instance, slab of whole groups), the tensor held in registers between the statistics
+    and the normalisation) at the bench's 8x8 / per-frame 16x16 geometries, ragged row counts and slabs of 1 / 2 / 4 groups:
+    against F.group_norm in f32 and against the two-launch path on the same input; also into a strided output."""
+    from emote_hack_amd import _lib
+    o = ops()
+    lib = _lib.load()
+    dti = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[dtype]
+    assert lib.emo_groupnorm_one_launch_ok(N, S, C, G, dti) == 1
+    x = q(seeded_randn((N * S, C), 5) * (1 + torch.arange(C) % 7 * 0.2) + 0.5, dtype)
+    g, b = 1 + 0.1 * seeded_randn((C,), 6), 0.1 * seeded_randn((C,), 7)
+    ref = F.group_norm(x.reshape(N, S, C).permute(0, 2, 1), G, g, b, 1e-5).permute(0, 2, 1).reshape(N * S, C)
+    if silu:
+        ref = F.silu(ref)
+    xd, gd, bd = x.to(DEV).to(dtype), g.to(DEV), b.to(DEV)
+    got = o.group_norm(xd, gd, bd, N, G, 1e-5, silu)
+    close(got, ref, dtype)
+    # the two-launch path on the same rows
+    part = torch.empty(lib.emo_groupnorm_workspace_bytes(N, S, C, G) // 4, device=DEV, dtype=torch.float32)
+    two = torch.empty_like(xd)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.emo_groupnorm_stats(xd.data_ptr(), C, part.data_ptr(), N, S, C, G, dti, st) == 0
+    assert lib.emo_groupnorm_apply(xd.data_ptr(), C, part.data_ptr(), gd.data_ptr(), bd.data_ptr(), two.data_ptr(), C, N, S, C, G, 1e-5,
+                                   int(silu), dti, st) == 0
+    close(got, two.float().cpu(), dtype)
+    # strided output (the concat buffers of the up path)
+    wide = torch.zeros(N * S, C + 64, device=DEV, dtype=dtype)
+    o.group_norm(xd, gd, bd, N, G, 1e-5, silu, out=wide[:, 32:32 + C])
+    assert torch.equal(wide[:, 32:32 + C], got) and not wide[:, :32].any() and not wide[:, 32 + C:].any()
+    # a geometry that does not fit is refused by the one-launch entry, not mangled
+    assert lib.emo_groupnorm_one_launch_ok(2, 12 * 64 * 64, 320, 32, dti) == 0
+    assert lib.emo_groupnorm(xd.data_ptr(), 320, gd.data_ptr(), bd.data_ptr(), two.data_ptr(), 320, 2, 12 * 64 * 64, 320, 32, 1e-5, 0, dti, st) != 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("N,S,C,G,Cout", [(6, 1024, 320, 32, 320), (3, 256, 64, 8, 96), (2, 4096, 640, 32, 640), (5, 256, 1280, 32, 128)])
 def test_groupnorm_folded_into_linear(dtype, N, S, C, G, Cout):
     """emo_groupnorm_fold_linear + emo_gemm(w_slab_rows): per-frame GroupNorm (eps 1e-6, no activation) followed by proj_in
