@@ -77,7 +77,7 @@ class EMOAnimationPipeline:
                         context_batch_size=1, context_schedule="uniform", audio_features=None, speed_embeddings=None, seed=0,
                         fusion_blocks="midup", dist=False, rank=0, world_size=1, return_eps=False, use_graphs=None,
                         controlnet=None, controlnet_cond=None, controlnet_conditioning_scale=1.0, reference_group=10,
-                        reference_lookahead=None, motion_latents=None):
+                        reference_lookahead=None, motion_latents=None, text_pairing="reference"):
         """Set up the loop state (EMOAnimationPipeline.py:628-696).  latents f32 (1,4,F_tot,h,w);
         ref_image_latents (1,4,h,w); text_embeddings (2,L,D) = [uncond, cond].
         reference_group = T: ReferenceNet timesteps computed per batched pass (1 = the reference's per-step order).
@@ -87,7 +87,13 @@ class EMOAnimationPipeline:
         (latents, reference image, text / audio / speed conditioning, ControlNet images, guidance scale, seed), which are copied
         into the plan's buffers in place: `reset_denoise` re-arms a prepared state for another clip of the same geometry.
         motion_latents (n_m, 4, h, w): latents of the previous clip's last frames - they go through the ReferenceNet next to the
-        reference image and their LN1 features join the banks as extra tokens (see denoise_chained)."""
+        reference image and their LN1 features join the banks as extra tokens (see denoise_chained).
+        text_pairing (matters at context_batch_size > 1 only): "reference" = the upstream row pairing, literally (see `unit_tv`
+        below: odd windows of a batch run their uncond row under the cond text and vice versa, which cancels guidance for them);
+        "branch" = the evidently intended one, every uncond row under the uncond text, every cond row under the cond text and the
+        cond-text bank - the same function as context_batch_size 1, batched."""
+        if text_pairing not in ("reference", "branch"):
+            raise ValueError(f"text_pairing must be 'reference' or 'branch', got {text_pairing!r}")
         unet, sch = self.unet, self.scheduler
         dev = unet.device
         # `do_classifier_free_guidance = guidance_scale > 1.0` (:622).  Without it the UNet batch is the window batch (:759-763
@@ -150,14 +156,15 @@ class EMOAnimationPipeline:
         # (mutual_self_attention.py:186-197): row r = branch * n + j of a batch of n windows is paired with text row r % 2, and a
         # cond row reads bank row r - written by the ReferenceNet under text row r % 2 as well (:711-716).  At
         # context_batch_size 1 that is variant = branch; at context_batch_size > 1 it is NOT (window 0's cond row runs under the
-        # uncond text and the uncond-text bank) - reference behaviour, reproduced (golden `ddim_cbs2`).
+        # uncond text and the uncond-text bank) - reference behaviour, reproduced (golden `ddim_cbs2`); text_pairing="branch"
+        # pairs by branch instead.
         st.unit_tv = {}
         pos = 0
         for wb in st.global_context:
             n = len(wb)
             for j in range(n):
                 for br in st.branches:
-                    st.unit_tv[(pos + j, br)] = ((br * n + j) % 2) if cfg else 1
+                    st.unit_tv[(pos + j, br)] = (br if text_pairing == "branch" else (br * n + j) % 2) if cfg else 1
             pos += n
         st.bank_variants = sorted({st.unit_tv[u] for u in st.units if u[1] == 1})   # the same on every rank
         mine = st.units[st.rank::st.world_size]
@@ -801,7 +808,8 @@ class EMOAnimationPipeline:
                            # prepared state kept for the next clip of the same geometry
                            use_graphs=kwargs.get("use_graphs"), reference_group=kwargs.get("reference_group", 25),   # whole clips: 2 ReferenceNet passes per 50 steps
                            reference_lookahead=kwargs.get("reference_lookahead"), fusion_blocks=kwargs.get("fusion_blocks", "midup"),
-                           motion_latents=kwargs.get("motion_latents"), reuse_state=kwargs.get("reuse_state", True))
+                           motion_latents=kwargs.get("motion_latents"), reuse_state=kwargs.get("reuse_state", True),
+                           text_pairing=kwargs.get("text_pairing", "reference"))
         if self.vae is not None and output_type != "latent":
             video = self.vae.decode_video(lat)   # caller-supplied (:291-307)
         else:

@@ -66,3 +66,26 @@ def test_cfg_decision_is_made_on_the_f32_value_the_kernel_sees():
     from emote_hack_amd.pipeline import EMOAnimationPipeline
     assert EMOAnimationPipeline._do_cfg(7.5) and EMOAnimationPipeline._do_cfg(1.0 + 2.0 ** -20)
     assert not EMOAnimationPipeline._do_cfg(1.0) and not EMOAnimationPipeline._do_cfg(1.0 + 2.0 ** -30) and not EMOAnimationPipeline._do_cfg(0.0)
+
+
+def test_text_pairing_by_branch_makes_window_batching_neutral():
+    """context_batch_size > 1 with the upstream row pairing (`torch.cat([text] * cbs)`, EMOAnimationPipeline.py:631 against the
+    [w0, w1, .., w0, w1, ..] latent rows of :759-763) runs odd windows' uncond rows under the cond text - reproduced literally by
+    default (golden `ddim_cbs2`).  text_pairing="branch" is the evident intent: the same function as context_batch_size 1, so the
+    two must agree; the literal pairing must not."""
+    from emote_hack_amd.synth import seeded_randn
+    pipe, ref = _pipe()
+    kw = dict(appearance_encoder=ref, num_inference_steps=2, context_frames=4, context_stride=1, context_overlap=2, reference_group=1,
+              guidance_scale=7.5, seed=0)
+    a = (seeded_randn((1, 4, 8, 8, 8), 5), seeded_randn((1, 4, 8, 8), 3), seeded_randn((2, 5, 32), 2))
+    one = pipe.denoise(*a, context_batch_size=1, **kw)
+    st = pipe.prepare_denoise(*a, context_batch_size=2, text_pairing="branch", **kw)
+    assert all(tv == br for (w, br), tv in st.unit_tv.items()) and st.bank_variants == [1]
+    lit = pipe.prepare_denoise(*a, context_batch_size=2, **kw)
+    assert any(tv != br for (w, br), tv in lit.unit_tv.items()) and lit.bank_variants == [0, 1]
+    two_branch = pipe.denoise(*a, context_batch_size=2, text_pairing="branch", **kw)
+    two_literal = pipe.denoise(*a, context_batch_size=2, **kw)
+    torch.testing.assert_close(two_branch, one, rtol=1e-3, atol=2e-4)      # (f32 CPU kernels, batches of 4 rows against 2)
+    assert (two_literal - one).abs().max() > 1e-3
+    with pytest.raises(ValueError, match="text_pairing"):
+        pipe.prepare_denoise(*a, text_pairing="both", **kw)
