@@ -195,15 +195,17 @@ template <typename T> __device__ __forceinline__ float gelu_for(float x) {
   if constexpr (sizeof(T) == 2) return gelu_erf_fast(x);
   else return gelu_erf_f(x);
 }
-// Two erf-GELUs at once for the bf16 GEGLU epilogue, no transcendentals: gelu(x) = 0.5 x + |x| * E(|x|) with
-// E(t) = 0.5 erf(t / sqrt 2) ~ t * P(t^2) on t <= 4 (degree-6 minimax in t^2, fitted to the gelu error), clamped to 0.5
-// beyond - so gelu(x) -> x / 0 exactly in the tails.  |error| <= 1.9e-4 absolute (a bf16 ulp at 0.05), ~8 issue slots
-// per value with packed f32 math instead of ~23 for the rcp + exp form: the 256x256 GEGLU epilogue is VALU-bound.
+// v * gelu(x) for two (value, gate) pairs - the GEGLU product of the bf16 epilogues - without transcendentals:
+// gelu(x) = x * (0.5 + E(x)), E(x) = 0.5 erf(x / sqrt 2) ~ x * P(x^2) on |x| <= 4 (degree-6 minimax in x^2, fitted to the gelu
+// error: |error| <= 1.9e-4 absolute, a bf16 ulp at 0.05), clamped to +-0.5.  Beyond the fitted range x * P(x^2) keeps growing
+// (>= 0.50001 at 4, monotone, +-inf at overflow), so the clamp alone gives gelu -> x / 0 exactly in the tails: no |x|, no input
+// clamp, and the product v * x * (0.5 + E) stays in packed f32 math - 16 issue slots per pair with the rounding (ocml erff: ~40
+// per VALUE; the rcp + exp form ~23; the first polynomial version, |x| * E(|x|) + x / 2 and a separate multiply: 21 per pair).
+// The 256x256 GEGLU epilogue is VALU-bound: 287 -> 266-273 us at M=98304 N=2560 K=320 (profiles/r04q_geglu_form.txt).
 typedef float v2f_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void gelu_erf_poly2(float xa, float xb, float& ga, float& gb) {
-  const v2f_t x = {xa, xb};
-  const v2f_t t = {fminf(fabsf(xa), 4.0f), fminf(fabsf(xb), 4.0f)};
-  const v2f_t u = t * t;
+__device__ __forceinline__ void geglu_poly2(float va, float vb, float xa, float xb, float& oa, float& ob) {
+  const v2f_t x = {xa, xb}, v = {va, vb};
+  const v2f_t u = x * x;
   v2f_t p = {2.2781060593501935e-08f, 2.2781060593501935e-08f};
   p = p * u + v2f_t{-1.598583253326069e-06f, -1.598583253326069e-06f};
   p = p * u + v2f_t{4.7955145419109613e-05f, 4.7955145419109613e-05f};
@@ -211,10 +213,10 @@ __device__ __forceinline__ void gelu_erf_poly2(float xa, float xb, float& ga, fl
   p = p * u + v2f_t{8.772371336817741e-03f, 8.772371336817741e-03f};
   p = p * u + v2f_t{-6.457307189702988e-02f, -6.457307189702988e-02f};
   p = p * u + v2f_t{3.978833258152008e-01f, 3.978833258152008e-01f};
-  const v2f_t e = t * p;
-  const v2f_t hx = x * v2f_t{0.5f, 0.5f};
-  ga = fmaf(fabsf(xa), fminf(e.x, 0.5f), hx.x);
-  gb = fmaf(fabsf(xb), fminf(e.y, 0.5f), hx.y);
+  const v2f_t e = x * p;
+  const v2f_t s = v2f_t{__builtin_amdgcn_fmed3f(e.x, -0.5f, 0.5f), __builtin_amdgcn_fmed3f(e.y, -0.5f, 0.5f)} + v2f_t{0.5f, 0.5f};
+  const v2f_t o = (v * x) * s;
+  oa = o.x; ob = o.y;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

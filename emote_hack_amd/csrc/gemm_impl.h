@@ -119,10 +119,8 @@ __device__ __forceinline__ void epilogue_row(const f32x16 (&acc)[WTN], const emo
           if (ln) { gt[0] *= ln_rstd; gt[1] *= ln_rstd; gt[2] *= ln_rstd; gt[3] *= ln_rstd; }
           if (p.bias) { const float4 b4 = *(const float4*)(p.bias + nw0 + 32); gt[0] += b4.x; gt[1] += b4.y; gt[2] += b4.z; gt[3] += b4.w; }
           if constexpr (sizeof(T) == 2) {
-            float g0, g1, g2, g3;
-            gelu_erf_poly2(gt[0], gt[1], g0, g1);
-            gelu_erf_poly2(gt[2], gt[3], g2, g3);
-            o[0] *= g0; o[1] *= g1; o[2] *= g2; o[3] *= g3;
+            geglu_poly2(o[0], o[1], gt[0], gt[1], o[0], o[1]);
+            geglu_poly2(o[2], o[3], gt[2], gt[3], o[2], o[3]);
           } else {
 #pragma unroll
             for (int e = 0; e < 4; e++) o[e] *= gelu_for<T>(gt[e]);
@@ -274,10 +272,8 @@ __device__ __forceinline__ void epilogue_lds(const f32x16 (&acc)[WTM][WTN], cons
         if constexpr (GEGLU) {
           float gt[4] = {acc[i][jv + 1][4 * g], acc[i][jv + 1][4 * g + 1], acc[i][jv + 1][4 * g + 2], acc[i][jv + 1][4 * g + 3]};
           if constexpr (LN) { const float rs = ln_rstd[i]; gt[0] *= rs; gt[1] *= rs; gt[2] *= rs; gt[3] *= rs; }
-          float g0, g1, g2, g3;
-          gelu_erf_poly2(gt[0], gt[1], g0, g1);
-          gelu_erf_poly2(gt[2], gt[3], g2, g3);
-          o[0] *= g0; o[1] *= g1; o[2] *= g2; o[3] *= g3;
+          geglu_poly2(o[0], o[1], gt[0], gt[1], o[0], o[1]);
+          geglu_poly2(o[2], o[3], gt[2], gt[3], o[2], o[3]);
         }
         lds_write8(xw + l31 * PITCH + t * 64 + (8 * g + 4 * half) * 2, pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]));
       }

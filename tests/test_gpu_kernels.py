@@ -334,6 +334,37 @@ def test_gemm_rowbias_geglu_transpose(dtype):
     close(got3[:, :, :L], ref3, dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("tile", [0, 2, 4])
+def test_geglu_gate_range_and_tails(dtype, tile):
+    """The GEGLU epilogue's erf-GELU (common.h geglu_poly2: gelu(x) = x * (0.5 + clamp(x * P(x^2), -0.5, 0.5)), no input clamp)
+    over the whole gate range: gates on a grid through [-12, 12] (the fitted range is |x| <= 4), at +-50 / +-3e4 / +-1e30 and 0,
+    values +-1 and 3 - against value * gelu(gate) in f64; beyond |gate| = 9 exactly value * gate / 0."""
+    o = ops()
+    M, K = 512, 64
+    big = 1e30 if dtype == torch.bfloat16 else 6e4       # (x^2 overflows f32 at 1e30: the clamp still decides)
+    gates = torch.cat([torch.linspace(-12, 12, M - 8), torch.tensor([0.0, -0.0, 50.0, -50.0, 3e4, -3e4, big, -big])])
+    vals = torch.tensor([1.0, -1.0, 3.0])[torch.arange(M) % 3]
+    a = torch.zeros(M, K)
+    a[:, 0], a[:, 1] = gates, vals
+    a = q(a, dtype)
+    w = torch.zeros(64, K)          # rows 0-31: value rows (pick column 1), rows 32-63: gate rows (pick column 0)
+    w[:32, 1], w[32:, 0] = 1.0, 1.0
+    got = o.gemm(a.to(DEV).to(dtype), w.to(DEV).to(dtype), None, geglu=True, tile=tile).float().cpu()
+    g, v = a[:, 0].double(), a[:, 1].double()
+    ref = (v * 0.5 * g * (1.0 + torch.erf(g / math.sqrt(2.0)))).float()
+    ref = ref.to(dtype).float()
+    assert tuple(got.shape) == (M, 32) and torch.equal(got, got[:, :1].expand(M, 32))
+    y = got[:, 0]
+    fin = ref.isfinite()
+    assert torch.equal(y.isfinite(), fin) and torch.equal(y[~fin], ref[~fin])          # value * (+1e30) overflows the 2-byte type alike
+    tol = TOL[dtype]
+    torch.testing.assert_close(y[fin], ref[fin], rtol=tol["rtol"], atol=2e-3)
+    far = fin & (g.abs() > 9)        # (erf(9 / sqrt 2) rounds to 1 in f64: the reference is value * gate / 0 exactly there)
+    assert torch.equal(y[far], ref[far])                                                 # the tails are exact: value * gate and 0
+    assert torch.equal(y[g == 0], torch.zeros(int((g == 0).sum())))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("n,H,W,Cin,Cout,stride,up", [(3, 8, 8, 32, 64, 1, False), (2, 16, 12, 64, 32, 2, False),
                                                       (2, 4, 6, 64, 64, 1, True), (1, 16, 16, 8, 320, 1, False),
