@@ -17,7 +17,7 @@ from emote_hack_amd.build import csrc_digest  # noqa: E402  (the build the count
 
 FAMILY = [("layernorm_stats_kernel", "layernorm_stats"), ("softmax_rows_kernel", "softmax_rows"), ("conv3x3_halo_kernel", "gemm_conv3x3"), (r"gemm_kernel<[^>]*?(unsigned short|float), true", "gemm_conv3x3"),
           ("gemm_kernel", "gemm_dense"), ("gemm_splitk_epilogue", "gemm_splitk_epilogue"), ("temporal_attention_mfma_kernel", "temporal_attention"), ("temporal_attention_kernel", "temporal_attention"),
-          ("attention_kernel", "attention"), ("layernorm_kernel", "layernorm"), ("gn_stats_kernel", "groupnorm"), ("gn_apply_kernel", "groupnorm"), ("gn_fold_linear_kernel", "groupnorm")]
+          ("attention_kernel", "attention"), ("layernorm_kernel", "layernorm"), ("gn_stats_kernel", "groupnorm"), ("gn_apply_kernel", "groupnorm"), ("gn_one_kernel", "groupnorm"), ("gn_fold_linear_kernel", "groupnorm")]
 
 
 def family(name):
