@@ -335,7 +335,9 @@ static inline Gn1Geom gn1_geom(int N, int64_t S, int C, int G, int V) {
   const int CVW = g.Wc / V;
   if (CVW > 256 || (int64_t)N * (G / gpb) < GN1_MINBLOCKS) return g;
   // measured (profiles/r04n_groupnorm_one_launch.txt): a slab is Wc * sizeof(T) contiguous bytes per row, so a block's loads are
-  // short row segments; past ~32 K elements per block the two coalesced passes are faster again
+  // short row segments; past ~32 K elements per block the two coalesced passes are faster again.  (Wider slabs - 160 / 320 bytes per
+  // row, as many rows as 16 x 1024 threads hold - measured 23.4 vs 27.5 us at N=24 S=1024 C=640 and 14.3 vs 16.3 at N=24 S=256 C=1280,
+  // 21.7 vs 19.3 at C=320: +-0.05 ms per step, not taken; 24 rows per thread spill.)
   if (S * g.Wc > GN1_MAXELEMS) return g;
   for (int nt = 256; nt <= GN1_MAXT; nt *= 2) {   // short load chains: <= 4 rows per thread if any block size gives that
     const int64_t rows = (S + nt / CVW - 1) / (nt / CVW);
@@ -443,7 +445,9 @@ __global__ __launch_bounds__(GN1_MAXT) void gn_one_kernel(const T* __restrict__ 
 
 extern "C" int emo_groupnorm_one_launch_ok(int N, int64_t S, int C, int G, int dtype) {
   if (!emo_dtype_ok(dtype)) return 0;
-  return gn1_geom(N, S, C, G, emo_dtype_vec(dtype)).ok;
+  const int V = emo_dtype_vec(dtype);
+  if (N <= 0 || S <= 0 || C <= 0 || G <= 0 || C % G || C % V || C / V > GN_THREADS * GN_MAXJ || G > GN_MAXG) return 0;   // (gn_check's limits)
+  return gn1_geom(N, S, C, G, V).ok;
 }
 
 extern "C" int emo_groupnorm(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, int N, int64_t S, int C,
