@@ -99,3 +99,55 @@ def test_strong_mode_deals_one_unit_per_rank_at_eight_gpus():
             for w, br in mine:
                 byw.setdefault(w, set()).add(br)
             assert all(v == {0, 1} for v in byw.values()), (world, r, mine)
+
+
+def test_groupnorm_one_launch_plan():
+    """emo_groupnorm_one_launch_ok (csrc/norm.hip gn1_geom): one workgroup per (instance, slab of whole groups) only where the slab
+    fits <= 32 K elements, the launch has >= 32 workgroups and a slab's channels fill whole 16-byte vectors."""
+    lib = _lib.load()
+    bf16, f16, f32 = _dt(torch.bfloat16), _dt(torch.float16), _dt(torch.float32)
+    ok = lib.emo_groupnorm_one_launch_ok
+    # the bench's norms (N instances of S rows, C channels, 32 groups): 8x8 level joint, 16x16 per frame -> one launch
+    assert ok(2, 12 * 64, 1280, 32, bf16) == 1 and ok(24, 256, 1280, 32, bf16) == 1 and ok(24, 64, 1280, 32, f16) == 1
+    # larger instances keep the two coalesced passes: 16x16 joint, 32x32 per frame / joint, 64x64
+    assert ok(2, 12 * 256, 1280, 32, bf16) == 0 and ok(24, 1024, 640, 32, bf16) == 0 and ok(2, 12 * 4096, 320, 32, bf16) == 0
+    # too few workgroups (2 instances x 8 slabs of 4 groups at 10 channels per group)
+    assert ok(2, 256, 320, 32, bf16) == 0 and ok(5, 37, 320, 32, bf16) == 1
+    # f32: 4-wide vectors, slabs of 2 groups at 10 channels per group
+    assert ok(5, 37, 320, 32, f32) == 1
+    # outside the kernels' limits (groups, width, divisibility, dtype): never
+    assert ok(4, 64, 1280, 256, bf16) == 0 and ok(4, 64, 1284, 32, bf16) == 0 and ok(4, 64, 1280, 32, 7) == 0 and ok(0, 64, 1280, 32, bf16) == 0
+
+
+def test_geglu_polynomial_constants():
+    """The erf-GELU polynomial of the bf16 GEGLU epilogue (csrc/common.h geglu_poly2), restated in numpy f32 with the constants read
+    from the header: |gelu error| <= 1.9e-4 over the fitted range, x * P(x^2) >= 0.5 from |x| = 4 on (so the output clamp alone
+    makes the tails exact - the kernel has no input clamp), monotone there, and no NaN up to overflow."""
+    import os
+    import re
+    import math
+    import numpy as np
+    src = open(os.path.join(os.path.dirname(_lib.HERE), "emote_hack_amd", "csrc", "common.h")).read()
+    body = src[src.index("void geglu_poly2("):]
+    body = body[:body.index("oa = o.x")]
+    coef = [float(m) for m in re.findall(r"v2f_t\{(-?[0-9.]+e[-+]?[0-9]+)f,", body)]
+    lead = float(re.search(r"v2f_t p = \{([0-9.e+-]+)f,", body).group(1))
+    coef = [lead] + coef
+    assert len(coef) == 7, coef
+
+    def E(t):
+        t = t.astype(np.float32)
+        u = t * t
+        p = np.full_like(t, np.float32(coef[0]))
+        for c in coef[1:]:
+            p = p * u + np.float32(c)
+        return t * p
+
+    x = np.linspace(-6, 6, 240001, dtype=np.float32)
+    g = x * (np.float32(0.5) + np.clip(E(x), -0.5, 0.5))
+    ref = np.array([0.5 * v * (1.0 + math.erf(v / math.sqrt(2.0))) for v in x.astype(np.float64)])
+    assert np.abs(g - ref).max() <= 1.9e-4
+    t = np.logspace(math.log10(4.0), 19, 200001).astype(np.float32)
+    with np.errstate(over="ignore"):
+        e = E(t)
+    assert not np.isnan(e).any() and e.min() >= 0.5 and (np.diff(e[np.isfinite(e)]) >= 0).all()
