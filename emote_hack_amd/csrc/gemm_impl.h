@@ -81,6 +81,11 @@ template <int WTM, int WTN, int WVM, int WVN, int NS_> struct GemmTile {
 #define EMO_GLDS16(gptr, lptr) \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
+// the same 16-byte direct-to-LDS load through a buffer resource: lane offset (range-checked: out of range reads 0) + scalar offset
+// (a __device__ function: with the builtin in a kernel template's own body the host pass drops the kernel's stub)
+__device__ __forceinline__ void glds16_buffer(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_dst, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) unsigned char*)lds_dst, 16, voff, soff, 0, 0);
+}
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ uint4 lds_read16(unsigned addr) {
@@ -394,6 +399,9 @@ struct ConvRow { int img, iy0, ix0; };
 // and that is group 1's request epoch.  A plain 2-deep ring (128 KB) therefore suffices.  Every wait is the issuing wave's
 // own vmcnt followed by a barrier the readers pass (LDS-DMA data is ordered by nothing else).  The offset collapses at a
 // tile's end (joint LDS-staged epilogue) - one half-idle epoch per group and tile.
+#ifndef EMO_GEMM_PH
+#define EMO_GEMM_PH 1      // 1: the ping-pong tile runs the PHASE main loop (below); 0: the stage-granular ping-pong of round 3 (A/B builds)
+#endif
 template <typename T, bool CONV, bool TRANS, int WTM, int WTN, int WVM, int WVN, int NS, bool LN = false, bool PP = false>
 __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::WPE)) void gemm_kernel(const emo_gemm_params p) {
   static_assert(!(LN && CONV), "the LayerNorm fold is for the dense loader");
@@ -621,8 +629,58 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
     }
   };
 
+  // ---- phase loader (PP with EMO_GEMM_PH): a K-tile's stage is requested in QUARTERS of 128 rows that follow the phases'
+  // last reads - A0 / A1 = the first / second 64 rows of each wave group's 128, B0 / B1 = the first / second 32 rows of each wave
+  // column's 64 (W rows = output columns).  A quarter is 16 pieces of 8 rows; wave w requests pieces 2w, 2w + 1.  Pointers are
+  // formed per request from (tile base, row, K-tile): the stream crosses tile boundaries without a loader state machine.
+  // Requests go through buffer resources anchored at the tile's first A row / W row: one 32-bit lane offset per piece, the
+  // K-tile in the scalar offset, the LDS address in M0 - 3-4 instructions per request; rows past M / N fall outside the
+  // resource's range and read zeros (their products land in accumulator rows / columns that are never stored).
+  int ph_abase[2], ph_bbase[2];     // [piece] first row (wave-uniform) of this wave's piece of quarter A0 / B0 (A1: + 64, B1: + 32)
+  unsigned ph_avoff[2], ph_bvoff[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int pr0 = (2 * wave + j) * (64 / CPR);
+    ph_abase[j] = (pr0 >> 6) * 128 + (pr0 & 63);
+    ph_bbase[j] = (pr0 >> 5) * 64 + (pr0 & 31);
+    const int ra = ph_abase[j] + lrow, rb = ph_bbase[j] + lrow;     // (swz(r + 64) == swz(r), swz(r + 32) == swz(r): one key per piece)
+    ph_avoff[j] = (unsigned)ra * (unsigned)p.lda * (unsigned)sizeof(T) + (unsigned)((lchunk ^ swz(ra)) * 16);
+    ph_bvoff[j] = (unsigned)rb * (unsigned)p.K * (unsigned)sizeof(T) + (unsigned)((lchunk ^ swz(rb)) * 16);
+  }
+  struct PhTile { __amdgpu_buffer_rsrc_t ra, rb; };
+  auto ph_tile = [&](int iter) -> PhTile {
+    int ltm, ltn;
+    tile_mn(tile_of(iter), ltm, ltn);
+    const int64_t tbm = (int64_t)ltm * BM;
+    const int tbn = ltn * BN;
+    const T* tw = p.w_slab_rows > 0 ? W + (tbm / p.w_slab_rows) * p.w_slab_stride : W;
+    const int64_t arows = p.M - tbm < BM ? p.M - tbm : BM, brows = p.N - tbn < BN ? p.N - tbn : BN;
+    PhTile t;
+    t.ra = __builtin_amdgcn_make_buffer_rsrc((void*)(A + tbm * p.lda), 0, (int)(((arows - 1) * p.lda + p.K) * (int64_t)sizeof(T)), 0x00020000);
+    t.rb = __builtin_amdgcn_make_buffer_rsrc((void*)(tw + (int64_t)tbn * p.K), 0, (int)(brows * (int64_t)p.K * (int64_t)sizeof(T)), 0x00020000);
+    return t;
+  };
+  auto ph_req_a = [&](int hf, const PhTile& t, int kt, int slot) {
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+      glds16_buffer(t.ra, lds + slot * Tile::STAGE_BYTES + (ph_abase[j] + hf * 64) * KBYTES, ph_avoff[j] + (unsigned)(hf * 64) * (unsigned)p.lda * (unsigned)sizeof(T),
+                    (unsigned)kt * (unsigned)KBYTES);
+  };
+  auto ph_req_b = [&](int hf, const PhTile& t, int kt, int slot) {
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+      glds16_buffer(t.rb, lds + slot * Tile::STAGE_BYTES + Tile::A_BYTES + (ph_bbase[j] + hf * 32) * KBYTES,
+                    ph_bvoff[j] + (unsigned)(hf * 32) * (unsigned)p.K * (unsigned)sizeof(T), (unsigned)kt * (unsigned)KBYTES);
+  };
+
   // stream prologue: NS-1 stages in flight
   int gs = 0;   // stream stage counter of the MFMA loop (ring slot = gs % NS)
+  if constexpr (PP && EMO_GEMM_PH) {
+    if (nk > 0 && (int)blockIdx.x < tiles_all) {   // all four quarters of the first tile's K-tile 0
+      const PhTile ft = ph_tile(blockIdx.x);
+      ph_req_a(0, ft, 0, 0); ph_req_b(0, ft, 0, 0); ph_req_b(1, ft, 0, 0); ph_req_a(1, ft, 0, 0);
+    }
+  } else
   if constexpr (PP) {
     if (nk > 0 && l_iter < tiles_all) {
       pp_setup(l_iter);
@@ -697,6 +755,91 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
       }
   }
 
+  if constexpr (PP && EMO_GEMM_PH) {
+    // PHASE main loop (the structure of the guide's 256^2 8-phase template on this kernel's 32x32x16 tiles; measured standalone in
+    // tools/bench/micro/gemm8p.hip, profiles/r04y_gemm8p_micro.txt).  A K-tile is 4 phases = the wave's 4 quadrants of 64 x 32:
+    //   P1 (A0, B0)   P2 (A0, B1)   P3 (A1, B1)   P4 (A1, B0 from registers)
+    // each  [fragment reads of the quadrant + one quarter's LDS-DMA requests]  s_barrier  lgkmcnt(0)  [8 MFMAs, nothing else]  s_barrier,
+    // and wave group 1 runs ONE barrier behind group 0: one wave per SIMD multiplies from registers while the other reads and
+    // requests.  Quarters are restaged behind their last read (both groups are past it two barriers later):
+    //   P1: B1 of K-tile kt+1 (last read: P2 of kt-1)      P2: A1 of kt+1 (P3 of kt-1)
+    //   P3: A0 of K-tile kt+2 (last read: P1 of kt)        P4: B0 of kt+2 (P1 of kt), then vmcnt(4): all of kt+1 has landed
+    // The K-tile stream continues into the block's next tile; only the two requests that would land in the slot the epilogue
+    // stages through (A0 / B0 of the next tile's K-tile 1) wait for the next tile's start.
+    wait_vmcnt<0>();                  // K-tile 0 of this tile (requested a tile ago) and the previous epilogue's stores
+    __builtin_amdgcn_s_barrier();     // ... visible to all; everyone is out of the previous epilogue's staging slot
+    const bool has_next = c_iter + G < tiles_all;
+    const PhTile ct = ph_tile(c_iter), nt = ph_tile(has_next ? c_iter + G : c_iter);
+    ph_req_a(0, ct, 1, (gs + 1) & 1); ph_req_b(0, ct, 1, (gs + 1) & 1);      // (nk >= 2: dispatch_tile)
+    if (pp_grp == 1) __builtin_amdgcn_s_barrier();
+    // (Measured and not kept: B0 of K-tile kt+1 read during P4 of kt into the registers B1 has left - 8 / 4 / 8 / 4 reads per load
+    // section instead of 12 / 4 / 8 / 0, the loop unrolled over two K-tiles: hipcc spills into the loop, and scratch accesses sit
+    // in the same vmcnt the requests are counted on - wrong tiles and 2x slower.)
+    uint4 ra[2][KSTEPS], rb0[KSTEPS], rb1[KSTEPS];
+    auto rd_a = [&](unsigned st, auto H) {
+      constexpr int h = decltype(H)::value;
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; kk++) ra[i][kk] = lds_read16((st + fa0[h * 2 + i]) ^ (kk << 5));
+    };
+    auto rd_b = [&](unsigned st, auto J, uint4 (&rb)[KSTEPS]) {
+      constexpr int j = decltype(J)::value;
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; kk++) rb[kk] = lds_read16((st + fb0[j]) ^ (kk << 5));
+    };
+    auto quad = [&](auto H, auto J, const uint4 (&rb)[KSTEPS]) {
+      constexpr int h = decltype(H)::value, j = decltype(J)::value;
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; kk++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) acc[h * 2 + i][j] = mma16<T>(rb[kk], ra[i][kk], acc[h * 2 + i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    for (int kt = 0; kt < nk; kt++, gs++) {
+      const unsigned st = (gs & 1) * Tile::STAGE_BYTES;
+      const int slot_c = gs & 1, slot_o = slot_c ^ 1;
+      const bool last = kt == nk - 1;
+      const bool t1 = !last || has_next;                          // K-tile kt+1 of the stream exists
+      const bool t1_here = !last;
+      const bool t2_here = kt + 2 < nk;
+      const bool t2 = !last && (t2_here || has_next);             // K-tile kt+2, unless it belongs behind the epilogue
+      // ---- P1
+      rd_b(st, I0{}, rb0);
+      __builtin_amdgcn_sched_barrier(0);
+      rd_a(st, I0{});
+      if (t1) ph_req_b(1, t1_here ? ct : nt, t1_here ? kt + 1 : 0, slot_o);
+      __builtin_amdgcn_s_barrier();
+      wait_lgkmcnt<0>();
+      quad(I0{}, I0{}, rb0);
+      __builtin_amdgcn_s_barrier();
+      // ---- P2
+      rd_b(st, I1{}, rb1);
+      if (t1) ph_req_a(1, t1_here ? ct : nt, t1_here ? kt + 1 : 0, slot_o);
+      __builtin_amdgcn_s_barrier();
+      wait_lgkmcnt<0>();
+      quad(I0{}, I1{}, rb1);
+      __builtin_amdgcn_s_barrier();
+      // ---- P3
+      rd_a(st, I1{});
+      if (t2) ph_req_a(0, t2_here ? ct : nt, t2_here ? kt + 2 : 0, slot_c);
+      __builtin_amdgcn_s_barrier();
+      wait_lgkmcnt<0>();
+      quad(I1{}, I1{}, rb1);
+      __builtin_amdgcn_s_barrier();
+      // ---- P4
+      if (t2) { ph_req_b(0, t2_here ? ct : nt, t2_here ? kt + 2 : 0, slot_c); wait_vmcnt<4>(); }
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      quad(I1{}, I0{}, rb0);
+      __builtin_amdgcn_s_barrier();
+    }
+    if (pp_grp == 0) __builtin_amdgcn_s_barrier();   // realign: group 1's last barrier
+  } else
   if constexpr (PP) {
     // the 32 MFMAs of one stage (4 k-steps x 8), next k-step's fragment reads between them - the lockstep loop's cluster
     auto pp_mma = [&](unsigned st) {
@@ -1314,7 +1457,7 @@ static int dispatch_tile(const emo_gemm_params& p, const GemmPlan& pl, int S, hi
   switch (pl.tile) {
     case EMO_TILE_256x256_PP:
       if constexpr (!CONV && !TRANS && sizeof(T) == 2) {
-        if (S == 1 && p.K % (KBYTES / (int)sizeof(T)) == 0 && p.split_k <= 1) return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, 2, LN, true>(p, S, st);
+        if (S == 1 && p.K % (KBYTES / (int)sizeof(T)) == 0 && p.K >= 2 * (KBYTES / (int)sizeof(T)) && p.split_k <= 1) return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, 2, LN, true>(p, S, st);   // (>= 2 K-tiles: the phase loader)
       }
       return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, NS_BIG, LN>(p, S, st);
     case EMO_TILE_256x256: return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, NS_BIG, LN>(p, S, st);

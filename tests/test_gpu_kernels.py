@@ -227,13 +227,16 @@ def test_gemm_persistent_many_tiles(dtype, M, N, K, geglu, res):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K,geglu,res,ln", [(8192 + 37, 2560, 320, True, False, True),   # GEGLU + LayerNorm fold, ragged last row panel
                                                 (140000, 512, 192, False, True, False),     # 1100 tiles: ~4 per persistent block, 3 stages each
-                                                (33000, 1280, 64, False, False, False),     # ONE stage per tile: every request crosses a tile boundary
+                                                (33000, 1280, 64, False, False, False),     # ONE K-tile per tile (the phase loader needs two: lockstep loop)
+                                                (33000, 1280, 128, False, False, False),    # TWO K-tiles per tile: every request crosses a tile boundary
                                                 (5000, 960, 1600, False, True, False),      # ragged last column panel, 25 stages
                                                 (6144, 3840, 1280, False, False, True)])
 def test_gemm_ping_pong_main_loop(dtype, M, N, K, geglu, res, ln):
-    """EMO_TILE_256x256_PP: the two wave rows of a block half a stage apart, the W panel requested by the lagging one only
-    (gemm_impl.h).  Every ordering rule of that loop is a data hazard when broken - checked on many tiles per block, one-stage
-    tiles, ragged edges, against the f32 matmul and BIT FOR BIT against the lockstep loop of the same tile (same MFMA order)."""
+    """EMO_TILE_256x256_PP: the PHASE main loop (gemm_impl.h EMO_GEMM_PH) - four quadrant phases per K-tile, each a load section
+    (fragment reads + the LDS-DMA requests of one quarter of a later K-tile) and a pure-MFMA section, the two wave rows of a block
+    one barrier apart, quarters restaged behind their last read, the K-tile stream running on into the block's next tile.  Every
+    ordering rule of that loop is a data hazard when broken - checked on many tiles per block, two- and three-K-tile tiles, ragged
+    edges, against the f32 matmul and BIT FOR BIT against the lockstep loop of the same tile (same MFMA order per accumulator)."""
     o = ops()
     g = torch.Generator(device="cpu").manual_seed(321)
     a = q(torch.randn(M, K, generator=g) * 1.5 + 0.2, dtype).to(DEV).to(dtype)
