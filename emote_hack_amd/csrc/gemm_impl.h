@@ -774,7 +774,8 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
     if (pp_grp == 1) __builtin_amdgcn_s_barrier();
     // (Measured and not kept: B0 of K-tile kt+1 read during P4 of kt into the registers B1 has left - 8 / 4 / 8 / 4 reads per load
     // section instead of 12 / 4 / 8 / 0, the loop unrolled over two K-tiles: hipcc spills into the loop, and scratch accesses sit
-    // in the same vmcnt the requests are counted on - wrong tiles and 2x slower.)
+    // in the same vmcnt the requests are counted on - wrong tiles and 2x slower; the same balance without unrolling - B0 read in P4 into
+    // B1's registers, 16 v_mov at the next P1, a counted vmcnt in P3 - is correct and 5-9 % slower: profiles/r04ph_phase_main_loop.txt.)
     uint4 ra[2][KSTEPS], rb0[KSTEPS], rb1[KSTEPS];
     auto rd_a = [&](unsigned st, auto H) {
       constexpr int h = decltype(H)::value;
