@@ -1458,7 +1458,9 @@ static int dispatch_tile(const emo_gemm_params& p, const GemmPlan& pl, int S, hi
   switch (pl.tile) {
     case EMO_TILE_256x256_PP:
       if constexpr (!CONV && !TRANS && sizeof(T) == 2) {
-        if (S == 1 && p.K % (KBYTES / (int)sizeof(T)) == 0 && p.K >= 2 * (KBYTES / (int)sizeof(T)) && p.split_k <= 1) return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, 2, LN, true>(p, S, st);   // (>= 2 K-tiles: the phase loader)
+        // (the phase loader: >= 2 K-tiles, and a tile's 256 rows of A / W inside the 31-bit range of its buffer resources)
+        const bool ph_ok = p.K >= 2 * (KBYTES / (int)sizeof(T)) && 256 * p.lda * (int64_t)sizeof(T) < (1ll << 31) && 256 * (int64_t)p.K * (int64_t)sizeof(T) < (1ll << 31);
+        if (S == 1 && p.K % (KBYTES / (int)sizeof(T)) == 0 && ph_ok && p.split_k <= 1) return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, 2, LN, true>(p, S, st);
       }
       return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, NS_BIG, LN>(p, S, st);
     case EMO_TILE_256x256: return launch_gemm<T, CONV, TRANS, 4, 2, 2, 4, NS_BIG, LN>(p, S, st);
