@@ -13,9 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libemo_hip.so")
-# the GEMM / conv kernels are instantiated per element type in their own translation units (parallel compile)
-SOURCES = ["elementwise.hip", "norm.hip", "gemm.hip", "gemm_f32.hip", "gemm_bf16.hip", "gemm_f16.hip", "attention.hip", "temporal.hip",
-           "conditioning.hip", "frontend.hip"]
+# the GEMM and the halo-conv kernels are instantiated per element type in their own translation units (parallel compile)
+SOURCES = ["elementwise.hip", "norm.hip", "gemm.hip", "gemm_f32.hip", "gemm_bf16.hip", "gemm_f16.hip", "conv_halo_f32.hip", "conv_halo_bf16.hip",
+           "conv_halo_f16.hip", "attention.hip", "temporal.hip", "conditioning.hip", "frontend.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-pass-failed"]
@@ -39,7 +39,7 @@ def _newer(a, b):
 
 def build_extension(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_api.h"), os.path.join(CSRC, "gemm_impl.h"),
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_api.h"), os.path.join(CSRC, "gemm_impl.h"), os.path.join(CSRC, "conv_halo_impl.h"),
             os.path.join(os.path.dirname(HERE), "include", "emo_hip.h")]
     objs, jobs = [], []
     for s in SOURCES:

@@ -16,6 +16,22 @@ extern "C" size_t emo_gemm_workspace_bytes(int64_t M, int N, int split_k) {
   return split_k > 1 ? (size_t)split_k * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
+// the stride-1 3x3 convs the halo-reuse kernel serves (conv_halo_impl.h); everything else takes the im2col loader of the GEMM
+static bool halo_conv_ok(const emo_gemm_params& p) {
+  const int S = p.split_k > 1 ? p.split_k : 1;
+  const int bk = KBYTES / (p.dtype == EMO_F32 ? 4 : 2);
+  // (the nearest x2 upsampling of resnet.py:74-82 rides along: the patch grid lives on the upsampled frame)
+  const int He = p.upsample2x ? 2 * p.H : p.H, We = p.upsample2x ? 2 * p.W_ : p.W_;
+  return p.conv_taps == 9 && p.stride == 1 && !p.conv_asym && !p.up_h && !p.transpose_out && !p.geglu && S == 1 && p.Cin > 0 && p.Cin % bk == 0 &&
+         He % 8 == 0 && We % HaloGeom::PW == 0 && (p.N & 3) == 0 &&
+         // (its loaders address one frame / one weight tile through 32-bit buffer offsets)
+         (int64_t)p.H * p.W_ * p.lda * (p.dtype == EMO_F32 ? 4 : 2) < (1ll << 31) && (int64_t)HaloGeom::BN * p.K * (p.dtype == EMO_F32 ? 4 : 2) < (1ll << 31) &&
+         (!p.rowbias || (p.rows_per_batch % (He * We) == 0 && (p.ld_rowbias & 3) == 0));
+}
+extern "C" int emo_conv3x3_gn_fusable(const emo_gemm_params* pp) {
+  return pp && emo_dtype_ok(pp->dtype) && pp->H > 0 && pp->W_ > 0 && halo_conv_ok(*pp) && !pp->upsample2x ? 1 : 0;
+}
+
 extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
   EMO_CHECK(pp, EMO_ERR_NULL, "emo_gemm: null params");
   const emo_gemm_params& p = *pp;
@@ -57,13 +73,15 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
     EMO_CHECK(p.N % 4 == 0 && ((uintptr_t)p.ln_colsum % 16) == 0 && ((uintptr_t)p.ln_stats % 8) == 0 && (!p.bias || ((uintptr_t)p.bias % 16) == 0),
               EMO_ERR_BAD_SHAPE, "emo_gemm: the LayerNorm fold needs N %% 4 == 0 and aligned colsum / stats / bias");
   }
+  if (p.gn_coef) {
+    EMO_CHECK(conv && halo_conv_ok(p) && !p.upsample2x, EMO_ERR_UNSUPPORTED,
+              "emo_gemm: gn_coef is served by the halo-reuse 3x3 conv only (ask emo_conv3x3_gn_fusable)");
+    EMO_CHECK(p.gn_imgs_per_inst > 0 && (p.M / ((int64_t)p.H * p.W_)) % p.gn_imgs_per_inst == 0 && ((uintptr_t)p.gn_coef % 16) == 0,
+              EMO_ERR_BAD_SHAPE, "emo_gemm: gn_imgs_per_inst=%d must divide the image count; gn_coef 16-byte aligned", p.gn_imgs_per_inst);
+  }
   {
-    const int bk = KBYTES / (p.dtype == EMO_F32 ? 4 : 2);
-    // (the nearest x2 upsampling of resnet.py:74-82 rides along: the patch grid lives on the upsampled frame)
-    const int He = p.upsample2x ? 2 * p.H : p.H, We = p.upsample2x ? 2 * p.W_ : p.W_;
-    if (conv && p.stride == 1 && !p.conv_asym && !p.up_h && !p.transpose_out && !p.geglu && S == 1 && p.Cin % bk == 0 &&
-        He % 8 == 0 && We % HaloGeom::PW == 0 && (p.N & 3) == 0 &&
-        (!p.rowbias || (p.rows_per_batch % (He * We) == 0 && (p.ld_rowbias & 3) == 0))) {
+    const int He = p.upsample2x ? 2 * p.H : p.H;
+    if (conv && halo_conv_ok(p)) {
       const int64_t nt = (p.N + HaloGeom::BN - 1) / HaloGeom::BN;
       // 16-row patches (8 waves, one block per CU) when they still give (nearly) every CU a block; p.tile 1 / 2 pins 8 / 16
       const int64_t tiles16 = (p.M / 256) * nt;

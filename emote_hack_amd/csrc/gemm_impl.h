@@ -1065,292 +1065,6 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
   }   // tiles of this block
 }
 
-// ------------------------------------------------------------------------------------------ 3x3 conv, halo reuse
-// Stride-1 3x3 convolution (resnet.py:30-38 - 44 of the 54 convs of a UNet pass) without the 9x re-read of the im2col
-// loader.  A block owns an 8x16 patch of output pixels of one frame (= 128 GEMM rows) x 128 output channels.  K runs
-// channel-chunk major: for every 128-byte channel chunk the (8+2)x(16+2) input HALO of the patch is brought into LDS ONCE
-// (23 KB instead of 9 x 16 KB of im2col rows) and the 9 taps read their A fragments from it at shifted pixel positions;
-// only the weight tile (128 x 128 B per tap) streams per stage.  LDS-DMA traffic per MFMA drops by ~40 % - the
-// direct-to-LDS path (~9 TB/s chip-wide measured) is what bounds the im2col kernel.
-//   * LDS: 2 halo buffers (chunk c+1 arrives in 6 pieces during the first 6 taps of chunk c) + a 2-deep weight ring
-//     = 78 KB -> 2 blocks per CU.  LDS "rows" of the halo are halo pixels; same XOR chunk swizzle as the GEMM.
-//   * persistent blocks, continuous loader stream across tiles, weights one stage ahead (requested right behind the
-//     barrier), vmcnt(0) + one s_barrier per tap-stage.
-//   * epilogue = the GEMM's row-major fused epilogue (bias, temb row bias, residual), rows mapped through the patch.
-// Needs Cin % (128 B of channels) == 0, H % 8 == 0, W % 16 == 0; everything else stays on the im2col loader.
-// PH_ = patch height: 8 (4 waves, 128 output pixels, 78 KB of LDS, 2 blocks per CU) or 16 (8 waves, 256 pixels, 114 KB,
-// 1 block per CU).  The weight tile is the larger stream: 16 KB per tap-stage against 2.6 KB of halo (PH 8) - the 16-row
-// patch feeds twice the MFMAs from the same weights, 4.9 KB of LDS-DMA traffic per MFLOP instead of 8.9 (the direct-to-LDS
-// path, ~9 TB/s chip-wide, is what the 8-row kernel sits on at 1000-1050 TFLOP/s).
-// BN_ = output channels per block: 128, or 64 for the REMAINDER columns of a width that is an odd multiple of 64 (N = 320: two
-// 128-column tiles + one of 64 - a third 128-column tile computed 64 columns of zeros, 17 % of the launch; host side: gemm.hip)
-template <int PH_, int BN_ = HaloGeom::BN> struct HaloT {
-  static constexpr int PH = PH_, PW = HaloGeom::PW, NW = PH_ / 2, HW_ = PW + 2, HPIX = (PH + 2) * (PW + 2);   // 180 / 324 halo pixels
-  static constexpr int PIECES = (HPIX + 7) / 8;                 // 1 KB glds pieces of 8 pixels: 23 / 41
-  static constexpr int LH = (PIECES + NW - 1) / NW;             // pieces per wave: 6 (the last round is partial)
-  static constexpr int HALO_BYTES = PIECES * 1024;              // 23 / 41 KB
-  static constexpr int BN = BN_, LB = BN / (8 * NW);            // weight tile rows, glds per wave per stage
-  static_assert(BN_ == 128 || BN_ == 64, "halo conv: 128 or 64 output channels per block");
-  static constexpr int B_BYTES = BN * KBYTES;                   // 16 KB
-  static constexpr int B_OFF = 2 * HALO_BYTES;
-  static constexpr int LDS_BYTES = 2 * HALO_BYTES + 2 * B_BYTES;   // 79872 / 116736
-  static_assert(LH == 6, "the halo pieces ride on taps 0..5");
-};
-
-template <typename T, int PH_, int BN_ = HaloGeom::BN>
-__global__ __launch_bounds__(32 * PH_, 2) void conv3x3_halo_kernel(const emo_gemm_params p) {
-  using Halo = HaloT<PH_, BN_>;
-  constexpr int V = TT<T>::VEC, BK = KBYTES / (int)sizeof(T);
-  constexpr int WTM = 2, WTN = BN_ / 64, NW = Halo::NW, LH = Halo::LH, LB = Halo::LB, BN = Halo::BN;   // two wave columns of WTN x 32 channels
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wvm = wave >> 1, wvn = wave & 1;
-  const int half = lane >> 5, l31 = lane & 31;
-
-  // nearest x2 upsampling folded into the halo loader (resnet.py:74-82: the interpolated tensor never exists): the patch
-  // grid lives on the UPSAMPLED frame (He x We), a halo pixel (y, x) is read from source pixel (y >> 1, x >> 1)
-  const int ups = p.upsample2x ? 1 : 0;
-  const int He = p.H << ups, We = p.W_ << ups;
-  const int tpx = We / Halo::PW, tpy = He / Halo::PH, tpi = tpx * tpy;   // patches per frame
-  const int tiles_m = (int)(p.M / ((int64_t)He * We)) * tpi;
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int tiles_all = tiles_m * tiles_n;
-  const int G = gridDim.x;
-  auto tile_of = [&](int i) {
-    const int qn = tiles_all >> 3, rn = tiles_all & 7, x = i & 7, idx = i >> 3;
-    return (x < rn ? x * (qn + 1) : rn * (qn + 1) + (x - rn) * qn) + idx;
-  };
-  const int nchunks = p.Cin / BK;
-  const int nk = nchunks * 9;            // tap-stages per tile
-
-  const T* __restrict__ A = (const T*)p.A;
-  const T* __restrict__ W = (const T*)p.W;
-  const T* zero = (const T*)g_zero_page;
-  const int lrow = lane / CPR, lchunk = lane % CPR;
-
-  // ---- halo loader: piece pi = i*4 + wave covers halo pixels pi*8 .. +8 (lane -> pixel pi*8 + lane/8, chunk lane%8)
-  int h_y[LH], h_x[LH], h_klog[LH];
-  bool h_piece[LH];
-#pragma unroll
-  for (int i = 0; i < LH; i++) {
-    const int pi = i * NW + wave, hp = pi * 8 + lrow;
-    h_piece[i] = pi < Halo::PIECES;
-    h_klog[i] = lchunk ^ swz(hp);
-    h_y[i] = hp < Halo::HPIX ? hp / Halo::HW_ : -100000;   // pad pixels of the last piece read the zero page
-    h_x[i] = hp % Halo::HW_;
-  }
-  const T* h_ptr[LH];
-  int h_inc[LH];
-  int h_iter = blockIdx.x, h_c = 0, h_count = 0;   // halo loader: tile, chunk, running chunk counter (buffer = count % 2)
-  auto setup_halo = [&](int iter) {
-    const int tile = tile_of(iter);
-    const int tm = tile / tiles_n;
-    const int img = tm / tpi, rem = tm % tpi;
-    const int y0 = (rem / tpx) * Halo::PH - 1, x0 = (rem % tpx) * Halo::PW - 1;
-#pragma unroll
-    for (int i = 0; i < LH; i++) {
-      const int iy = y0 + h_y[i], ix = x0 + h_x[i];
-      const bool ok = iy >= 0 && iy < He && ix >= 0 && ix < We;
-      h_ptr[i] = ok ? A + (((int64_t)img * p.H + (iy >> ups)) * p.W_ + (ix >> ups)) * p.lda + h_klog[i] * V : zero;
-      h_inc[i] = ok ? BK : 0;
-    }
-  };
-  auto issue_halo = [&](auto I) {
-    constexpr int i = decltype(I)::value;
-    if (h_piece[i]) {
-      EMO_GLDS16(h_ptr[i], lds + (h_count & 1) * Halo::HALO_BYTES + (i * NW + wave) * 1024);
-      h_ptr[i] += h_inc[i];
-    }
-  };
-  auto advance_halo = [&]() {   // after the last piece of a chunk
-    h_count++;
-    if (++h_c >= nchunks) {
-      h_c = 0;
-      h_iter += G;
-      if (h_iter < tiles_all) setup_halo(h_iter);
-    }
-  };
-
-  // ---- weight loader: stage (c, t) of a tile reads W[n][t*Cin + c*BK ..+BK)
-  int b_klog[LB];
-  const T* b_base[LB];
-  bool b_ok[LB];
-#pragma unroll
-  for (int i = 0; i < LB; i++) b_klog[i] = lchunk ^ swz((i * NW + wave) * (64 / CPR) + lrow);
-  int l_iter = blockIdx.x, l_c = 0, l_t = 0;
-  auto setup_b = [&](int iter) {
-    const int tile = tile_of(iter);
-    const int lbn = (tile % tiles_n) * BN;
-#pragma unroll
-    for (int i = 0; i < LB; i++) {
-      const int n = lbn + (i * NW + wave) * (64 / CPR) + lrow;
-      b_ok[i] = n < p.N;
-      b_base[i] = b_ok[i] ? W + (int64_t)n * p.K + b_klog[i] * V : zero;
-    }
-  };
-  auto issue_b = [&](int slot) {
-    const int koff = l_t * p.Cin + l_c * BK;
-#pragma unroll
-    for (int i = 0; i < LB; i++)
-      EMO_GLDS16(b_ok[i] ? b_base[i] + koff : zero, lds + Halo::B_OFF + slot * Halo::B_BYTES + (i * NW + wave) * 1024);
-  };
-  auto advance_b = [&]() {
-    if (++l_t >= 9) {
-      l_t = 0;
-      if (++l_c >= nchunks) {
-        l_c = 0;
-        l_iter += G;
-        if (l_iter < tiles_all) setup_b(l_iter);
-      }
-    }
-  };
-
-  // ---- fragment addressing
-  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-  int hp0[WTM];   // halo pixel of tap (0,0) for this lane's output pixel of MFMA tile row i
-#pragma unroll
-  for (int i = 0; i < WTM; i++) hp0[i] = ((wvm * WTM + i) * 2 + (l31 >> 4)) * Halo::HW_ + (l31 & 15);
-  unsigned fb_off[WTN][KSTEPS];
-#pragma unroll
-  for (int j = 0; j < WTN; j++) {
-    const int r = wvn * 32 * WTN + j * 32 + l31;
-#pragma unroll
-    for (int kk = 0; kk < KSTEPS; kk++) fb_off[j][kk] = Halo::B_OFF + r * KBYTES + (((kk * 2 + half) ^ swz(r)) * 16);
-  }
-
-  T* __restrict__ C = (T*)p.C;
-  const T* __restrict__ R = (const T*)p.residual;
-  emo_gemm_params pe = p;     // the accumulators start at bias + temb row bias: the epilogue sees neither
-  pe.bias = nullptr;
-  pe.rowbias = nullptr;
-  const bool lds_epi = sizeof(T) == 2 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!R || (p.ldr & 7) == 0);
-
-  // ---- stream prologue: halo of the first chunk, weights of the first stage
-  setup_halo(h_iter);
-  static_for<LH>([&](auto I) { issue_halo(I); });
-  advance_halo();
-  setup_b(l_iter);
-  issue_b(0);
-  advance_b();
-
-  int gs = 0, gc = 0;   // running tap-stage / chunk counters of the MFMA loop (weight slot = gs % 2, halo buffer = gc % 2)
-  for (int c_iter = blockIdx.x; c_iter < tiles_all; c_iter += G) {
-    const int c_tile = tile_of(c_iter);
-    f32x16 acc[WTM][WTN];
-    init_acc_bias<WTM, WTN>(acc, p.bias, (c_tile % tiles_n) * BN + wvn * 32 * WTN, half, p.N);   // zeros without a bias
-    if (p.rowbias) {   // temb row bias (resnet.py:188): one row per frame, a patch lies inside one frame
-      const int tm0 = c_tile / tiles_n;
-      const int64_t m0 = (int64_t)(tm0 / tpi) * He * We;
-      const float* rb = p.rowbias + (m0 / p.rows_per_batch) * p.ld_rowbias;
-      const int wnb = (c_tile % tiles_n) * BN + wvn * 32 * WTN;
-#pragma unroll
-      for (int j = 0; j < WTN; j++)
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const int n0 = wnb + j * 32 + 8 * g + 4 * half;
-          if (n0 < p.N) {
-            const float4 b4 = *(const float4*)(rb + n0);
-#pragma unroll
-            for (int i = 0; i < WTM; i++) { acc[i][j][4 * g] += b4.x; acc[i][j][4 * g + 1] += b4.y; acc[i][j][4 * g + 2] += b4.z; acc[i][j][4 * g + 3] += b4.w; }
-          }
-        }
-    }
-
-    for (int c = 0; c < nchunks; c++, gc++) {
-      const unsigned stH = lds_base + (gc & 1) * Halo::HALO_BYTES;
-      for (int t = 0; t < 9; t++, gs++) {
-        wait_vmcnt<0>();                  // this stage's weights (and, at t == 0, the whole halo) have landed
-        __builtin_amdgcn_s_barrier();     // ... for every wave; everyone is done with the previous stage's slot
-        // next stage's weights, then one piece of the next chunk's halo (pieces 0..5 ride on taps 0..5)
-        if (l_iter < tiles_all) { issue_b((gs + 1) & 1); advance_b(); }
-        if (t < LH && h_iter < tiles_all) {
-          switch (t) {
-            case 0: issue_halo(std::integral_constant<int, 0>{}); break;
-            case 1: issue_halo(std::integral_constant<int, 1>{}); break;
-            case 2: issue_halo(std::integral_constant<int, 2>{}); break;
-            case 3: issue_halo(std::integral_constant<int, 3>{}); break;
-            case 4: issue_halo(std::integral_constant<int, 4>{}); break;
-            default: issue_halo(std::integral_constant<int, 5>{}); break;
-          }
-          if (t == LH - 1) advance_halo();
-        }
-        const unsigned stB = lds_base + (gs & 1) * Halo::B_BYTES;
-        // A fragment addresses of this tap: halo pixel (y + ky, x + kx)
-        const int toff = (t / 3) * Halo::HW_ + (t % 3);
-        unsigned fa_base[WTM], fa_key[WTM];
-#pragma unroll
-        for (int i = 0; i < WTM; i++) {
-          const int hp = hp0[i] + toff;
-          fa_base[i] = stH + hp * KBYTES;
-          fa_key[i] = swz(hp);
-        }
-        uint4 fa[2][WTM], fb[2][WTN];
-#pragma unroll
-        for (int i = 0; i < WTM; i++) fa[0][i] = lds_read16(fa_base[i] + ((half ^ fa_key[i]) << 4));
-#pragma unroll
-        for (int j = 0; j < WTN; j++) fb[0][j] = lds_read16(stB + fb_off[j][0]);
-        constexpr int NMMA = WTM * WTN, NRD = WTM + WTN;
-        static_for<KSTEPS>([&](auto KK) {
-          constexpr int kk = decltype(KK)::value, cur = kk & 1, nxt = cur ^ 1;
-          wait_lgkmcnt<0>();
-          __builtin_amdgcn_sched_barrier(0);
-          constexpr int n_rd = (kk + 1 < KSTEPS) ? NRD : 0;
-          static_for<NMMA>([&](auto Q) {
-            constexpr int q = decltype(Q)::value, i = q / WTN, j = q % WTN;
-            acc[i][j] = mma16<T>(fb[cur][j], fa[cur][i], acc[i][j]);   // rows = n, lane = m
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (q < n_rd) {
-              if constexpr (q < WTM) fa[nxt][q] = lds_read16(fa_base[q] + ((((kk + 1) * 2 + half) ^ fa_key[q]) << 4));
-              else fb[nxt][q - WTM] = lds_read16(stB + fb_off[q - WTM][kk + 1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          });
-          // (64-channel blocks: 2 MFMAs per k-step carry 2 of the 3 fragment reads of the next one)
-          static_for<(n_rd > NMMA ? n_rd - NMMA : 0)>([&](auto Q) {
-            constexpr int q = decltype(Q)::value + NMMA;
-            if constexpr (q < WTM) fa[nxt][q] = lds_read16(fa_base[q] + ((((kk + 1) * 2 + half) ^ fa_key[q]) << 4));
-            else fb[nxt][q - WTM] = lds_read16(stB + fb_off[q - WTM][kk + 1]);
-          });
-          __builtin_amdgcn_sched_barrier(0);
-        });
-      }
-    }
-
-    // ---- epilogue: MFMA tile row i of this wave = patch rows 2*(wvm*2+i), +1 (16 pixels each)
-    const int tm = c_tile / tiles_n;
-    const int img = tm / tpi, rem = tm % tpi;
-    const int y0 = (rem / tpx) * Halo::PH, x0 = (rem % tpx) * Halo::PW;
-    const int wn0 = (c_tile % tiles_n) * BN + wvn * 32 * WTN;
-    bool staged = false;
-    if constexpr (sizeof(T) == 2) {
-      if (lds_epi) {
-        // the halo buffer of the chunk just finished is free once every wave is past its last tap; the halo loader
-        // rewrites it only behind the next stage's barrier
-        __builtin_amdgcn_s_barrier();
-        // (rows of this wave's tile: patch rows (wvm*WTM + i)*2 + r/16, pixels r%16 - the linear-rows epilogue with a row pitch)
-        const int64_t wm0 = ((int64_t)img * He + y0 + wvm * WTM * 2) * We + x0;
-        const float no_ln[WTM] = {1.f, 1.f};
-        const unsigned xb = lds_base + ((gc + 1) & 1) * Halo::HALO_BYTES;
-        // (bias and the temb row bias are already in the accumulators)
-        if (R != nullptr || p.out_scale != 1.0f)
-          epilogue_lds<T, WTM, WTN, NW, Halo::HALO_BYTES, false, false, true, false, Halo::PW>(acc, pe, wm0, wn0, wave, lane, xb, C, R, no_ln, We);
-        else
-          epilogue_lds<T, WTM, WTN, NW, Halo::HALO_BYTES, false, false, false, false, Halo::PW>(acc, pe, wm0, wn0, wave, lane, xb, C, R, no_ln, We);
-        staged = true;
-      }
-    }
-    if (!staged) {
-#pragma unroll
-      for (int i = 0; i < WTM; i++) {
-        const int y = y0 + (wvm * WTM + i) * 2 + (l31 >> 4), x = x0 + (l31 & 15);
-        const int64_t m = ((int64_t)img * He + y) * We + x;
-        epilogue_row<T, WTN>(acc[i], pe, m, true, wn0, half, C, R);
-      }
-    }
-  }
-}
-
 // split-K second pass: fixed-order reduction of the f32 partials + the same fused epilogue; a thread owns 4 consecutive
 // output columns (N % 4 == 0 is enforced for split-K): 16-byte partial loads, 8/16-byte stores
 template <typename T>
@@ -1496,23 +1210,4 @@ template <typename T> int gemm_run(const emo_gemm_params& p, const GemmPlan& pl,
     EMO_LAUNCH_CHECK();
   }
   return EMO_OK;
-}
-
-template <typename T, int PH_, int BN_> static int launch_halo(const emo_gemm_params& p, int64_t gx, hipStream_t st) {
-  using Halo = HaloT<PH_, BN_>;
-  static bool once = false;
-  if (!once) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_halo_kernel<T, PH_, BN_>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo::LDS_BYTES);
-    if (e != hipSuccess) return emo_fail(EMO_ERR_HIP, "emo_gemm: hipFuncSetAttribute(halo conv): %s", hipGetErrorString(e));
-    once = true;
-  }
-  conv3x3_halo_kernel<T, PH_, BN_><<<(unsigned)gx, 64 * Halo::NW, Halo::LDS_BYTES, st>>>(p);
-  EMO_LAUNCH_CHECK();
-  return EMO_OK;
-}
-
-// bn = output channels per block (128, or 64: the remainder launch of a width that is an odd multiple of 64)
-template <typename T> int gemm_run_halo(const emo_gemm_params& p, int ph, int bn, int64_t gx, hipStream_t st) {
-  if (bn == 64) return ph == 16 ? launch_halo<T, 16, 64>(p, gx, st) : launch_halo<T, 8, 64>(p, gx, st);
-  return ph == 16 ? launch_halo<T, 16, 128>(p, gx, st) : launch_halo<T, 8, 128>(p, gx, st);
 }

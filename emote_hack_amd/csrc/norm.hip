@@ -317,6 +317,62 @@ extern "C" int emo_groupnorm_apply(const void* x, int ldx, const void* partials,
   return EMO_OK;
 }
 
+// The coefficient half of the apply pass for consumers that normalise on the fly (the halo conv, emo_gemm_params.gn_coef): one
+// block per instance runs the SAME statistics prologue as gn_apply_kernel - per column part, TPG lanes per group, strided f64
+// sums + shuffle tree - and writes scale = rstd * gamma, shift = beta - mean * scale, channel pairs interleaved (s, s, b, b).
+__global__ __launch_bounds__(GN_THREADS) void gn_coeffs_kernel(const float* __restrict__ partials, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ coef,
+                                                               int C, int G_all, int NC, int nsplit_stats, double count, float eps) {
+  __shared__ float s_stats[GN_MAXG * 2];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int G = G_all / NC;
+  int TPG = 1;
+  while (TPG * 2 * G <= GN_THREADS && TPG < 64) TPG *= 2;
+  for (int y = 0; y < NC; y++) {
+    const float* pin = partials + ((int64_t)n * nsplit_stats * G_all + (int64_t)y * G) * 2;
+    for (int g0 = 0; g0 < G; g0 += GN_THREADS / TPG) {
+      const int g = g0 + tid / TPG, part = tid % TPG;
+      double a = 0.0, b = 0.0;
+      if (g < G)
+        for (int q = part; q < nsplit_stats; q += TPG) {
+          const float2 pv = *(const float2*)(pin + ((int64_t)q * G_all + g) * 2);
+          a += (double)pv.x; b += (double)pv.y;
+        }
+      for (int d = TPG / 2; d > 0; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+      if (g < G && part == 0) {
+        const double mean = a / count;
+        double var = b / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_stats[2 * (y * G + g)] = (float)mean;
+        s_stats[2 * (y * G + g) + 1] = (float)(1.0 / sqrt(var + (double)eps));
+      }
+    }
+  }
+  __syncthreads();
+  const int cpg = C / G_all;
+  for (int c = tid; c < C; c += GN_THREADS) {
+    const int g = c / cpg;
+    const float mean = s_stats[2 * g], rstd = s_stats[2 * g + 1];
+    const float a = rstd * gamma[c];
+    float* dst = coef + (int64_t)n * 2 * C + (c >> 1) * 4 + (c & 1);
+    dst[0] = a;
+    dst[2] = beta[c] - mean * a;
+  }
+}
+
+extern "C" int emo_groupnorm_coeffs(const void* partials, const float* gamma, const float* beta, float* coef, int N,
+                                    int64_t S, int C, int G, float eps, int dtype, void* stream) {
+  EMO_CHECK(partials && gamma && beta && coef, EMO_ERR_NULL, "emo_groupnorm_coeffs: null pointer");
+  int rc = gn_check("emo_groupnorm_coeffs", N, S, C, G, C, dtype);
+  if (rc) return rc;
+  const GnGeom gg = gn_geom(N, S, C, G, emo_dtype_vec(dtype));
+  const double count = (double)S * (C / G);
+  gn_coeffs_kernel<<<(unsigned)N, GN_THREADS, 0, as_stream(stream)>>>((const float*)partials, gamma, beta, coef, C, G, gg.NC,
+                                                                      gg.nsplit_stats, count, eps);
+  EMO_LAUNCH_CHECK();
+  return EMO_OK;
+}
+
 // ------------------------------------------------------------------------------------------ GroupNorm in one launch
 // Instances small enough that one block holds (instance, slab of whole groups) in registers: one read, statistics through
 // LDS in the same fixed order as the two-pass path (f32 per-thread partials, f64 mean / variance), normalise from the

@@ -196,6 +196,26 @@ def group_norm(x: torch.Tensor, gamma, beta, n_inst: int, groups: int, eps: floa
     return y
 
 
+def group_norm_coeffs(x: torch.Tensor, gamma, beta, n_inst: int, groups: int, eps: float) -> torch.Tensor:
+    """The statistics half of a GroupNorm whose normalisation runs inside its consumer (conv3x3(gn=...)): one read-only pass over x,
+    then the per-(instance, channel) factors (n_inst, 2C) f32, channel pairs interleaved (scale, scale, shift, shift) - emo_hip.h
+    emo_groupnorm_coeffs.  The normalised tensor is never materialised."""
+    _need_cuda(x)
+    lib = _lib.load()
+    M, Cc = x.shape
+    S = M // n_inst
+    px, ldx = _rows(x)
+    part = torch.empty(max(lib.emo_groupnorm_workspace_bytes(n_inst, S, Cc, groups) // 4, 1), device=x.device, dtype=torch.float32)
+    coef = torch.empty(n_inst, 2 * Cc, device=x.device, dtype=torch.float32)
+
+    def run():
+        check(lib.emo_groupnorm_stats(px, ldx, _ptr(part), n_inst, S, Cc, groups, dt(x), _stream()), "emo_groupnorm_stats")
+        check(lib.emo_groupnorm_coeffs(_ptr(part), _ptr(gamma), _ptr(beta), _ptr(coef), n_inst, S, Cc, groups, float(eps), dt(x), _stream()),
+              "emo_groupnorm_coeffs")
+    _launch("groupnorm_stats", 0.0, x.element_size() * 1.0 * M * Cc, run, tag=f"M={M} C={Cc}")   # algorithmic: one read
+    return coef
+
+
 def group_norm_fold_linear(x: torch.Tensor, gamma, beta, n_inst: int, groups: int, eps: float, w: torch.Tensor, bias):
     """GroupNorm (no activation) folded into the Linear / 1x1 conv behind it (emo_hip.h emo_groupnorm_fold_linear): one
     statistics pass over x, then per-instance weights (n_inst, Cout, C) and a per-instance bias (n_inst, Cout) f32 for
@@ -247,13 +267,15 @@ GEMM_TILE = 0   # tuning hook for tools/bench: pins emo_gemm_params.tile of ever
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, geglu=False,
          out_scale=1.0, out=None, transpose_rows=0, transpose_ld=0, conv=None, split_k=None, ln=None, tile=None,
-         w_slab_rows=0) -> torch.Tensor:
+         w_slab_rows=0, gn=None) -> torch.Tensor:
     """out = epilogue(a @ w.T).  a (M, K) rows view; w (N, K) contiguous in the compute dtype.
     ln = (colsum f32 (N,), stats f32 (M, 2) from layer_norm_stats(a)): LayerNorm over K folded into the GEMM - a holds the RAW
     rows, w / bias carry the folded affine (emo_hip.h emo_gemm_params.ln_colsum).
     conv = dict(H, W, Cin, stride, upsample2x, Ho, Wo) selects the implicit 3x3 conv loader (then a is
     the (B*F*H*W, >=Cin) NHWC input and M = B*F*Ho*Wo).
-    transpose_rows=L stores V^T per batch of L rows: out (M/L, N, transpose_ld)."""
+    transpose_rows=L stores V^T per batch of L rows: out (M/L, N, transpose_ld).
+    gn = (coef from group_norm_coeffs(a), images per instance, silu): GroupNorm (+ SiLU) of the conv's input applied inside the
+    halo-reuse 3x3 conv - a holds the RAW rows (emo_hip.h emo_gemm_params.gn_coef; conv_gn_fusable says which convs qualify)."""
     _need_cuda(a, w)
     p = GemmParams()
     pa, lda = _rows(a)
@@ -297,6 +319,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
         p.conv_asym = int(conv.get("asym", 0))
         p.up_h, p.up_w = conv.get("up", (0, 0))
     p.dtype = dt(a)
+    if gn is not None:
+        coef, imgs_per_inst, gn_silu = gn
+        assert conv is not None and coef.dtype == torch.float32 and coef.is_contiguous() and coef.shape[1] == 2 * conv["Cin"], coef.shape
+        p.gn_coef, p.gn_imgs_per_inst, p.gn_silu = coef.data_ptr(), int(imgs_per_inst), int(bool(gn_silu))
+        split_k = 1
     p.tile = int(tile if tile is not None else (GEMM_TILE if conv is None else 0))
     if ln is not None:
         colsum, stats = ln
@@ -316,8 +343,22 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
             lambda: check(_lib.load().emo_gemm(C.byref(p), _stream()), "emo_gemm"),
             tag=f"M={M} N={N} K={K}" + (" geglu" if geglu else "") + (" T" if transpose_rows else "") +
                 (f" s{conv['stride']}{'u' if conv['upsample2x'] else ''}" if conv is not None else "") + (f" sk{sk}" if sk > 1 else "") +
-                (" ln" if ln is not None else "") + (" slab" if w_slab_rows else "") + (" rowbias" if rowbias is not None else ""))
+                (" ln" if ln is not None else "") + (" slab" if w_slab_rows else "") + (" rowbias" if rowbias is not None else "") +
+                (" gn" if gn is not None else ""))
     return out
+
+
+def conv_gn_fusable(x: torch.Tensor, w: torch.Tensor, n_img: int, H: int, W: int, rowbias=None, rows_per_batch=0) -> bool:
+    """Whether the stride-1 3x3 conv of x (n_img*H*W, >= Cin) with the re-laid weight w runs on the halo-reuse kernel, i.e. may take
+    its GroupNorm (+ SiLU) along as conv3x3(gn=...) (emo_hip.h emo_conv3x3_gn_fusable)."""
+    p = GemmParams()
+    _, lda = _rows(x)
+    p.lda, p.M, p.N, p.K = lda, n_img * H * W, w.shape[0], w.shape[1]
+    p.conv_taps, p.H, p.W_, p.Cin, p.stride, p.Ho, p.Wo = 9, H, W, w.shape[1] // 9, 1, H, W
+    p.dtype = dt(x)
+    if rowbias is not None:
+        p.rowbias, p.rows_per_batch, p.ld_rowbias = rowbias.data_ptr(), rows_per_batch, rowbias.stride(0)
+    return bool(_lib.load().emo_conv3x3_gn_fusable(C.byref(p)))
 
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias, n_img: int, H: int, W: int, *, stride=1, upsample2x=False, pad=1, upsample_to=None, **kw):

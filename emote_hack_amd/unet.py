@@ -59,6 +59,11 @@ FUSE_FF_TAIL = True
 # activation) disappears: 81 -> 59 us per norm + proj_in at the 64x64 level, -0.25 ms per step.  Below it the weight copies
 # cost what the pass they replace costs (32x32: 58 vs 58 us; 16x16: 64 vs 46) - tools/bench/gn_fold_bench.py.  0 = off.
 GN_FOLD_MIN_HW = 4096
+# GroupNorm + SiLU in front of a resnet's 3x3 convs (resnet.py:180-183,191-196) applied INSIDE the conv: the halo-reuse kernel
+# normalises each halo chunk in LDS right after its direct-to-LDS load (ops.conv3x3(gn=...)), so the apply pass - one read and one
+# write of the activation per conv - disappears; what remains of the norm is its read-only statistics pass.  Served where the conv
+# runs on the halo kernel (W % 16 == 0); frames smaller than this many pixels keep the one-launch GroupNorm kernel.  0 = off.
+GN_CONV_MIN_HW = 256
 
 
 def ff_tail_weights(w_out, b_out, w2, b2):
@@ -373,14 +378,22 @@ class UNet3DConditionModel:
         w, p = self._w, r.prefix
         G, eps = self.config["norm_num_groups"], self.config["norm_eps"]
         n_img = c.B * c.F
-        h = ops.group_norm(x, w[p + ".norm1.g"], w[p + ".norm1.b"], c.B, G, eps, True)
         off = self._temb_off[p]
-        h, _, _ = ops.conv3x3(h, w[p + ".conv1.w"], w[p + ".conv1.b"], n_img, H, W,
-                              rowbias=temb_all[:, off:off + r.cout], rows_per_batch=c.F * H * W)
-        h = ops.group_norm(h, w[p + ".norm2.g"], w[p + ".norm2.b"], c.B, G, eps, True, out=h)
+        temb = temb_all[:, off:off + r.cout]
+        h = self._norm_act_conv(x, p + ".norm1", p + ".conv1", c, H, W, G, eps, rowbias=temb, rows_per_batch=c.F * H * W)
         sc = ops.gemm(x, w[p + ".sc.w"], w[p + ".sc.b"]) if r.has_shortcut else x
-        out, _, _ = ops.conv3x3(h, w[p + ".conv2.w"], w[p + ".conv2.b"], n_img, H, W, residual=sc, out_scale=1.0 / scale, out=out)
-        return out
+        return self._norm_act_conv(h, p + ".norm2", p + ".conv2", c, H, W, G, eps, inplace=True, residual=sc, out_scale=1.0 / scale, out=out)
+
+    def _norm_act_conv(self, x, norm, conv, c: _Ctx, H, W, G, eps, inplace=False, **kw):
+        """GroupNorm (joint over the F frames of a batch row) -> SiLU -> 3x3 conv (resnet.py:180-183,191-196; unet_controlnet.py:476-477)
+        with the normalisation inside the conv where the halo-reuse kernel serves it (GN_CONV_MIN_HW)."""
+        w = self._w
+        n_img = c.B * c.F
+        if GN_CONV_MIN_HW and H * W >= GN_CONV_MIN_HW and ops.conv_gn_fusable(x, w[conv + ".w"], n_img, H, W, kw.get("rowbias"), kw.get("rows_per_batch", 0)):
+            coef = ops.group_norm_coeffs(x, w[norm + ".g"], w[norm + ".b"], c.B, G, eps)
+            return ops.conv3x3(x, w[conv + ".w"], w[conv + ".b"], n_img, H, W, gn=(coef, c.F, True), **kw)[0]
+        h = ops.group_norm(x, w[norm + ".g"], w[norm + ".b"], c.B, G, eps, True, out=x if inplace else None)
+        return ops.conv3x3(h, w[conv + ".w"], w[conv + ".b"], n_img, H, W, **kw)[0]
 
     def _kv(self, rows, wk, wv, L):
         """K rows and V^T (per batch of L rows) projections of `rows` (nb*L, Cin)."""
@@ -748,8 +761,7 @@ class UNet3DConditionModel:
             rc._finish(c, self)
         if not spec.has_out or x is _STOP:
             return None
-        x = ops.group_norm(x, w["conv_norm_out.g"], w["conv_norm_out.b"], B, cfg["norm_num_groups"], cfg["norm_eps"], True)
-        x, _, _ = ops.conv3x3(x, w["conv_out.w"], w["conv_out.b"], B * F, h_, w_)
+        x = self._norm_act_conv(x, "conv_norm_out", "conv_out", c, h_, w_, cfg["norm_num_groups"], cfg["norm_eps"])
         if return_rows:  # the sampler consumes NHWC rows directly (no layout round trip)
             return x
         return ops.rows_to_ncfhw(x, B, cfg["out_channels"], F, h_, w_)

@@ -87,6 +87,13 @@ int emo_groupnorm_apply(const void* x, int ldx, const void* partials, const floa
                         void* y, int ldy, int N, int64_t S, int C, int G, float eps, int silu, int dtype,
                         void* stream);
 
+/* The coefficient half of emo_groupnorm_apply for consumers that normalise on the fly (emo_gemm_params.gn_coef):
+ * scale_c = rstd_{n,g(c)} * gamma_c, shift_c = beta_c - mean_{n,g(c)} * scale_c from the `partials` of emo_groupnorm_stats with the
+ * same fixed-order f64 combine - bit-identical to the factors emo_groupnorm_apply uses.  coef is f32 [N][2 * C], channel PAIRS
+ * interleaved: coef[n][4 * j ..] = (scale_2j, scale_2j+1, shift_2j, shift_2j+1) - one 16-byte read per packed pair.  C even. */
+int emo_groupnorm_coeffs(const void* partials, const float* gamma, const float* beta, float* coef, int N, int64_t S,
+                         int C, int G, float eps, int dtype, void* stream);
+
 /* The same GroupNorm in ONE launch, for instances small enough that one workgroup holds (instance, slab of whole groups)
  * in registers (<= 32 K elements per workgroup: the 8x8 level and the per-frame 16x16 norms at the bench size): one read of x, statistics in the same fixed
  * order (f32 partials, f64 mean / variance), one write.  emo_groupnorm_one_launch_ok returns 1 when the geometry fits;
@@ -164,8 +171,18 @@ typedef struct {
                       straddles two slabs).  `bias` is then per instance as well: f32 [M / w_slab_rows][N].  0 = one W (and one bias)
                       for every row.  Made by emo_groupnorm_fold_linear (GroupNorm folded into proj_in); row-major output with
                       N % 4 == 0 only, not with the LayerNorm fold, split-K or the conv loader. */
+  /* 3x3 conv only: GroupNorm (+ SiLU) of the conv's INPUT applied inside the conv (resnet.py:180-183,191-196: norm -> nonlinearity ->
+   * conv).  A holds the RAW producer output; gn_coef is the f32 [instances][2 * Cin] table of emo_groupnorm_coeffs
+   * (per channel pair: scale, scale, shift, shift with scale = rstd * gamma, shift = beta - mean * scale), image i of A belongs to
+   * instance i / gn_imgs_per_inst (F for the joint 5-D statistics of the resnets, 1 per frame).  The kernel normalises, activates and rounds each halo chunk in LDS right
+   * after its direct-to-LDS load lands - the same arithmetic, in the same order, as emo_groupnorm_apply followed by the plain conv
+   * (the padding stays zero) - so the normalised tensor is never written to or re-read from HBM.  Served by the halo-reuse kernel
+   * only: emo_conv3x3_gn_fusable(p) says whether a given conv qualifies; emo_gemm returns EMO_ERR_UNSUPPORTED otherwise. */
+  const float* gn_coef; int gn_imgs_per_inst; int gn_silu;
 } emo_gemm_params;
 int emo_gemm(const emo_gemm_params* p, void* stream);
+/* 1 when the conv described by p (gn_* fields ignored) runs on the halo-reuse kernel, i.e. may carry gn_coef */
+int emo_conv3x3_gn_fusable(const emo_gemm_params* p);
 /* heuristic split factor for (M, N, K) and the workspace it needs */
 int emo_gemm_suggest_split_k(int64_t M, int N, int K, int dtype, int geglu, int transpose_out);
 size_t emo_gemm_workspace_bytes(int64_t M, int N, int split_k);

@@ -453,6 +453,54 @@ def test_conv3x3_halo_remainder_launch_is_the_same_conv(dtype, ph, n, H, W, Cin,
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("ph", [8, 16])
+@pytest.mark.parametrize("B,Fr,H,W,Cin,Cout,lda_pad,silu", [(2, 3, 16, 32, 128, 320, 0, True), (1, 2, 16, 16, 64, 64, 64, True), (3, 1, 32, 16, 192, 132, 0, True),
+                                                           (2, 2, 16, 16, 320, 128, 320, False), (1, 13, 16, 16, 64, 192, 0, True)])
+def test_conv3x3_groupnorm_silu_inside_the_conv(dtype, ph, B, Fr, H, W, Cin, Cout, lda_pad, silu):
+    """resnet.py:180-183,191-196 norm -> nonlinearity -> conv with the normalisation INSIDE the halo-reuse conv (emo_gemm_params.gn_coef):
+    the conv reads the RAW rows, each halo chunk is normalised, activated and rounded in LDS behind its direct-to-LDS load - against
+    F.group_norm (statistics joint over the Fr frames of a batch row) -> silu -> conv2d in f32, and against the unfused pair of
+    launches on the same input, which it must reproduce BIT FOR BIT in the 2-byte modes (same factors, same arithmetic, same rounding of the
+    normalised tensor; the padding stays zero).  Both patch heights, the 64-column remainder launch (N = 320, 132, 192), an input
+    that is the left part of a wider buffer (the concat buffers of the up path), several instances, temb row bias + residual."""
+    o = ops()
+    n, G = B * Fr, 32
+    x = q(seeded_randn((n, Cin, H, W), 331) * (1 + torch.arange(Cin)[None, :, None, None] % 5 * 0.3) + 0.4, dtype)
+    g, b = 1 + 0.1 * seeded_randn((Cin,), 336), 0.1 * seeded_randn((Cin,), 337)
+    wt, bias = q(seeded_randn((Cout, Cin, 3, 3), 332) / math.sqrt(9 * Cin), dtype), 0.1 * seeded_randn((Cout,), 333)
+    res = q(seeded_randn((n, Cout, H, W), 334), dtype)
+    rb = seeded_randn((B, Cout), 335)
+    xn = F.group_norm(x.reshape(B, Fr, Cin, H, W).permute(0, 2, 1, 3, 4), G, g, b, 1e-5).permute(0, 2, 1, 3, 4).reshape(n, Cin, H, W)
+    if silu:
+        xn = F.silu(xn)
+    ref = F.conv2d(xn, wt, bias, padding=1) + rb.repeat_interleave(Fr, 0)[:, :, None, None] + res
+    wide = torch.zeros(n * H * W, Cin + lda_pad, device=DEV, dtype=dtype)
+    wide[:, :Cin] = x.permute(0, 2, 3, 1).reshape(-1, Cin).to(DEV).to(dtype)
+    if lda_pad:
+        wide[:, Cin:] = 7.0          # the neighbour's columns must not leak into the statistics or the halo
+    rows = wide[:, :Cin]
+    wp = wt.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).to(DEV).to(dtype).contiguous()
+    rrows = res.permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().to(DEV).to(dtype)
+    gd, bd = g.to(DEV), b.to(DEV)
+    kw = dict(rowbias=rb.to(DEV), rows_per_batch=Fr * H * W, residual=rrows, split_k=1, tile=1 if ph == 8 else 2)
+    assert o.conv_gn_fusable(rows, wp, n, H, W, kw["rowbias"], kw["rows_per_batch"])
+    coef = o.group_norm_coeffs(rows, gd, bd, B, G, 1e-5)
+    assert tuple(coef.shape) == (B, 2 * Cin)
+    got, _, _ = o.conv3x3(rows, wp, bias.to(DEV), n, H, W, gn=(coef, Fr, silu), **kw)
+    close(got, ref.permute(0, 2, 3, 1).reshape(-1, Cout), dtype, scale=2.0)
+    two, _, _ = o.conv3x3(o.group_norm(rows, gd, bd, B, G, 1e-5, silu), wp, bias.to(DEV), n, H, W, **kw)
+    if dtype == torch.float32:
+        close(got, two.float().cpu(), dtype)
+    else:
+        assert torch.equal(got, two)
+    # a conv the halo kernel does not serve refuses the fusion instead of ignoring it
+    from emote_hack_amd._lib import EmoHipError
+    assert not o.conv_gn_fusable(rows, wp, n * (W // 8), H, 8)          # 8-pixel rows: the im2col loader
+    with pytest.raises(EmoHipError):
+        o.conv3x3(rows, wp, bias.to(DEV), n * (W // 8), H, 8, gn=(coef, Fr * (W // 8), silu), split_k=1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ph", [8, 16])
 @pytest.mark.parametrize("n,H,W,Cin,Cout", [(3, 8, 8, 128, 192), (2, 16, 8, 64, 320), (5, 4, 16, 192, 132)])
 def test_conv3x3_halo_upsample(dtype, ph, n, H, W, Cin, Cout):
     """Upsample3D (resnet.py:74-82: F.interpolate(scale_factor=2, mode="nearest") -> conv 3x3) on the halo-reuse kernel: the

@@ -22,7 +22,7 @@ done
 wait
 L=emote_hack_amd/lib
 OBJS=""
-for o in elementwise norm gemm gemm_f32 gemm_bf16 gemm_f16 attention temporal conditioning frontend; do
+for o in elementwise norm gemm gemm_f32 gemm_bf16 gemm_f16 conv_halo_f32 conv_halo_bf16 conv_halo_f16 attention temporal conditioning frontend; do
   if [[ " $TUS " == *" $o "* ]]; then OBJS="$OBJS /tmp/emo_variant_${N}_$o.o"; else OBJS="$OBJS $L/$o.o"; fi
 done
 mkdir -p $L/variants
