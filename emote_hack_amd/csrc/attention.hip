@@ -411,10 +411,26 @@ __global__ __launch_bounds__(ATT_THREADS, (QT == 2 ? 2 : (DCH <= 6 ? 3 : (DCH <=
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
         mx = max2f(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
       }
-      const float m_new = max2f(m_run[t], mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run[t] - m_new) * c_exp);   // raw v_exp_f32: arguments are <= 0, no denormal care
-      m_run[t] = m_new;
-      const float m_sc = m_new * c_exp;
+      // THRESHOLDED online softmax: the running reference m_run of a query row moves only when the tile's maximum exceeds it by
+      // more than ATT_TAU in log2 units.  Any reference common to all of a row's terms gives the same quotient O / l, so this is
+      // exact; what it bounds is the size of the probabilities, P <= 2^ATT_TAU = 256 (bf16 / f16 round P relatively, and the sums
+      // are f32).  With "moves whenever the maximum grows at all" one of a wave's 32 rows moved in about every second interior
+      // tile - 32 multiplies of the O accumulators, an exponential and the ballot on an issue-bound kernel; now the branch is
+      // taken in a row's first tile(s) and practically never again.
+      constexpr float ATT_TAU = 8.0f;
+      const float m_old = m_run[t];
+      const bool grow = (mx - m_old) * c_exp > ATT_TAU;
+      float alpha = 1.0f;
+      if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+        const float m_new = grow ? mx : m_old;
+        alpha = __builtin_amdgcn_exp2f((m_old - m_new) * c_exp);   // raw v_exp_f32: arguments are <= 0, no denormal care
+        m_run[t] = m_new;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) o[t][nt][r] *= alpha;
+      }
+      const float m_sc = m_run[t] * c_exp;
       float p0[16], p1[16];
       {
         const v2f cc = {c_exp, c_exp}, mm = {m_sc, m_sc};
@@ -431,12 +447,6 @@ __global__ __launch_bounds__(ATT_THREADS, (QT == 2 ? 2 : (DCH <= 6 ? 3 : (DCH <=
 #pragma unroll
         for (int r = 0; r < 16; r++) psum += p0[r] + p1[r];
         l_run[t] = l_run[t] * alpha + psum;
-      }
-      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // skip the O rescale when no lane's max moved
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) o[t][nt][r] *= alpha;
       }
 #pragma unroll
       for (int sp = 0; sp < STEPS; sp++) {
