@@ -7,11 +7,31 @@ __device__ __forceinline__ void lds_write16(unsigned addr, const uint4& v) {
   const u32x4_t x = {v.x, v.y, v.z, v.w};
   asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(x) : "memory");
 }
-// one packed 32-bit word of two 2-byte elements -> f32
-template <typename T> __device__ __forceinline__ void unpack2(unsigned w, float& lo, float& hi) {
-  float o[4];
-  unpack4<T>(make_uint2(w, 0u), o);
-  lo = o[0]; hi = o[1];
+// The LDS reads of this file are inline asm with hand-counted lgkmcnt waits, and hipcc knows nothing of the latency between the two:
+// a compiler-generated instruction that consumes a read's result - or a register COPY of it, which the allocator is free to insert
+// right behind the read - may land in front of the s_waitcnt asm (it depends on the read, not on the wait) and then works on whatever
+// the registers held (seen: v_mov of a ds_read's output three instructions ahead of its wait - profiles/r05*_gn_conv.txt).  Two
+// shapes are safe and used below: (a) read and wait in ONE asm statement, for code off the critical path; (b) the first consumers of
+// an early read are themselves asm volatile statements taking the registers as plain inputs - volatile asms keep their order, so
+// they sit behind the wait, and an input operand needs no copy.
+__device__ __forceinline__ uint4 lds_read16_sync(unsigned addr) {
+  uint4 v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr));
+  return v;
+}
+// (b): x0, x1 = the two elements of packed word w as f32; t = x * a + b (one correctly rounded fma, like the compiler's contraction)
+template <typename T> __device__ __forceinline__ void unpack2_asm(unsigned w, float& x0, float& x1);
+template <> __device__ __forceinline__ void unpack2_asm<bf16_t>(unsigned w, float& x0, float& x1) {
+  asm volatile("v_lshlrev_b32 %0, 16, %2\n\tv_and_b32 %1, 0xffff0000, %2" : "=&v"(x0), "=&v"(x1) : "v"(w));
+}
+template <> __device__ __forceinline__ void unpack2_asm<f16_t>(unsigned w, float& x0, float& x1) {
+  asm volatile("v_cvt_f32_f16 %0, %2\n\tv_lshrrev_b32 %1, 16, %2\n\tv_cvt_f32_f16 %1, %1" : "=&v"(x0), "=&v"(x1) : "v"(w));
+}
+template <> __device__ __forceinline__ void unpack2_asm<float>(unsigned w, float& x0, float& x1) { x0 = __uint_as_float(w); x1 = 0.f; }
+__device__ __forceinline__ float fma_asm(float x, unsigned a, unsigned b) {
+  float t;
+  asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(x), "v"(a), "v"(b));
+  return t;
 }
 
 // ------------------------------------------------------------------------------------------ 3x3 conv, halo reuse
@@ -148,21 +168,18 @@ __global__ __launch_bounds__(32 * PH_, 2) void conv3x3_halo_kernel(const emo_gem
   // one whole slot at once (stream prologue and the f32 validation mode): the arithmetic of gn_apply_kernel, element by element
   auto gn_slot_now = [&](int i, unsigned buf) {
     const unsigned a = lds_base + buf * Halo::HALO_BYTES + (i * NW + wave) * 1024 + lane * 16;
-    uint4 v = lds_read16(a);
-    wait_lgkmcnt<0>();
+    uint4 v = lds_read16_sync(a);
     float f[V];
     unpack16<T>(v, f);
     static_for<V / 2>([&](auto J) {
       constexpr int j = decltype(J)::value;
-      const uint4 c = lds_read16(g_caddr + j * 16);
-      wait_lgkmcnt<0>();
+      const uint4 c = lds_read16_sync(g_caddr + j * 16);
       const float t0 = f[2 * j] * __uint_as_float(c.x) + __uint_as_float(c.z), t1 = f[2 * j + 1] * __uint_as_float(c.y) + __uint_as_float(c.w);
       f[2 * j] = gn_silu ? silu_f(t0) : t0;
       f[2 * j + 1] = gn_silu ? silu_f(t1) : t1;
     });
     const uint4 o = pack16<T>(f);
-    if ((g_ok >> i) & 1) v = o;
-    lds_write16(a, v);
+    lds_write16(a, ((g_ok >> i) & 1) ? o : make_uint4(0, 0, 0, 0));   // (the slot of a pad pixel holds zeros and keeps them)
   };
   auto advance_halo = [&]() {   // after the last piece of a chunk
     h_count++;
@@ -309,7 +326,7 @@ __global__ __launch_bounds__(32 * PH_, 2) void conv3x3_halo_kernel(const emo_gem
         auto ksteps = [&](auto GT) {
           constexpr bool G_ = decltype(GT)::value;
           uint4 fa[2][WTM], fb[2][WTN];
-          uint4 g_v = make_uint4(0, 0, 0, 0), g_q[2];
+          uint4 g_v = make_uint4(0, 0, 0, 0), g_o = make_uint4(0, 0, 0, 0), g_q[2];
           float g_t0 = 0.f, g_t1 = 0.f, g_e0 = 0.f, g_e1 = 0.f;
           if constexpr (G_) { g_v = lds_read16(g_addr); g_q[0] = lds_read16(g_caddr); }
 #pragma unroll
@@ -321,12 +338,13 @@ __global__ __launch_bounds__(32 * PH_, 2) void conv3x3_halo_kernel(const emo_gem
             constexpr int kk = decltype(KK)::value, st = decltype(ST)::value;
             if constexpr (G_ && sizeof(T) == 2) {
               if constexpr (st == 0) {
+                // (asm: the first consumers of g_v / g_q - read before the k-step's lgkmcnt wait - must not be movable in front of it)
                 const unsigned w = kk == 0 ? g_v.x : kk == 1 ? g_v.y : kk == 2 ? g_v.z : g_v.w;
                 float x0, x1;
-                unpack2<T>(w, x0, x1);
+                unpack2_asm<T>(w, x0, x1);
                 const uint4& c = g_q[kk & 1];
-                g_t0 = x0 * __uint_as_float(c.x) + __uint_as_float(c.z);
-                g_t1 = x1 * __uint_as_float(c.y) + __uint_as_float(c.w);
+                g_t0 = fma_asm(x0, c.x, c.z);
+                g_t1 = fma_asm(x1, c.y, c.w);
                 // (pure VALU code has no place of its own in the instruction stream - hipcc's DAG linearisation gathers all of it
                 // behind the k-step's last MFMA, where it waits out four back-to-back MFMA issues; an empty asm with the stage's
                 // results as operands keeps every quarter behind ITS MFMA, in the issue slots the matrix pipe leaves free)
@@ -341,10 +359,9 @@ __global__ __launch_bounds__(32 * PH_, 2) void conv3x3_halo_kernel(const emo_gem
                 asm volatile("" : "+v"(g_e0), "+v"(g_e1));
               } else {
                 const float o0 = gn_silu ? g_t0 * g_e0 : g_t0, o1 = gn_silu ? g_t1 * g_e1 : g_t1;
-                const unsigned w = kk == 0 ? g_v.x : kk == 1 ? g_v.y : kk == 2 ? g_v.z : g_v.w;
-                unsigned r = g_valid ? pack2<T>(o0, o1) : w;
+                unsigned r = g_valid ? pack2<T>(o0, o1) : 0u;     // (the slot of a pad pixel holds zeros and keeps them)
                 asm volatile("" : "+v"(r));
-                if constexpr (kk == 0) g_v.x = r; else if constexpr (kk == 1) g_v.y = r; else if constexpr (kk == 2) g_v.z = r; else g_v.w = r;
+                if constexpr (kk == 0) g_o.x = r; else if constexpr (kk == 1) g_o.y = r; else if constexpr (kk == 2) g_o.z = r; else g_o.w = r;
               }
             }
           };
@@ -373,7 +390,7 @@ __global__ __launch_bounds__(32 * PH_, 2) void conv3x3_halo_kernel(const emo_gem
             });
             __builtin_amdgcn_sched_barrier(0);
           });
-          if constexpr (G_) lds_write16(g_addr, g_v);   // (complete behind the next tap's first lgkmcnt(0), two barriers before it is read)
+          if constexpr (G_) lds_write16(g_addr, g_o);   // (complete behind the next tap's first lgkmcnt(0), two barriers before it is read)
         };
         if (g_do) ksteps(std::true_type{});
         else ksteps(std::false_type{});

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
     for (int e = 0; e < V; e++) {
       const int g = (cv * V + e) / cpg;
       const float mean = s_stats[2 * g], rstd = s_stats[2 * g + 1];
-      a[e] = rstd * gm[e]; b[e] = bt[e] - mean * a[e];
+      a[e] = rstd * gm[e]; b[e] = fmaf(-mean, a[e], bt[e]);
     }
     while (have) {   // the next 4 rows are requested before the current 4 are normalised and stored
       const int64_t sn = s + 4 * RP;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
       for (int e = 0; e < V; e++) {
         int c = cv * V + e, g = c / cpg;
         float mean = s_stats[2 * g], rstd = s_stats[2 * g + 1];
-        a[e] = rstd * gamma[c]; b[e] = beta[c] - mean * a[e];
+        a[e] = rstd * gamma[c]; b[e] = fmaf(-mean, a[e], beta[c]);
       }
       for (int64_t s = s0; s < s1; s++) {
         float f[V];
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_coeffs_kernel(const float* __re
     const float a = rstd * gamma[c];
     float* dst = coef + (int64_t)n * 2 * C + (c >> 1) * 4 + (c & 1);
     dst[0] = a;
-    dst[2] = beta[c] - mean * a;
+    dst[2] = fmaf(-mean, a, beta[c]);   // (the very expression of the apply kernels: one fma, whatever the compiler would contract)
   }
 }
 
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(GN1_MAXT) void gn_one_kernel(const T* __restrict__ 
     for (int e = 0; e < V; e++) {
       const int g = (cv * V + e) / cpg;
       const float mean = s_stats[2 * g], rstd = s_stats[2 * g + 1];
-      a[e] = rstd * gm[e]; b[e] = bt[e] - mean * a[e];
+      a[e] = rstd * gm[e]; b[e] = fmaf(-mean, a[e], bt[e]);
     }
   }
 #pragma unroll

@@ -41,6 +41,10 @@ class AnimationPipelineOutput:  # EMOAnimationPipeline.py:79-81
     videos: Union[torch.Tensor, "object"]
 
 
+def _default(v, d):
+    return d if v is None else v
+
+
 class EMOAnimationPipeline:
     def __init__(self, vae=None, text_encoder=None, tokenizer=None, unet=None, controlnet=None, scheduler=None):
         """EMOAnimationPipeline.py:87-130.  The ctor forces steps_offset=1 / clip_sample=False on the
@@ -121,7 +125,8 @@ class EMOAnimationPipeline:
         st.reader = ReferenceAttentionControl(unet, do_classifier_free_guidance=cfg, mode="read", batch_size=cbs,
                                               fusion_blocks=fusion_blocks)                        # :634
         st.num_inference_steps = num_inference_steps
-        st.timesteps = sch.set_timesteps(num_inference_steps)
+        st.scheduler = sch
+        st.timesteps = list(sch.set_timesteps(num_inference_steps))
         n_steps = len(st.timesteps)
         # ReferenceNet images = [reference, motion frames] (Net.py:56-72 intent; junk/EMo-write-up.txt:104-110)
         st.n_ref_images = 1 + (0 if motion_latents is None else self._motion_rows(motion_latents).shape[0])
@@ -595,7 +600,9 @@ class EMOAnimationPipeline:
             import torch.distributed as td
             td.all_gather_into_tensor(st.recv.view(-1), st.send.view(-1))
         self._accumulate_all(st)
-        c_x, c_eps, c_n = sch.coefficients(t, st.eta) if isinstance(sch, DDIMScheduler) else sch.coefficients(t)
+        # (the state's own scheduler object and step count: `self.scheduler` may have been replaced or re-timed since the plan was made)
+        sch = st.scheduler
+        c_x, c_eps, c_n = sch.coefficients(t, st.eta if isinstance(sch, DDIMScheduler) else None, st.num_inference_steps)
         eps_out = torch.empty(st.C4 * st.f_tot * st.HW, device=dev, dtype=torch.float32) if st.return_eps else None
         ops.cfg_step(st.noise_pred, st.counter, st.latents, C_=st.C4, F=st.f_tot, HW=st.HW, guidance_scale=st.guidance_scale,
                      c_x=c_x, c_eps=c_eps, c_noise=c_n, seed=st.seed, step=si, eps_out=eps_out)  # :812-817 fused
@@ -627,7 +634,10 @@ class EMOAnimationPipeline:
         if cached is not None and cached[0] == key:
             st = cached[1]
             bind = {k: kw[k] for k in ("audio_features", "speed_embeddings", "motion_latents", "controlnet_cond",
-                                       "controlnet_conditioning_scale", "guidance_scale", "eta", "seed") if kw.get(k) is not None}
+                                       "controlnet_conditioning_scale") if kw.get(k) is not None}
+            # an omitted guidance_scale / eta / seed means the documented DEFAULT, not "what the previous clip used" (they are not
+            # part of the plan key, so the hit happens either way; "None = keep" is reset_denoise's contract, not this one's)
+            bind.update(guidance_scale=_default(kw.get("guidance_scale"), 7.5), eta=_default(kw.get("eta"), 0.0), seed=_default(kw.get("seed"), 0))
             self._bind_inputs(st, latents, ref_image_latents, text_embeddings, **bind)
         else:
             self._plan_cache = None          # drop the old graphs before the new plan allocates
@@ -636,6 +646,10 @@ class EMOAnimationPipeline:
         res = self._run_loop(st, num_actual_inference_steps, callback, callback_steps)
         # (the state's latents are overwritten by the next clip)
         return (res[0].clone(), list(res[1])) if isinstance(res, tuple) else res.clone()
+
+    def clear_plan_cache(self):
+        """Release the prepared state `denoise(reuse_state=True)` / `__call__` keep (buffers, captured HIP graphs, bank cache)."""
+        self._plan_cache = None
 
     def _plan_key(self, latents, ref_image_latents, text_embeddings, kw):
         """Everything a prepared state's PLAN depends on (prepare_denoise above `_bind_inputs`): tensor shapes, the settings that
@@ -647,13 +661,22 @@ class EMOAnimationPipeline:
 
         def wid(m):   # a re-pack (load_state_dict / .to) builds a new dict of packed tensors: captured graphs are stale
             return None if m is None else (id(m), id(getattr(m, "_w", None)), str(getattr(m, "dtype", None)))
+        def sched_id(s):   # the scheduler OBJECT the state steps with and everything its tables depend on
+            c = s.config
+            return (id(s), type(s).__name__, c.num_train_timesteps, c.beta_start, c.beta_end, c.beta_schedule, c.steps_offset, c.set_alpha_to_one)
+
+        def pg_id():       # a state prepared with dist=True holds communicators of the default group it was made under
+            if not kw.get("dist"):
+                return None
+            import torch.distributed as td
+            return id(td.distributed_c10d._get_default_group()) if td.is_initialized() else None
         plan = {k: v for k, v in kw.items() if k not in ("audio_features", "speed_embeddings", "motion_latents", "controlnet_cond",
                                                             "controlnet_conditioning_scale", "guidance_scale", "eta", "seed",
                                                             "appearance_encoder", "controlnet")}
         return (shp(latents), shp(ref_image_latents), shp(text_embeddings), shp(kw.get("audio_features")), shp(kw.get("speed_embeddings")),
                 shp(kw.get("motion_latents")), shp(kw.get("controlnet_cond")), kw.get("controlnet_conditioning_scale", 1.0),
                 self._do_cfg(kw.get("guidance_scale", 7.5)), wid(self.unet), wid(kw.get("appearance_encoder")), wid(kw.get("controlnet")),
-                type(self.scheduler).__name__, unet_mod.SHARE_CFG_PREFIX, unet_mod.GN_FOLD_MIN_HW,
+                sched_id(self.scheduler), pg_id(), unet_mod.SHARE_CFG_PREFIX, unet_mod.GN_FOLD_MIN_HW, unet_mod.GN_CONV_MIN_HW,
                 tuple(sorted((k, repr(v)) for k, v in plan.items())))
 
     def reset_denoise(self, st, latents, motion_latents=None, **inputs):

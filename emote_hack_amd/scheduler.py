@@ -53,8 +53,11 @@ class _SchedulerBase:
     def scale_model_input(self, sample, timestep=None):
         return sample
 
-    def _alphas(self, t):
-        prev_t = t - self.config.num_train_timesteps // self.num_inference_steps
+    def _alphas(self, t, num_inference_steps=None):
+        # (a prepared loop state passes ITS step count: the scheduler object is shared, and another prepare_denoise /
+        # set_timesteps in between must not change the coefficients of a state that is still being stepped)
+        n = self.num_inference_steps if num_inference_steps is None else num_inference_steps
+        prev_t = t - self.config.num_train_timesteps // n
         a_t = float(self.alphas_cumprod[t])
         a_prev = float(self.alphas_cumprod[prev_t]) if prev_t >= 0 else self._final_alpha()
         return a_t, a_prev
@@ -70,9 +73,9 @@ class DDIMScheduler(_SchedulerBase):
     def _final_alpha(self):
         return self.final_alpha_cumprod
 
-    def coefficients(self, t, eta=None):
+    def coefficients(self, t, eta=None, num_inference_steps=None):
         eta = self.eta if eta is None else eta
-        a_t, a_prev = self._alphas(t)
+        a_t, a_prev = self._alphas(t, num_inference_steps)
         var = (1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev)
         std = eta * math.sqrt(max(var, 0.0))
         c_x = math.sqrt(a_prev / a_t)
@@ -84,8 +87,8 @@ class DDPMScheduler(_SchedulerBase):
     def _final_alpha(self):
         return 1.0
 
-    def coefficients(self, t, eta=None):
-        a_t, a_prev = self._alphas(t)
+    def coefficients(self, t, eta=None, num_inference_steps=None):
+        a_t, a_prev = self._alphas(t, num_inference_steps)
         cur_alpha = a_t / a_prev
         cur_beta = 1 - cur_alpha
         k0 = math.sqrt(a_prev) * cur_beta / (1 - a_t)       # coefficient of x0 (Eq. 7)

@@ -63,7 +63,7 @@ GN_FOLD_MIN_HW = 4096
 # normalises each halo chunk in LDS right after its direct-to-LDS load (ops.conv3x3(gn=...)), so the apply pass - one read and one
 # write of the activation per conv - disappears; what remains of the norm is its read-only statistics pass.  Served where the conv
 # runs on the halo kernel (W % 16 == 0); frames smaller than this many pixels keep the one-launch GroupNorm kernel.  0 = off.
-GN_CONV_MIN_HW = 256
+GN_CONV_MIN_HW = 0
 
 
 def ff_tail_weights(w_out, b_out, w2, b2):

@@ -89,3 +89,42 @@ def test_text_pairing_by_branch_makes_window_batching_neutral():
     assert (two_literal - one).abs().max() > 1e-3
     with pytest.raises(ValueError, match="text_pairing"):
         pipe.prepare_denoise(*a, text_pairing="both", **kw)
+
+
+def test_a_plan_keeps_its_own_step_count_and_scheduler():
+    """A non-reuse call with another step count between two uses of a cached plan re-times the SHARED scheduler object; the cached
+    state must keep stepping with ITS coefficients (its own step count and scheduler object).  A replaced scheduler - same class -
+    is another plan."""
+    from emote_hack_amd import DDIMScheduler
+    from emote_hack_amd.synth import seeded_randn
+    pipe, ref = _pipe()
+    kw = dict(appearance_encoder=ref, context_frames=4, context_stride=1, context_overlap=0, reference_group=1)
+    a = (seeded_randn((1, 4, 4, 8, 8), 5), seeded_randn((1, 4, 8, 8), 3), seeded_randn((2, 5, 32), 2))
+    first = pipe.denoise(*a, reuse_state=True, num_inference_steps=4, **kw)
+    st = pipe._plan_cache[1]
+    pipe.denoise(*a, num_inference_steps=2, **kw)                       # leaves scheduler.num_inference_steps == 2
+    assert pipe.scheduler.num_inference_steps == 2
+    again = pipe.denoise(*a, reuse_state=True, num_inference_steps=4, **kw)
+    assert pipe._plan_cache[1] is st and torch.equal(again, first)
+    # a state stepped by hand after the scheduler moved on
+    st2 = pipe.prepare_denoise(*a, num_inference_steps=4, **kw)
+    pipe.prepare_denoise(*a, num_inference_steps=2, **kw)
+    assert torch.equal(pipe._run_loop(st2), first)
+    pipe.scheduler = DDIMScheduler()                                     # same class, new object: not the cached plan's scheduler
+    pipe.denoise(*a, reuse_state=True, num_inference_steps=4, **kw)
+    assert pipe._plan_cache[1] is not st
+    pipe.clear_plan_cache()
+    assert pipe._plan_cache is None
+
+
+def test_omitted_guidance_eta_seed_mean_their_defaults_on_a_cache_hit():
+    from emote_hack_amd.synth import seeded_randn
+    pipe, ref = _pipe()
+    kw = dict(appearance_encoder=ref, num_inference_steps=2, context_frames=4, context_stride=1, context_overlap=0, reference_group=1)
+    a = (seeded_randn((1, 4, 4, 8, 8), 5), seeded_randn((1, 4, 8, 8), 3), seeded_randn((2, 5, 32), 2))
+    fresh = pipe.denoise(*a, **kw)                                       # guidance 7.5, eta 0, seed 0
+    pipe.denoise(*a, reuse_state=True, guidance_scale=3.0, seed=5, eta=0.5, **kw)
+    st = pipe._plan_cache[1]
+    out = pipe.denoise(*a, reuse_state=True, **kw)
+    assert pipe._plan_cache[1] is st and (st.guidance_scale, st.eta, st.seed) == (7.5, 0.0, 0)
+    assert torch.equal(out, fresh)

@@ -9,11 +9,11 @@ for i in 1 2; do
 python bench.py --no-cpu-baseline --no-profile > $O/b_fused_$i.json 2>$O/err_fused_$i.txt
 python bench.py --no-cpu-baseline --no-profile --gn-conv-min-hw 0 > $O/b_unfused_$i.json 2>$O/err_unfused_$i.txt
 python bench.py --no-cpu-baseline --no-profile --gn-conv-min-hw 1024 > $O/b_fused1024_$i.json 2>$O/err_f1024_$i.txt
-(cd tools/bench/_r04_tree && python bench.py --no-cpu-baseline --no-profile > ../../../$O/b_r04_$i.json 2>../../../$O/err_r04_$i.txt)
+(cd tools/bench/_r04_tree && EMO_HIP_LIB=$PWD/../../../emote_hack_amd/lib/variants/r04z.so python bench.py --no-cpu-baseline --no-profile > ../../../$O/b_r04_$i.json 2>../../../$O/err_r04_$i.txt)
 done
 EMO_BENCH_SHAPES=$O/shapes.md python bench.py --no-cpu-baseline > $O/bench.json 2>$O/bench.err
 EMO_BENCH_SHAPES=$O/shapes_unfused.md python bench.py --no-cpu-baseline --gn-conv-min-hw 0 > $O/bench_unfused.json 2>>$O/bench.err
-(cd tools/bench/_r04_tree && EMO_BENCH_SHAPES=../../../$O/shapes_r04.md python bench.py --no-cpu-baseline > ../../../$O/bench_r04.json 2>>../../../$O/bench.err)
+(cd tools/bench/_r04_tree && EMO_HIP_LIB=$PWD/../../../emote_hack_amd/lib/variants/r04z.so EMO_BENCH_SHAPES=../../../$O/shapes_r04.md python bench.py --no-cpu-baseline > ../../../$O/bench_r04.json 2>>../../../$O/bench.err)
 python - $O <<'PY'
 import json,glob,sys
 O=sys.argv[1]
