@@ -48,6 +48,18 @@ NUM_INFERENCE_STEPS = 50
 REF_GROUP = 10
 # algorithmic TFLOP per UNet forward at cfg2 (cond with ReferenceNet K/V, uncond, ReferenceNet image)
 TFLOP_COND, TFLOP_UNCOND, TFLOP_REFNET = 14.319, 13.251, 0.803
+# BASELINE.json configs (SURVEY.md 8d for the FLOP figures): latent size, frames per window, compute dtype, per-frame audio context,
+# speed-layer embeddings, algorithmic TFLOP per (cond, uncond, ReferenceNet image) forward
+CONFIGS = {
+    "cfg2": dict(hw=64, f_win=12, dtype="bf16", audio=False, speed=False, tflop=(14.319, 13.251, 0.803),
+                 name="cfg2 (BASELINE configs[1]): 512x512 latents 64x64, 12-frame window per GPU"),
+    # (the 5-token audio context replaces the 77-token text context of the cond units' attn2: ~0.07 TFLOP less per forward; priced at the cfg2 figure)
+    "cfg3": dict(hw=64, f_win=12, dtype="bf16", audio=True, speed=False, tflop=(14.319, 13.251, 0.803),
+                 name="cfg3 (BASELINE configs[2]): cfg2 + per-frame wav2vec audio tokens (5 x 768) as the attn2 context of the cond units (train_stage_2 path)"),
+    "cfg5": dict(hw=96, f_win=24, dtype="f16", audio=True, speed=True, tflop=(77.394, 67.625, 2.148),
+                 name="cfg5 (BASELINE configs[4]): 768x768 latents 96x96, 24-frame window per GPU, fp16, speed-layer embedding + per-frame audio "
+                      "context (train_stage_3 path)"),
+}
 
 
 def build_models(dev, dtype):
@@ -289,7 +301,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"])
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f32", "f16"], help="compute dtype (default: the config's - bf16, cfg5 fp16)")
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS), help="BASELINE.json configuration: cfg2 (the headline metric), cfg3 (+ audio "
+                    "context), cfg5 (768x768 x 24 frames, fp16, speed + audio)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event instrumentation pass")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel from Python instead of replaying HIP graphs")
@@ -314,9 +328,13 @@ def main():
     ap.add_argument("--controlnet", action="store_true",
                     help="the loop with the ControlNet branch on (EMOAnimationPipeline.py:718-746, SURVEY 8f row 1): SD-1.5-sized "
                          "ControlNetModel on 512x512 conditioning images, residuals cached per frame and step")
-    ap.add_argument("--cpu-baseline-full", action="store_true",
-                    help="cpu_baseline from ONE full 12-frame cfg2 uncond forward of the oracle (BASELINE.md section 4) instead of the "
-                         "2-frame sample scaled x6: minutes of CPU time")
+    ap.add_argument("--cpu-baseline-sample", action="store_true",
+                    help="cpu_baseline from a 2-frame forward scaled x6 (~25 s of CPU time) instead of the default: ONE full 12-frame cfg2 uncond "
+                         "forward of the oracle (BASELINE.md section 4; ~60 s in all)")
+    ap.add_argument("--emulate-rank", default=None, metavar="R/N",
+                    help="MEASUREMENT aid on one GPU: time the work of rank R of an N-rank job (its units, its share of every ReferenceNet group, the "
+                         "projection of the whole group) without collectives - a rank's critical path per step, i.e. what N GPUs would give if the "
+                         "exchanges were free.  e.g. --mode strong --emulate-rank 4/8 = one cond unit of BASELINE configs[3].  NOT a multi-GPU number")
     ap.add_argument("--share-gpu", action="store_true", help="validation on a 1-GPU box: every rank on cuda:0, exchange through gloo "
                                                              "(RCCL takes one device per rank) - the number is NOT a multi-GPU measurement")
     a = ap.parse_args()
@@ -353,7 +371,10 @@ def main():
     from emote_hack_amd.pipeline import EMOAnimationPipeline
     from emote_hack_amd.synth import seeded_randn
 
+    cfg = CONFIGS[a.config]
+    a.dtype = a.dtype or cfg["dtype"]
     dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[a.dtype]
+    T_COND, T_UNCOND, T_REF = cfg["tflop"]
     if a.no_ln_fold:
         from emote_hack_amd import unet as unet_mod
         unet_mod.FOLD_LAYERNORM = False
@@ -375,8 +396,20 @@ def main():
     if a.stage == "vae":
         return bench_vae(a, dev, dtype)
     unet, ref = build_models(dev, dtype)
-    F_WIN = 12
-    f_tot = F_WIN * world if a.mode == "weak" else 4 * F_WIN       # strong: BASELINE configs[3] - 48 frames = 4 windows
+    F_WIN, HW_LAT = cfg["f_win"], cfg["hw"]
+    emu = None
+    if a.emulate_rank:
+        emu = tuple(int(v) for v in a.emulate_rank.split("/"))
+        if world != 1 or not 0 <= emu[0] < emu[1]:
+            raise SystemExit("--emulate-rank R/N runs in ONE process (--gpus 1), 0 <= R < N")
+    f_tot = F_WIN * (emu[1] if emu else world) if a.mode == "weak" else 4 * F_WIN       # strong: BASELINE configs[3] - 48 frames = 4 windows
+    if a.config != "cfg2" and (a.entry != "step" or a.controlnet or a.mode != "weak"):
+        raise SystemExit("--config cfg3 / cfg5 run the default loop measurement (--entry step, --mode weak, no ControlNet)")
+    extra_kw = {}
+    if cfg["audio"]:   # per-frame audio tokens (Net.py:649-667 windows of wav2vec features, projected to the context width)
+        extra_kw["audio_features"] = seeded_randn((f_tot, 5, 768), 4)
+    if cfg["speed"]:   # speed-bucket embedding added to the time embedding (train_stage_3_speedlayers.py:242-271)
+        extra_kw["speed_embeddings"] = 0.1 * seeded_randn((1, 4 * 320), 5)
     pipe = EMOAnimationPipeline(unet=unet, scheduler=DDPMScheduler())
     if a.entry == "call":
         return bench_call(a, pipe, ref, dev, rank, world, dist, F_WIN, f_tot)
@@ -391,13 +424,15 @@ def main():
         cn.to(dev, dtype)
         cn_kw = dict(controlnet=cn, controlnet_cond=seeded_randn((f_tot, 3, 512, 512), 77).clamp(-1, 1) * 0.5 + 0.5,
                      controlnet_conditioning_scale=1.0)
-    st = pipe.prepare_denoise(seeded_randn((1, 4, f_tot, 64, 64), 1).to(dev), seeded_randn((1, 4, 64, 64), 3),
+    st = pipe.prepare_denoise(seeded_randn((1, 4, f_tot, HW_LAT, HW_LAT), 1).to(dev), seeded_randn((1, 4, HW_LAT, HW_LAT), 3),
                               seeded_randn((2, 77, 768), 2), appearance_encoder=ref, num_inference_steps=NUM_INFERENCE_STEPS,
                               guidance_scale=7.5, context_frames=F_WIN, context_stride=1, context_overlap=0, seed=0,
-                              dist=dist, rank=rank, world_size=world, use_graphs=not a.no_graphs, reference_group=a.ref_group, **cn_kw)
-    n_win = world if a.mode == "weak" else 4
-    assert len(st.windows) == n_win and len(st.units) == 2 * n_win
-    assert sum(len(c.units) for c in st.calls) == (2 if a.mode == "weak" else len(st.units[rank::world]))
+                              dist=dist, rank=rank, world_size=world, use_graphs=not a.no_graphs, reference_group=a.ref_group,
+                              _emulate_rank=emu, **cn_kw, **extra_kw)
+    n_win = (emu[1] if emu else world) if a.mode == "weak" else 4
+    if emu is None:
+        assert len(st.windows) == n_win and len(st.units) == 2 * n_win
+        assert sum(len(c.units) for c in st.calls) == (2 if a.mode == "weak" else len(st.units[rank::world]))
 
     def sync():
         torch.cuda.synchronize()
@@ -449,8 +484,10 @@ def main():
         out = {
             "metric": "denoised frames/s (512x512, 50-step DDPM)", "value": fps, "unit": "frames/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": a.mode,
-            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic" if not a.share_gpu else "synthetic; --share-gpu: ranks time-share ONE GPU over gloo (logic validation, not a multi-GPU number)",
-            "config": {"workload": ("cfg2: 512x512 latents 64x64, 12-frame window per GPU, 50-step DDPM, CFG 7.5 (uc+c batched), "
+            "vs_baseline": None, "dtype": a.dtype, "data": (f"synthetic; --emulate-rank {a.emulate_rank}: ONE rank's work on one GPU without collectives - `value` is the "
+                                                            "N-GPU rate IF the exchanges were free and every rank as fast as this one (an upper bound, NOT a measurement)") if emu else
+            "synthetic" if not a.share_gpu else "synthetic; --share-gpu: ranks time-share ONE GPU over gloo (logic validation, not a multi-GPU number)",
+            "config": {"workload": (cfg["name"] + ", 50-step DDPM, CFG 7.5 (uc+c batched), "
                                     if a.mode == "weak" else
                                     "cfg4 (BASELINE configs[3]): 512x512 latents 64x64, ONE 48-frame clip = 4 windows of 12 x 2 CFG branches "
                                     f"= 8 units over {world} GPU(s), 50-step DDPM, CFG 7.5, ") +
@@ -463,6 +500,7 @@ def main():
                                       "all_gather of eps slices per step, all_gather of ReferenceNet banks per group",
                        "latents_finite": finite, "host_enqueue_ms_per_step": host_s / a.steps * 1e3,
                        "hip_graphs": not a.no_graphs, "reference_group": st.T,
+                       "reference_group_note": "the same group size EMOAnimationPipeline.__call__ uses by default",
                        "reference_passes_in_timed_region": ref_passes,
                        "reference_passes_fair_share": a.steps / st.T},
         }
@@ -470,12 +508,17 @@ def main():
         # runs the ReferenceNet on [uncond-text, cond-text] copies of the image (2 x 0.803 TFLOP); the uncond copy's features
         # are never read (mutual_self_attention.py:243-256 overwrites the uc rows) and everything behind the last bank write
         # is dead, so this path computes less.  The achieved rate is priced on the SURVEY figure for the cond copy only.
-        tflop_ref = n_win * (TFLOP_COND + TFLOP_UNCOND) + 2 * TFLOP_REFNET
-        tflop_step = n_win * (TFLOP_COND + TFLOP_UNCOND) + 1 * TFLOP_REFNET
+        tflop_ref = n_win * (T_COND + T_UNCOND) + 2 * T_REF
+        tflop_step = n_win * (T_COND + T_UNCOND) + 1 * T_REF
+        out["config"]["name"] = a.config
+        out["config"]["algorithmic_tflop_per_frame_reference"] = NUM_INFERENCE_STEPS * tflop_ref / f_tot
         out["config"]["algorithmic_tflop_per_step_reference"] = tflop_ref
         out["config"]["algorithmic_tflop_per_step"] = tflop_step
-        out["config"]["achieved_tflops_whole_path"] = tflop_step / (dt_s / a.steps) / world
-        out["config"]["whole_path_frac_of_mfma_peak"] = tflop_step / (dt_s / a.steps) / world / MFMA_PEAK_BF16_TFLOPS
+        out["config"]["achieved_tflops_whole_path"] = None if emu else tflop_step / (dt_s / a.steps) / world
+        out["config"]["whole_path_frac_of_mfma_peak"] = None if emu else tflop_step / (dt_s / a.steps) / world / MFMA_PEAK_BF16_TFLOPS
+        if emu:
+            out["config"]["emulated_rank"] = {"rank": emu[0], "world": emu[1], "units": [list(u) for c in st.calls for u in c.units],
+                                              "reference_lookahead": st.lookahead, "reference_timesteps_per_group_this_rank": -(-st.T // emu[1])}
         if prof is not None:
             summ, summ_ref = prof.summary(), prof_ref.summary()
             merged = {}
@@ -516,9 +559,9 @@ def main():
                     tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["flops"] else 0.0
                     f.write(f"| {name} | {tag} | {v['launches']:.1f} | {v['ms']:.3f} | {tf:.0f} | "
                             f"{v['bytes'] / (v['ms'] * 1e-3) / 1e9:.0f} |\n")
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.config == "cfg2":   # (the baseline leg times the cfg2 forward)
             try:
-                out["cpu_baseline"] = cpu_baseline(unet, ref, full=a.cpu_baseline_full)
+                out["cpu_baseline"] = cpu_baseline(unet, ref, full=not a.cpu_baseline_sample)
             except Exception as ex:   # the baseline leg must never cost the measurement
                 out["cpu_baseline"] = {"error": f"{type(ex).__name__}: {ex}"}
         print(json.dumps(out))

@@ -81,7 +81,7 @@ class EMOAnimationPipeline:
                         context_batch_size=1, context_schedule="uniform", audio_features=None, speed_embeddings=None, seed=0,
                         fusion_blocks="midup", dist=False, rank=0, world_size=1, return_eps=False, use_graphs=None,
                         controlnet=None, controlnet_cond=None, controlnet_conditioning_scale=1.0, reference_group=10,
-                        reference_lookahead=None, motion_latents=None, text_pairing="reference"):
+                        reference_lookahead=None, motion_latents=None, text_pairing="reference", _emulate_rank=None):
         """Set up the loop state (EMOAnimationPipeline.py:628-696).  latents f32 (1,4,F_tot,h,w);
         ref_image_latents (1,4,h,w); text_embeddings (2,L,D) = [uncond, cond].
         reference_group = T: ReferenceNet timesteps computed per batched pass (1 = the reference's per-step order).
@@ -95,7 +95,10 @@ class EMOAnimationPipeline:
         text_pairing (matters at context_batch_size > 1 only): "reference" = the upstream row pairing, literally (see `unit_tv`
         below: odd windows of a batch run their uncond row under the cond text and vice versa, which cancels guidance for them);
         "branch" = the evidently intended one, every uncond row under the uncond text, every cond row under the cond text and the
-        cond-text bank - the same function as context_batch_size 1, batched."""
+        cond-text bank - the same function as context_batch_size 1, batched.
+        _emulate_rank=(r, n): MEASUREMENT aid (bench.py --emulate-rank): the work of rank r of an n-rank job - its units, its share of every
+        ReferenceNet group, the projection of the whole group - in ONE process without collectives (the other ranks' eps slices are
+        missing, so the latents are not a sample of anything): a rank's critical path per step on an otherwise idle GPU."""
         if text_pairing not in ("reference", "branch"):
             raise ValueError(f"text_pairing must be 'reference' or 'branch', got {text_pairing!r}")
         unet, sch = self.unet, self.scheduler
@@ -151,6 +154,11 @@ class EMOAnimationPipeline:
         # world_size 1 that is exactly the reference's [uc x cbs, c x cbs] batch (:759-763).
         st.dist = bool(dist)
         st.rank, st.world_size = (int(rank), int(world_size)) if st.dist else (0, 1)
+        st.emulate = _emulate_rank is not None
+        if st.emulate:
+            if st.dist:
+                raise ValueError("_emulate_rank replaces dist=True")
+            st.rank, st.world_size = int(_emulate_rank[0]), int(_emulate_rank[1])
         # (branch-major order: with as many windows as ranks a rank owns BOTH branches of one window - balanced, the cond
         # branch costs ~8 % more - and with twice as many ranks as windows, BASELINE configs[3], every rank owns one unit)
         st.branches = (0, 1) if cfg else (1,)
@@ -203,6 +211,8 @@ class EMOAnimationPipeline:
                                          [u[0] for u in call.units[:call.n_uc]] == [u[0] for u in call.units[call.n_uc:]])
                 call.idx = [torch.tensor(st.windows[w], dtype=torch.int64, device=dev) for w, _ in call.units]
                 st.calls.append(call)
+        if st.emulate:          # no exchange: the accumulators see this rank's units only
+            st.units = mine
         st.t_table = torch.tensor(st.timesteps, dtype=torch.int64, device=dev)   # INT timestep table, bit-exact
         st.t_buf = torch.zeros(1, dtype=torch.int64, device=dev)
         if use_graphs is None:      # the measured path is the default one on a HIP device
@@ -228,7 +238,7 @@ class EMOAnimationPipeline:
         st.counter = torch.empty(st.f_tot, device=dev, dtype=torch.float32)
         st.return_eps, st.eps_trace = return_eps, []
         # ---- ReferenceNet groups: the banks depend on the timestep only (never on the latents): T timesteps per pass
-        st.T = T = self.reference_group_size(reference_group, n_steps, st.world_size if st.dist else 1)
+        st.T = T = self.reference_group_size(reference_group, n_steps, st.world_size if (st.dist or st.emulate) else 1)
         st.groups = [list(range(i, min(i + T, n_steps))) for i in range(0, n_steps, T)]
         st.ref_t = torch.zeros(T, dtype=torch.int64, device=dev)
         st.row_table = torch.tensor([((s_ // T) % 2) * T + s_ % T for s_ in range(n_steps)], dtype=torch.int32, device=dev)
@@ -253,7 +263,7 @@ class EMOAnimationPipeline:
         # stream - two collectives whose device-side start order can differ between ranks.  Off by default there (the pass
         # then costs ~1 % on the main stream); pass reference_lookahead=True to overlap it anyway.
         if reference_lookahead is None:
-            reference_lookahead = not (st.dist and st.world_size > 1)
+            reference_lookahead = not ((st.dist or st.emulate) and st.world_size > 1)
         st.lookahead = bool(reference_lookahead) and dev.type == "cuda"
         st.side = torch.cuda.Stream() if st.lookahead else None
         # ControlNet branch (EMOAnimationPipeline.py:643-650,678-679,718-746): (F_tot,3,H,W) conditioning images in [0,1]
@@ -478,7 +488,10 @@ class EMOAnimationPipeline:
                 if (Tg, tv) not in st.ref_gath:
                     st.ref_recv[(Tg, tv)] = torch.empty(st.world_size * n, send.shape[1], device=send.device, dtype=send.dtype)
                     st.ref_gath[(Tg, tv)] = torch.empty(st.world_size * n, send.shape[1], device=send.device, dtype=send.dtype)
-                td.all_gather_into_tensor(st.ref_recv[(Tg, tv)].view(-1), send.contiguous().view(-1), group=st.bank_pg)
+                if st.emulate:      # (stands in for the gathered rows: this rank's banks, repeated)
+                    st.ref_recv[(Tg, tv)].view(st.world_size, -1).copy_(send.contiguous().view(1, -1).expand(st.world_size, -1))
+                else:
+                    td.all_gather_into_tensor(st.ref_recv[(Tg, tv)].view(-1), send.contiguous().view(-1), group=st.bank_pg)
                 # row (rank r, slot i) is group-local timestep i*world + r -> group order
                 st.ref_gath[(Tg, tv)].view(n, st.world_size, -1).copy_(st.ref_recv[(Tg, tv)].view(st.world_size, n, -1).transpose(0, 1))
             self._run(st, ("ref_project", Tg, tv), lambda tv=tv: self._part_reference_project(st, Tg, tv), pool=st.writer_pool)
@@ -592,6 +605,8 @@ class EMOAnimationPipeline:
         st.bank_idx.copy_(st.row_table[si:si + 1], non_blocking=True)  # ... and its row in the resident bank cache
         st.noise_pred.zero_()
         st.counter.zero_()
+        if st.emulate:
+            st.counter.add_(1e-6)       # frames of the other ranks' windows: 0 / 1e-6 instead of 0 / 0
         if st.controlnet is not None and st.calls:   # per-frame residual cache of this step (:718-746)
             self._run(st, "controlnet", lambda: self._part_controlnet(st))
         for ci in range(len(st.calls)):                                                        # :757
@@ -829,7 +844,7 @@ class EMOAnimationPipeline:
                            controlnet_conditioning_scale=controlnet_conditioning_scale,
                            # the measured path: HIP-graph replay (default on a HIP device), batched ReferenceNet groups, and the
                            # prepared state kept for the next clip of the same geometry
-                           use_graphs=kwargs.get("use_graphs"), reference_group=kwargs.get("reference_group", 25),   # whole clips: 2 ReferenceNet passes per 50 steps
+                           use_graphs=kwargs.get("use_graphs"), reference_group=kwargs.get("reference_group", 10),   # = the configuration bench.py measures (25: two passes per 50-step clip, -0.35 ms per step)
                            reference_lookahead=kwargs.get("reference_lookahead"), fusion_blocks=kwargs.get("fusion_blocks", "midup"),
                            motion_latents=kwargs.get("motion_latents"), reuse_state=kwargs.get("reuse_state", True),
                            text_pairing=kwargs.get("text_pairing", "reference"))

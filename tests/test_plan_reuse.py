@@ -128,3 +128,27 @@ def test_omitted_guidance_eta_seed_mean_their_defaults_on_a_cache_hit():
     out = pipe.denoise(*a, reuse_state=True, **kw)
     assert pipe._plan_cache[1] is st and (st.guidance_scale, st.eta, st.seed) == (7.5, 0.0, 0)
     assert torch.equal(out, fresh)
+
+
+def test_emulated_rank_runs_its_units_and_its_share_of_the_reference_groups():
+    """prepare_denoise(_emulate_rank=(r, n)) - bench.py --emulate-rank: rank r's units of an n-rank job in one process, no
+    collectives; its eps slices equal what the full single-process run produces for those units in the first step."""
+    from emote_hack_amd.synth import seeded_randn
+    pipe, ref = _pipe()
+    kw = dict(appearance_encoder=ref, num_inference_steps=2, context_frames=4, context_stride=1, context_overlap=0, reference_group=2, return_eps=True)
+    a = (seeded_randn((1, 4, 8, 8, 8), 5), seeded_randn((1, 4, 8, 8), 3), seeded_randn((2, 5, 32), 2))
+    full = pipe.prepare_denoise(*a, **kw)
+    assert full.units == [(0, 0), (1, 0), (0, 1), (1, 1)]
+    pipe.denoise_step(full, 0)
+    for r in range(4):
+        st = pipe.prepare_denoise(*a, _emulate_rank=(r, 4), **kw)
+        assert st.units == [full.units[r]] and st.world_size == 4 and not st.dist and st.T == 2 and not st.lookahead
+        pipe.denoise_step(st, 0)
+        assert bool(torch.isfinite(st.latents).all())
+        i = full.units.index(st.units[0])
+        if st.units[0][1] == 0:     # an uncond unit reads no bank: the same forward (batched with its sibling there, alone here)
+            torch.testing.assert_close(st.send[0], full.send[i], rtol=1e-4, atol=1e-5)
+        else:                       # a cond unit reads the stand-in for the gathered banks (this rank's timesteps, repeated)
+            assert bool(torch.isfinite(st.send[0]).all())
+    with pytest.raises(ValueError):
+        pipe.prepare_denoise(*a, _emulate_rank=(0, 2), dist=True, **kw)
