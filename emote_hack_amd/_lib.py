@@ -39,6 +39,7 @@ class GemmParams(C.Structure):
         ("up_h", C.c_int), ("up_w", C.c_int),
         ("w_slab_rows", C.c_int), ("w_slab_stride", C.c_int64),
         ("gn_coef", C.c_void_p), ("gn_imgs_per_inst", C.c_int), ("gn_silu", C.c_int),
+        ("vt", C.c_void_p), ("vt_col0", C.c_int),
     ]
 
 
@@ -80,6 +81,7 @@ SIGNATURES = {
     "emo_layernorm_stats": (_i, [_p, _i, _p, _i64, _i, _f, _i, _p]),
     "emo_gemm": (_i, [C.POINTER(GemmParams), _p]),
     "emo_conv3x3_gn_fusable": (_i, [C.POINTER(GemmParams)]),
+    "emo_gemm_vt_ok": (_i, [C.POINTER(GemmParams)]),
     "emo_gemm_suggest_split_k": (_i, [_i64, _i, _i, _i, _i, _i]),
     "emo_gemm_workspace_bytes": (C.c_size_t, [_i64, _i, _i]),
     "emo_attention": (_i, [C.POINTER(AttentionParams), _p]),

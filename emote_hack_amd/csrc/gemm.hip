@@ -32,6 +32,26 @@ extern "C" int emo_conv3x3_gn_fusable(const emo_gemm_params* pp) {
   return pp && emo_dtype_ok(pp->dtype) && pp->H > 0 && pp->W_ > 0 && halo_conv_ok(*pp) && !pp->upsample2x ? 1 : 0;
 }
 
+// columns a wave of the planned tile covers: the split store of emo_gemm_params.vt switches per wave
+static int tile_wave_cols(int tile) {
+  switch (tile) {
+    case EMO_TILE_64x64: return 32;
+    case EMO_TILE_128x160: case EMO_TILE_256x160: case EMO_TILE_256x320: return 160;
+    default: return 64;   // 128x128, 256x256 (+ ping-pong / phase loop)
+  }
+}
+static bool gemm_vt_ok(const emo_gemm_params& p) {
+  if (!p.vt || !p.ln_colsum || p.conv_taps || p.transpose_out || p.geglu || p.residual || p.rowbias || p.split_k > 1 || p.w_slab_rows || p.out_scale != 1.0f) return false;
+  if (p.vt_col0 <= 0 || p.vt_col0 >= p.N || (p.N - p.vt_col0) % 8 || p.M % 32 || p.t_rows <= 0 || p.t_ld < p.t_rows || p.ldc < p.vt_col0) return false;
+  const GemmPlan pl = plan_gemm(p.M, p.N, p.K, p.dtype, 0, 0, p.tile & 15, p.ln_colsum != nullptr);
+  if (pl.split_k > 1) return false;
+  int bm, bn;
+  tile_dims(pl.tile, bm, bn);
+  // a wave's rows (32 .. 128 of the tile's) must lie inside one batch of t_rows rows, its columns on one side of vt_col0
+  return p.t_rows % bm == 0 && p.vt_col0 % tile_wave_cols(pl.tile) == 0 && ((uintptr_t)p.vt % 16) == 0;
+}
+extern "C" int emo_gemm_vt_ok(const emo_gemm_params* pp) { return pp && emo_dtype_ok(pp->dtype) && gemm_vt_ok(*pp) ? 1 : 0; }
+
 extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
   EMO_CHECK(pp, EMO_ERR_NULL, "emo_gemm: null params");
   const emo_gemm_params& p = *pp;
@@ -73,6 +93,7 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
     EMO_CHECK(p.N % 4 == 0 && ((uintptr_t)p.ln_colsum % 16) == 0 && ((uintptr_t)p.ln_stats % 8) == 0 && (!p.bias || ((uintptr_t)p.bias % 16) == 0),
               EMO_ERR_BAD_SHAPE, "emo_gemm: the LayerNorm fold needs N %% 4 == 0 and aligned colsum / stats / bias");
   }
+  if (p.vt) EMO_CHECK(gemm_vt_ok(p), EMO_ERR_UNSUPPORTED, "emo_gemm: vt / vt_col0=%d is not served for this GEMM (ask emo_gemm_vt_ok)", p.vt_col0);
   if (p.gn_coef) {
     EMO_CHECK(conv && halo_conv_ok(p) && !p.upsample2x, EMO_ERR_UNSUPPORTED,
               "emo_gemm: gn_coef is served by the halo-reuse 3x3 conv only (ask emo_conv3x3_gn_fusable)");

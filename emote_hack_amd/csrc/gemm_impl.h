@@ -182,6 +182,46 @@ __device__ __forceinline__ void lds_write8(unsigned addr, unsigned lo, unsigned 
   const unsigned long long v = ((unsigned long long)hi << 32) | lo;
   asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
+// V^T store of a wave's tile from the ROW-MAJOR accumulator layout (lane <-> output row m, register <-> column n): register r of tile
+// (i, j) holds, over the 32 lanes of a half-wave, 32 CONSECUTIVE rows m of column n = wn0 + j*32 + 8*(r>>2) + 4*half + (r&3) - 64 (bf16)
+// contiguous bytes of V^T row n.  One 2-byte (4-byte: f32) buffer store per register: the lane part of the address (m, and the half-wave's
+// 4 columns) is one constant VGPR, the (tile, register) part a scalar offset; rows past M carry an out-of-range lane offset.
+// emo_gemm_params.vt: the V columns of a merged q | k | v projection.  (bias / LayerNorm-folded bias are in the accumulators already.)
+template <typename T, int WTM, int WTN, bool LN>
+__device__ __forceinline__ void epilogue_vt(const f32x16 (&acc)[WTM][WTN], const emo_gemm_params& p, int64_t wm0, int wn0, int lane,
+                                            const float (&ln_rstd)[WTM]) {
+  const int half = lane >> 5, l31 = lane & 31;
+  const int64_t b = wm0 / p.t_rows, ml0 = wm0 % p.t_rows;             // (a wave's 32 * WTM rows lie inside one batch: t_rows % (32 * WTM) == 0 is checked by the host)
+  T* base = (T*)p.vt + b * p.t_batch_stride + (int64_t)(wn0 - p.vt_col0) * p.t_ld + ml0;
+  const int n_left = p.N - wn0;                                        // columns of this wave that exist (a multiple of 8)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((((int64_t)(n_left > 0 ? n_left : 1) - 1) * p.t_ld + 32 * WTM) * (int64_t)sizeof(T)),
+                                                                      0x00020000);
+  const unsigned t_ld_b = (unsigned)p.t_ld * (unsigned)sizeof(T);
+#pragma unroll
+  for (int i = 0; i < WTM; i++) {
+    const bool m_ok = wm0 + i * 32 + l31 < p.M;
+    const unsigned voff = m_ok ? (unsigned)(i * 32 + l31) * (unsigned)sizeof(T) + (unsigned)(4 * half) * t_ld_b : 0x80000000u;
+    const float rs_m = LN ? ln_rstd[i] : 1.0f;
+#pragma unroll
+    for (int j = 0; j < WTN; j++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        if (j * 32 + 8 * g >= n_left) continue;                        // wave-uniform (N - vt_col0 is a multiple of 8)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float v = acc[i][j][4 * g + e] * rs_m;
+          const unsigned soff = (unsigned)(j * 32 + 8 * g + e) * t_ld_b;
+          if constexpr (sizeof(T) == 2) {
+            const unsigned short h = (unsigned short)(pack2<T>(v, 0.f) & 0xffffu);
+            __builtin_amdgcn_raw_buffer_store_b16(h, rs, voff, soff, 2);   // (aux 2 = non-temporal, like the staged epilogue: EPI_STORE_AUX)
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, 2);
+          }
+        }
+      }
+  }
+}
+
 // Addressing and order follow one observation: on gfx950 stores and loads share the in-order vmcnt, so a load issued after a
 // pass's stores (the next pass's residual chunks, a row-bias quad, a spilled 64-bit row address coming back from scratch) cannot
 // be waited for without waiting for those stores to be acknowledged by L2.  The first version (64-bit row addresses per chunk,
@@ -962,6 +1002,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
 
   const bool ln_on = LN;
   bool lds_epilogue = false;
+  // merged q | k | v projection (emo_gemm_params.vt): the waves whose columns are V columns store transposed, the others as usual
+  bool vt_wave = false;
+  if constexpr (!TRANS && !CONV && LN) vt_wave = p.vt != nullptr && wn0 >= p.vt_col0;
   if constexpr (!TRANS && sizeof(T) == 2 && Tile::STAGE_BYTES >= 80 * 32 * NW) {   // (a ring slot must hold a wave's 32 x 32 staging tile)
     lds_epilogue = use_lds_epi;
     if (lds_epilogue) {
@@ -975,6 +1018,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
             acc, pe, wm0, wn0, wave, lane, xbase, C, R, ln_rstd);
       };
       using Tr = std::true_type; using Fa = std::false_type;
+      if (vt_wave) {
+        if constexpr (!TRANS && !CONV && LN) epilogue_vt<T, WTM, WTN, LN>(acc, pe, wm0, wn0, lane, ln_rstd);
+      } else
       if (p.geglu) {   // (GEGLU with a row bias is not staged: use_lds_epi)
         if constexpr (WTN % 2 == 0) { if (res) run(Tr{}, Tr{}, Fa{}); else run(Tr{}, Fa{}, Fa{}); }
       } else if (rowb) {
@@ -985,6 +1031,8 @@ __global__ __launch_bounds__(64 * WVM * WVN, (GemmTile<WTM, WTN, WVM, WVN, NS>::
     }
   }
   if (lds_epilogue) {
+  } else if (vt_wave) {
+    if constexpr (!TRANS && !CONV && LN) epilogue_vt<T, WTM, WTN, LN>(acc, pe, wm0, wn0, lane, ln_rstd);
   } else if constexpr (!TRANS) {
     // lane <-> output row m; register quad g of tile j <-> columns j*32 + 8*g + 4*half + {0..3}
 #pragma unroll

@@ -267,7 +267,7 @@ GEMM_TILE = 0   # tuning hook for tools/bench: pins emo_gemm_params.tile of ever
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_batch=0, residual=None, geglu=False,
          out_scale=1.0, out=None, transpose_rows=0, transpose_ld=0, conv=None, split_k=None, ln=None, tile=None,
-         w_slab_rows=0, gn=None) -> torch.Tensor:
+         w_slab_rows=0, gn=None, vt_cols=0, vt_rows=0, vt_ld=0):
     """out = epilogue(a @ w.T).  a (M, K) rows view; w (N, K) contiguous in the compute dtype.
     ln = (colsum f32 (N,), stats f32 (M, 2) from layer_norm_stats(a)): LayerNorm over K folded into the GEMM - a holds the RAW
     rows, w / bias carry the folded affine (emo_hip.h emo_gemm_params.ln_colsum).
@@ -275,7 +275,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
     the (B*F*H*W, >=Cin) NHWC input and M = B*F*Ho*Wo).
     transpose_rows=L stores V^T per batch of L rows: out (M/L, N, transpose_ld).
     gn = (coef from group_norm_coeffs(a), images per instance, silu): GroupNorm (+ SiLU) of the conv's input applied inside the
-    halo-reuse 3x3 conv - a holds the RAW rows (emo_hip.h emo_gemm_params.gn_coef; conv_gn_fusable says which convs qualify)."""
+    halo-reuse 3x3 conv - a holds the RAW rows (emo_hip.h emo_gemm_params.gn_coef; conv_gn_fusable says which convs qualify).
+    vt_cols = n: the LAST n output columns are stored transposed per batch of vt_rows rows (V^T (M / vt_rows, n, vt_ld)), the first N - n
+    row-major: returns (out (M, N - n), vt) - or None when this GEMM is not served that way (emo_hip.h emo_gemm_params.vt; the caller
+    then runs two launches)."""
     _need_cuda(a, w)
     p = GemmParams()
     pa, lda = _rows(a)
@@ -300,7 +303,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
         p.C, p.ldc = out.data_ptr(), 0
     else:
         if out is None:
-            out = torch.empty(M, n_out, device=a.device, dtype=a.dtype)
+            out = torch.empty(M, n_out - vt_cols, device=a.device, dtype=a.dtype)
         pc, ldc = _rows(out)
         p.C, p.ldc = pc.value, ldc
     p.A, p.lda, p.W = pa.value, lda, w.data_ptr()
@@ -319,6 +322,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
         p.conv_asym = int(conv.get("asym", 0))
         p.up_h, p.up_w = conv.get("up", (0, 0))
     p.dtype = dt(a)
+    vt = None
+    if vt_cols:
+        assert conv is None and not geglu and residual is None and not transpose_rows and tuple(out.shape) == (M, N - vt_cols)
+        vt = torch.empty(M // vt_rows, vt_cols, vt_ld, device=a.device, dtype=a.dtype)
+        p.vt, p.vt_col0, p.t_rows, p.t_ld, p.t_batch_stride = vt.data_ptr(), N - vt_cols, vt_rows, vt_ld, vt_cols * vt_ld
     if gn is not None:
         coef, imgs_per_inst, gn_silu = gn
         assert conv is not None and coef.dtype == torch.float32 and coef.is_contiguous() and coef.shape[1] == 2 * conv["Cin"], coef.shape
@@ -332,6 +340,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
         p.ln_colsum, p.ln_stats = colsum.data_ptr(), stats.data_ptr()
         split_k = 1   # the correction rides in the accumulator init of ONE pass over K
     lib = _lib.load()
+    if vt_cols:
+        split_k = 1
+        if not lib.emo_gemm_vt_ok(C.byref(p)):
+            return None
     sk = lib.emo_gemm_suggest_split_k(M, N, K, p.dtype, int(bool(geglu)), int(bool(transpose_rows))) if split_k is None else split_k
     ws = None
     if sk > 1:
@@ -344,8 +356,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
             tag=f"M={M} N={N} K={K}" + (" geglu" if geglu else "") + (" T" if transpose_rows else "") +
                 (f" s{conv['stride']}{'u' if conv['upsample2x'] else ''}" if conv is not None else "") + (f" sk{sk}" if sk > 1 else "") +
                 (" ln" if ln is not None else "") + (" slab" if w_slab_rows else "") + (" rowbias" if rowbias is not None else "") +
-                (" gn" if gn is not None else ""))
-    return out
+                (" gn" if gn is not None else "") + (f" vt{vt_cols}" if vt_cols else ""))
+    return (out, vt) if vt_cols else out
 
 
 def conv_gn_fusable(x: torch.Tensor, w: torch.Tensor, n_img: int, H: int, W: int, rowbias=None, rows_per_batch=0) -> bool:

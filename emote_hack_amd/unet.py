@@ -64,6 +64,9 @@ GN_FOLD_MIN_HW = 4096
 # write of the activation per conv - disappears; what remains of the norm is its read-only statistics pass.  Served where the conv
 # runs on the halo kernel (W % 16 == 0); frames smaller than this many pixels keep the one-launch GroupNorm kernel.  0 = off.
 GN_CONV_MIN_HW = 0
+# attn1's q | k | v projection (orig_attention.py:598-600) as one LayerNorm-folded GEMM whose V columns are stored transposed by the same
+# launch (emo_gemm_params.vt) instead of a q | k launch and a V^T launch that both read the rows.
+MERGE_QKV = True
 
 
 def ff_tail_weights(w_out, b_out, w2, b2):
@@ -319,6 +322,9 @@ class UNet3DConditionModel:
                 if fold:
                     w[tb + ".attn1.qk_ln"] = ln_fold(torch.cat([m[tb + ".attn1.to_q.weight"], m[tb + ".attn1.to_k.weight"]], 0), None, tb + ".norm1")
                     w[tb + ".attn1.v_ln"] = ln_fold(m[tb + ".attn1.to_v.weight"], None, tb + ".norm1")
+                    # q | k | v as ONE projection (the V columns stored transposed by the same launch: ops.gemm(vt_cols=)); the two
+                    # launches above remain for geometries the split store does not serve
+                    w[tb + ".attn1.qkv_ln"] = tuple(torch.cat([x_, y_], 0).contiguous() for x_, y_ in zip(w[tb + ".attn1.qk_ln"], w[tb + ".attn1.v_ln"]))
                     w[tb + ".attn2.q_ln"] = ln_fold(m[tb + ".attn2.to_q.weight"], None, tb + ".norm2")
                     w[tb + ".ff1_ln"] = geglu_ln(tb + ".ff.net.0.proj", tb + ".norm3")
                 else:
@@ -453,10 +459,17 @@ class UNet3DConditionModel:
         LN_EPS = 1e-5   # nn.LayerNorm default (attention.py:240-252)
         if fold:        # LN1 folded into the q|k and V^T projections
             st = ops.layer_norm_stats(h, LN_EPS)
-            wq, cs, bq = w[tb + ".attn1.qk_ln"]
-            qk = ops.gemm(h, wq, bq, ln=(cs, st))
-            wv, cs, bv = w[tb + ".attn1.v_ln"]
-            vt = ops.gemm(h, wv, bv, ln=(cs, st), transpose_rows=HW, transpose_ld=_round_up(HW, 8))
+            both = None
+            if MERGE_QKV:   # one launch: h is read once, q | k row-major, V^T by the V waves of the same tiles
+                wq, cs, bq = w[tb + ".attn1.qkv_ln"]
+                both = ops.gemm(h, wq, bq, ln=(cs, st), vt_cols=C_, vt_rows=HW, vt_ld=_round_up(HW, 8))
+            if both is not None:
+                qk, vt = both
+            else:
+                wq, cs, bq = w[tb + ".attn1.qk_ln"]
+                qk = ops.gemm(h, wq, bq, ln=(cs, st))
+                wv, cs, bv = w[tb + ".attn1.v_ln"]
+                vt = ops.gemm(h, wv, bv, ln=(cs, st), transpose_rows=HW, transpose_ld=_round_up(HW, 8))
         else:
             n1 = ops.layer_norm(h, w[tb + ".norm1.g"], w[tb + ".norm1.b"])
             if c.bank_mode == "write" and p in c.active:

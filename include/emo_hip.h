@@ -179,10 +179,20 @@ typedef struct {
    * (the padding stays zero) - so the normalised tensor is never written to or re-read from HBM.  Served by the halo-reuse kernel
    * only: emo_conv3x3_gn_fusable(p) says whether a given conv qualifies; emo_gemm returns EMO_ERR_UNSUPPORTED otherwise. */
   const float* gn_coef; int gn_imgs_per_inst; int gn_silu;
+  /* dense, single pass, row-major: the columns [vt_col0, N) are stored TRANSPOSED into `vt` instead - V^T [(m / t_rows)][n - vt_col0][m % t_rows]
+   * with t_ld / t_batch_stride as for transpose_out - while the columns [0, vt_col0) go to C as usual (ldc >= vt_col0): ONE launch for the
+   * q | k | v projection of a self-attention whose V the attention kernel wants key-contiguous (orig_attention.py:598-600 to_q / to_k / to_v on
+   * the same rows; attention.py:279-293) - the rows are read once.  The accumulator layout of the row-major kernels already has consecutive rows m in
+   * consecutive lanes: a register is 32 contiguous elements of a V^T row.  vt_col0 must be a multiple of the planned tile's wave width
+   * (emo_gemm_vt_ok), N - vt_col0 a multiple of 8, M a multiple of 32; with the LayerNorm fold (ln_colsum / ln_stats) only; no GEGLU / residual / row bias /
+   * out_scale.  NULL = off. */
+  void* vt; int vt_col0;
 } emo_gemm_params;
 int emo_gemm(const emo_gemm_params* p, void* stream);
 /* 1 when the conv described by p (gn_* fields ignored) runs on the halo-reuse kernel, i.e. may carry gn_coef */
 int emo_conv3x3_gn_fusable(const emo_gemm_params* p);
+/* 1 when p (with vt / vt_col0 set) is a GEMM the split row-major | transposed store serves on the tile the planner picks for it */
+int emo_gemm_vt_ok(const emo_gemm_params* p);
 /* heuristic split factor for (M, N, K) and the workspace it needs */
 int emo_gemm_suggest_split_k(int64_t M, int N, int K, int dtype, int geglu, int transpose_out);
 size_t emo_gemm_workspace_bytes(int64_t M, int N, int split_k);

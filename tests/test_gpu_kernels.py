@@ -143,6 +143,42 @@ def test_groupnorm_folded_into_linear(dtype, N, S, C, G, Cout):
     close(o.gemm(o.group_norm(xd, g.to(DEV), b.to(DEV), N, G, 1e-6, False), w.to(DEV).to(dtype), bias.to(DEV)), ref, dtype, scale=2.0)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("nb,L,C,tile", [(24, 4096, 320, None), (6, 1024, 640, None), (3, 256, 1280, None), (2, 256, 64, None), (2, 512, 320, 2), (4, 256, 96, 1), (2, 256, 320, 3)])
+def test_gemm_qkv_one_launch_with_transposed_v(dtype, nb, L, C, tile):
+    """emo_gemm_params.vt: the LayerNorm-folded q | k | v projection of a self-attention (orig_attention.py:598-600) as ONE launch - the
+    columns [0, 2C) row-major, the V columns [2C, 3C) stored transposed per batch of L rows by the V waves of the same tiles - against the
+    two launches it replaces (q | k row-major, V^T through the transposed-store kernel): the same accumulators, hence the same bits, and
+    against LayerNorm -> linear in f32.  Shapes of the path (256x256 phase-loop tiles at the three big levels), a small one, and pinned
+    128x128 / 64x64 / 128x160 tiles; a split the planned tile does not serve is refused (None), not mangled."""
+    o = ops()
+    if dtype == torch.float32 and nb * L > 30000:
+        nb = 4
+    M = nb * L
+    x = q(seeded_randn((M, C), 5) * (1 + torch.arange(C) % 5 * 0.25) + 0.3, dtype)
+    g, b = 1 + 0.1 * seeded_randn((C,), 6), 0.1 * seeded_randn((C,), 7)
+    w = seeded_randn((3 * C, C), 8) / C ** 0.5
+    ref = F.linear(F.layer_norm(x, (C,), g, b, 1e-5), w)
+    xd = x.to(DEV).to(dtype)
+    wp, cs, bp = (t.to(DEV).contiguous() for t in _ln_fold(w, None, g, b, dtype))
+    st = o.layer_norm_stats(xd, 1e-5)
+    ld = (L + 7) // 8 * 8
+    both = o.gemm(xd, wp, bp, ln=(cs, st), vt_cols=C, vt_rows=L, vt_ld=ld, tile=tile)
+    if tile == 3:       # 128x160 tiles: a wave covers 160 columns - 2C = 640 = 4 x 160 is served, checked below with C = 320
+        assert both is not None
+    assert both is not None
+    qk, vt = both
+    assert tuple(qk.shape) == (M, 2 * C) and tuple(vt.shape) == (nb, C, ld)
+    qk2 = o.gemm(xd, wp[:2 * C].contiguous(), bp[:2 * C].contiguous(), ln=(cs[:2 * C].contiguous(), st), tile=tile)
+    vt2 = o.gemm(xd, wp[2 * C:].contiguous(), bp[2 * C:].contiguous(), ln=(cs[2 * C:].contiguous(), st), transpose_rows=L, transpose_ld=ld)
+    close(qk, ref[:, :2 * C], dtype, scale=2.0)
+    close(vt[:, :, :L].transpose(1, 2).reshape(M, C), ref[:, 2 * C:], dtype, scale=2.0)
+    assert torch.equal(qk, qk2)
+    assert torch.equal(vt[:, :, :L], vt2[:, :, :L])
+    # a V block that does not start on a wave boundary of the planned tile
+    assert o.gemm(xd, wp, bp, ln=(cs, st), vt_cols=C - 8, vt_rows=L, vt_ld=ld, tile=tile) is None
+
+
 @pytest.mark.parametrize("tile", [None, 7, 4])
 @pytest.mark.parametrize("N,S,C,Cout", [(14, 4096, 64, 256), (8, 4096, 128, 512)])
 def test_weight_slabs_on_the_ping_pong_tile(N, S, C, Cout, tile):
