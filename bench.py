@@ -313,6 +313,7 @@ def main():
     ap.add_argument("--no-fused-tail", action="store_true", help="A/B: ff.net.2 and proj_out as two GEMMs instead of one over [g | h]")
     ap.add_argument("--gn-fold-min-hw", type=int, default=None, help="A/B: pixels per frame from which the transformer GroupNorm is folded into proj_in (0 = never)")
     ap.add_argument("--gn-two-launch", action="store_true", help="A/B: every GroupNorm as statistics + apply launches (no one-launch kernel)")
+    ap.add_argument("--no-merge-qkv", action="store_true", help="A/B: attn1's q | k and V^T projections as two launches instead of one")
     ap.add_argument("--gn-conv-min-hw", type=int, default=None, help="A/B: pixels per frame from which the resnets' GroupNorm + SiLU run inside the 3x3 conv (0 = never)")
     ap.add_argument("--mode", default="weak", choices=["weak", "strong"],
                     help="weak: a 12-frame window per GPU (12*N frames); strong: BASELINE configs[3], one 48-frame clip = 8 units over N GPUs")
@@ -390,6 +391,9 @@ def main():
     if a.gn_two_launch:
         from emote_hack_amd import ops as ops_mod
         ops_mod.GN_ONE_LAUNCH = False
+    if a.no_merge_qkv:
+        from emote_hack_amd import unet as unet_mod
+        unet_mod.MERGE_QKV = False
     if a.gn_conv_min_hw is not None:
         from emote_hack_amd import unet as unet_mod
         unet_mod.GN_CONV_MIN_HW = a.gn_conv_min_hw

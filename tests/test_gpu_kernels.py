@@ -174,7 +174,12 @@ def test_gemm_qkv_one_launch_with_transposed_v(dtype, nb, L, C, tile):
     close(qk, ref[:, :2 * C], dtype, scale=2.0)
     close(vt[:, :, :L].transpose(1, 2).reshape(M, C), ref[:, 2 * C:], dtype, scale=2.0)
     assert torch.equal(qk, qk2)
-    assert torch.equal(vt[:, :, :L], vt2[:, :, :L])
+    # (the transposed-store kernel multiplies with the operands swapped - W rows as the MFMA's B operand; bf16 and f32 give the same bits either
+    # way, the f16 MFMA now and then an accumulator that rounds to the neighbouring half)
+    d = (vt[:, :, :L].float() - vt2[:, :, :L].float()).abs()
+    assert float((d > 0).float().mean()) < 1e-3 and float(d.max()) <= 2 * torch.finfo(dtype).eps * float(vt2[:, :, :L].float().abs().max())
+    if dtype != torch.float16:
+        assert torch.equal(vt[:, :, :L], vt2[:, :, :L])
     # a V block that does not start on a wave boundary of the planned tile
     assert o.gemm(xd, wp, bp, ln=(cs, st), vt_cols=C - 8, vt_rows=L, vt_ld=ld, tile=tile) is None
 
