@@ -16,6 +16,20 @@ extern "C" size_t emo_gemm_workspace_bytes(int64_t M, int N, int split_k) {
   return split_k > 1 ? (size_t)split_k * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
+// The same row-major GEMM / conv restricted to the output columns [n0, n0 + n): EVERY per-column operand moves with them (weights rows,
+// output, bias, residual, row bias) - one place to extend when a per-column field is added to emo_gemm_params.
+static emo_gemm_params output_columns(const emo_gemm_params& p, int n0, int n) {
+  const int esz = p.dtype == EMO_F32 ? 4 : 2;
+  emo_gemm_params q = p;
+  q.N = n;
+  q.W = (const char*)p.W + (int64_t)n0 * p.K * esz;
+  q.C = (char*)p.C + (int64_t)n0 * esz;
+  if (p.bias) q.bias = p.bias + n0;
+  if (p.residual) q.residual = (const char*)p.residual + (int64_t)n0 * esz;
+  if (p.rowbias) q.rowbias = p.rowbias + n0;
+  return q;
+}
+
 // the stride-1 3x3 convs the halo-reuse kernel serves (conv_halo_impl.h); everything else takes the im2col loader of the GEMM
 static bool halo_conv_ok(const emo_gemm_params& p) {
   const int S = p.split_k > 1 ? p.split_k : 1;
@@ -120,17 +134,10 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
         return rc_h;
       };
       if (!n_rem) return launch(p, p.N == 64 ? 64 : HaloGeom::BN);
-      const int esz = p.dtype == EMO_F32 ? 4 : 2;
-      emo_gemm_params a = p, b = p;
+      emo_gemm_params a = p;
       a.N = p.N - n_rem;
-      b.N = n_rem;
-      b.W = (const char*)p.W + (int64_t)a.N * p.K * esz;
-      b.C = (char*)p.C + (int64_t)a.N * esz;
-      if (p.bias) b.bias = p.bias + a.N;
-      if (p.residual) b.residual = (const char*)p.residual + (int64_t)a.N * esz;
-      if (p.rowbias) b.rowbias = p.rowbias + a.N;
       const int rc_a = launch(a, HaloGeom::BN);
-      return rc_a ? rc_a : launch(b, 64);
+      return rc_a ? rc_a : launch(output_columns(p, a.N, n_rem), 64);
     }
   }
   GemmPlan pl = plan_gemm(p.M, p.N, p.K, p.dtype, p.geglu, p.transpose_out, p.tile & 15, p.ln_colsum != nullptr);   // (tile >> 4: tile-order override, gemm_impl.h)

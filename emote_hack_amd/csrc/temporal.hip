@@ -324,7 +324,9 @@ extern "C" int emo_temporal_attention(const void* qkv, int64_t ldqkv, void* out,
   EMO_CHECK(d % V == 0 && ldqkv % V == 0 && ldo % V == 0, EMO_ERR_BAD_SHAPE, "emo_temporal_attention: d=%d must be a multiple of %d", d, V);
   const int C = heads * d;
   EMO_CHECK(ldqkv >= 3 * C && ldo >= C, EMO_ERR_BAD_SHAPE, "emo_temporal_attention: leading dims");
-  if (dtype != EMO_F32 && d % 8 == 0 && d <= 256) {   // MFMA formulation (one wave per (batch row, pixel, head)); F <= 32 checked above
+  // MFMA formulation (one wave per (batch row, pixel, head)); F <= 32 checked above; its four wave-private V images must fit the 64 KB a
+  // launch gets without an attribute (d = 256 with F > 16 does not: the kernel below serves it)
+  if (dtype != EMO_F32 && d % 8 == 0 && d <= 256 && TAM_WAVES * (16 * (F <= 16 ? 1 : 2) * d * 2 + 64) <= 64 * 1024) {
     if (dtype == EMO_BF16) launch_temporal_mfma<bf16_t>(qkv, ldqkv, out, ldo, B, F, HW, heads, d, scale, as_stream(stream));
     else launch_temporal_mfma<f16_t>(qkv, ldqkv, out, ldo, B, F, HW, heads, d, scale, as_stream(stream));
     EMO_LAUNCH_CHECK();
