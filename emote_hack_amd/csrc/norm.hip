@@ -399,8 +399,9 @@ static inline Gn1Geom gn1_geom(int N, int64_t S, int C, int G, int V) {
     const int64_t rows = (S + nt / CVW - 1) / (nt / CVW);
     const int64_t lim = nt == GN1_MAXT ? GN1_MAXR : 4;
     if (rows <= lim) {
-      // (dynamic LDS [RP][Wc][2] floats + the kernel's static tables must fit the 64 KB a launch gets without an attribute)
-      if ((size_t)(nt / CVW) * g.Wc * 2 * sizeof(float) + 2304 > 64 * 1024) return g;
+      // (the DYNAMIC LDS [RP][Wc][2] floats must fit the 64 KB a launch gets without hipFuncAttributeMaxDynamicSharedMemorySize; the 2 KB of
+      // static tables come on top - 65280 + 2176 bytes at N = 2, S = 768, C = 1280 is a geometry of the bench and launches)
+      if ((size_t)(nt / CVW) * g.Wc * 2 * sizeof(float) > 64 * 1024) return g;
       g.NT = nt; g.R = rows <= 2 ? 2 : rows <= 4 ? 4 : rows <= 8 ? 8 : 16; g.ok = 1;
       return g;
     }
