@@ -40,7 +40,9 @@ static GemmPlan plan_gemm(int64_t M, int N, int K, int dtype, int geglu, int tra
   const int nk = (K + bk - 1) / bk;
   // (LayerNorm-folded projections: the 256-row tile also wins at N = 640 / 960 - 105 vs 128 us at M=98304 N=960 K=320, 84 vs 92
   // at N=640 - although the last 256-column tile is ragged)
-  const bool big = dtype != EMO_F32 && tiles256 >= 224 && (N % 256 == 0 || N >= 1792 || (ln && !transpose_out && N >= 640 && (N % 256 == 0 || N % 256 >= 128)));
+  // (round 5, profiles/r05l_tile_sweep.txt: with a ragged last column tile the 256-row tile pays only from ~512 tiles on - M=24576 N=640 K=640
+  // ln, the 32x32 level's attn2 to_q: 40.1 us on 96 x 3 tiles of 256x256 against 31.1 on 128x128)
+  const bool big = dtype != EMO_F32 && tiles256 >= 224 && (N % 256 == 0 || N >= 1792 || (ln && !transpose_out && N >= 640 && tiles256 >= 512 && N % 256 >= 128));
   bool nt5 = !big && !geglu && N % 160 == 0;
   if (nt5 && N % 128 == 0) {
     // both 128x160 and 128x128 tile N exactly: take the one that fills the 2-blocks-per-CU slots better (the 2x2 wave
