@@ -213,3 +213,47 @@ def test_level0_transformer_and_motion_block_at_bench_size_vs_oracle(dtype):
     rows_m = ops.ncfhw_to_rows(ref_t.to(DEV), dtype)
     got_m = ops.rows_to_ncfhw(m._motion(mo, rows_m, c, H, W), 1, 320, Fr, H, W)
     check(got_m, ref_m, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,HW,cin", [(640, 32, 1280), (1280, 16, 2560), (1280, 8, 2560)])
+def test_deeper_levels_resnet_transformer_motion_at_bench_size_vs_oracle(dtype, C, HW, cin):
+    """The blocks of the 32x32 / 16x16 / 8x8 levels at the size bench.py runs them (12 frames; 640 / 1280 channels, 8 heads of 80 / 160),
+    each against the reference-pinned CPU oracle on its own: an UP-path ResnetBlock3D with the concatenated [hidden | skip] input
+    (resnet.py:177-207; Cin 1280 / 2560 -> the long-K 3x3 convs: 16-row halo patches at the 32x32 / 16x16 levels, the im2col loader with
+    256x256 tiles split 8 ways at 8x8; 1x1 shortcut; temb row bias; joint 5-D GroupNorm), the Transformer3DModel block (merged q | k | v
+    launch, d = 80 / 160 attention, GEGLU feed-forward with the fused tail) and its motion module - the full-size-only plans of these
+    levels, which the level-0 test above does not reach."""
+    from oracle import unet_ref as U
+    from emote_hack_amd import ops
+    from emote_hack_amd.spec import param_shapes
+    from emote_hack_amd.unet import UNet3DConditionModel, _Ctx
+    # a two-level network whose FIRST up block has the level's geometry: resnets (cin -> C) + transformers + motion modules at C channels
+    cfg = dict(cases.SD15_MOTION, block_out_channels=(C, cin - C), down_block_types=("CrossAttnDownBlock3D", "DownBlock3D"),
+               up_block_types=("UpBlock3D", "CrossAttnUpBlock3D"), layers_per_block=1)
+    m = UNet3DConditionModel(**cfg)
+    sd = synth_state_dict(param_shapes(m.spec))
+    m.load_state_dict(sd)
+    m.to(DEV, dtype)
+    blk = m.spec.up[1]
+    r, a, mo = blk.resnets[0], blk.attentions[0], blk.motions[0]
+    assert (r.cin, r.cout, a.channels, a.heads) == (cin, C, C, 8) and mo is not None and r.has_shortcut
+    Fr, B = 12, 1
+    x = seeded_randn((B, cin, Fr, HW, HW), 31)
+    ctx = seeded_randn((B, 77, 768), 32)
+    emb = seeded_randn((B, 4 * C), 33)
+    G, eps = cfg["norm_num_groups"], 1e-5
+    with torch.no_grad():
+        ref_r = U.resnet_block(sd, r.prefix, x, emb, G, eps)
+        ref_t = U.transformer3d(sd, a.prefix, ref_r, ctx, 8, G)
+        ref_m = U.motion_module(sd, mo.prefix, ref_t, 8)
+    c = _Ctx(B, Fr, HW, HW)
+    # the resnet reads its slice of the fused time_emb_proj table (unet._temb_off): F.silu(emb) W^T + b for every resnet of the model
+    temb_all = ops.convert(ops.gemm(ops.silu(ops.convert(emb.to(DEV), dtype)), m._w["temb_all.w"], m._w["temb_all.b"]), torch.float32)
+    got_r = ops.rows_to_ncfhw(m._resnet(r, ops.ncfhw_to_rows(x.to(DEV), dtype), temb_all, c, HW, HW), B, C, Fr, HW, HW)
+    check(got_r, ref_r, dtype)
+    ctx_rows = ops.convert(ctx.to(DEV).float().reshape(-1, 768), dtype)
+    got_t = ops.rows_to_ncfhw(m._transformer(a, ops.ncfhw_to_rows(ref_r.to(DEV), dtype), ctx_rows, 77, Fr, c, HW, HW), B, C, Fr, HW, HW)
+    check(got_t, ref_t, dtype)
+    got_m = ops.rows_to_ncfhw(m._motion(mo, ops.ncfhw_to_rows(ref_t.to(DEV), dtype), c, HW, HW), B, C, Fr, HW, HW)
+    check(got_m, ref_m, dtype)
