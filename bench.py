@@ -113,15 +113,18 @@ def cpu_baseline(unet, ref, full=False):
     F_WIN = 12
     t_uncond = t_unet * F_WIN / Fs
     t_full = None
+    parity = None
     if full:   # ONE whole 12-frame cfg2 uncond forward (temporal attention ~ F^2, the 5-D GroupNorm working set)
         xf = seeded_randn((1, 4, F_WIN, 64, 64), 1)
+        kept = []
         with torch.no_grad():
-            t_full = timed(lambda: U.unet_forward(sd_u, cases.SD15_MOTION, xf, 981, ctx), warm=False)
+            t_full = timed(lambda: kept.append(U.unet_forward(sd_u, cases.SD15_MOTION, xf, 981, ctx)), warm=False)
         t_uncond = t_full
+        parity = parity_vs_oracle(unet, xf, ctx, kept[0])
     t_cond = t_uncond * TFLOP_COND / TFLOP_UNCOND
     t_step = t_uncond + t_cond + 2 * t_ref
     t_step8 = (t_unet8 * F_WIN) * (1 + TFLOP_COND / TFLOP_UNCOND) + 2 * t_ref * (t_unet8 / (t_unet / Fs))
-    return {"value": F_WIN / (NUM_INFERENCE_STEPS * t_step), "unit": "denoised frames/s", "cores": cores, "kind": "port",
+    return parity, {"value": F_WIN / (NUM_INFERENCE_STEPS * t_step), "unit": "denoised frames/s", "cores": cores, "kind": "port",
             "sample": (f"oracle fp32: ONE full 12-frame 512x512 uncond UNet fwd ({t_full:.1f}s, cold) + 1 ReferenceNet fwd ({t_ref:.1f}s, warm); step = uncond + "
                        f"1.08 x uncond (cond, by FLOPs) + 2 x refnet = {t_step:.0f}s, x{NUM_INFERENCE_STEPS} steps" if full else
                        f"oracle fp32, warm: 1 uncond UNet fwd on a {Fs}-frame 512x512 window ({t_unet:.1f}s) + 1 ReferenceNet fwd "
@@ -130,6 +133,85 @@ def cpu_baseline(unet, ref, full=False):
             "sample_8_threads": f"1 cold 1-frame uncond fwd on 8 threads ({t_unet8:.1f}s), same extrapolation",
             "full_12_frame_uncond_forward_s": t_full,
             "cfg1_seconds_per_forward": t_cfg1, "cfg1": "BASELINE configs[0]: (1,4,1,32,32), t=981, ctx 77x768, no motion module, full forward"}
+
+
+def parity_vs_oracle(unet, x, ctx, y_ref):
+    """The forward the cpu_baseline leg has just paid for, used as the CHECKER: the same 12-frame 512x512 uncond UNet evaluation
+    (t = 981) on the HIP path - in the benchmarked dtype and in the f32 validation mode of the same kernels - against the oracle's
+    output.  north_star's tolerance (rtol 1e-3 / atol 1e-4) is a statement about the f32 mode; the low-precision figure is reported
+    next to it, not hidden in the smoke log."""
+    from emote_hack_amd.unet import UNet3DConditionModel
+    from tests import cases
+    dev = unet.device
+    out = {"what": "one full-size cfg2 uncond UNet forward (1,4,12,64,64), t=981, ctx (1,77,768): HIP vs the CPU oracle's fp32 output",
+           "ref_mean_abs": float(y_ref.abs().mean()), "ref_max_abs": float(y_ref.abs().max())}
+
+    def one(m):
+        y = m(x.to(dev), 981, ctx.to(dev)).sample.float().cpu()
+        e = (y - y_ref).abs()
+        return {"max_abs": float(e.max()), "mean_abs": float(e.mean()),
+                "within_rtol1e-3_atol1e-4": bool(torch.allclose(y, y_ref, rtol=1e-3, atol=1e-4))}
+    name = {torch.bfloat16: "bf16", torch.float16: "f16", torch.float32: "f32"}[unet.dtype]
+    out["dtype"] = name
+    out.update(one(unet))
+    if unet.dtype != torch.float32:
+        m32 = UNet3DConditionModel(**cases.SD15_MOTION)
+        m32.load_state_dict(unet._master)
+        m32.to(dev, torch.float32)
+        out["f32"] = one(m32)
+        del m32
+        torch.cuda.empty_cache()
+    return out
+
+
+def gpu_clocks(index=0):
+    """Current shader / memory clock of the GPU (MHz) from the amdgpu sysfs tables (the line marked '*' in pp_dpm_sclk /
+    pp_dpm_mclk); None where the node is not readable.  Compute-bound kernels move with SCLK, HBM-bound ones do not - boxes of
+    this pool differ by ~8 % on the same build, so the line says which clocks it was measured at."""
+    import glob
+    import re
+    cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+    if not cards:
+        return None
+    base = os.path.dirname(cards[min(index, len(cards) - 1)])
+    out = {}
+    for key, fn in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
+        try:
+            cur = [ln for ln in open(os.path.join(base, fn)).read().splitlines() if ln.strip().endswith("*")]
+            out[key] = int(re.search(r"(\d+)\s*mhz", cur[0], re.I).group(1)) if cur else None
+        except Exception:
+            out[key] = None
+    return out
+
+
+class ClockSampler:
+    """Samples gpu_clocks() every 50 ms on a host thread while a region runs (sysfs reads, no GPU work)."""
+
+    def __init__(self, index=0):
+        import threading
+        self.index, self.samples, self._stop = index, [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            c = gpu_clocks(self.index)
+            if c:
+                self.samples.append(c)
+            self._stop.wait(0.05)
+
+    def __enter__(self):
+        self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._t.join()
+
+    def summary(self):
+        def agg(k):
+            v = [s[k] for s in self.samples if s.get(k)]
+            return {"min": min(v), "max": max(v), "mean": sum(v) / len(v)} if v else None
+        return {"samples": len(self.samples), "sclk_mhz": agg("sclk_mhz"), "mclk_mhz": agg("mclk_mhz")}
 
 
 def _profile_of_this_build(pattern):
@@ -323,6 +405,8 @@ def main():
                          "entry point EMOAnimationPipeline.__call__ end to end for WHOLE 50-step clips (output_type='latent'): one "
                          "cold call (plan + graph capture), then --calls timed calls that reuse the prepared plan")
     ap.add_argument("--calls", type=int, default=2, help="--entry call: timed calls after the cold one")
+    ap.add_argument("--clips", type=int, default=None, help="whole 50-step clips run back to back BEHIND the timed region and reported as "
+                    "config.whole_clips_after_timed_region (default 3; cfg5: 1; 0 = skip)")
     ap.add_argument("--stage", default="loop", choices=["loop", "vae"],
                     help="loop: the sampling loop (the headline metric); vae: the step right behind it - decode_latents of the 12-frame "
                          "512x512 clip (EMOAnimationPipeline.py:291-307) on the HIP AutoencoderKL, ms per frame (SURVEY 8f row 2)")
@@ -374,6 +458,8 @@ def main():
 
     cfg = CONFIGS[a.config]
     a.dtype = a.dtype or cfg["dtype"]
+    if a.clips is None:
+        a.clips = 1 if a.config == "cfg5" else 3
     dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[a.dtype]
     T_COND, T_UNCOND, T_REF = cfg["tflop"]
     if a.no_ln_fold:
@@ -450,15 +536,40 @@ def main():
         pipe.denoise_step(st, si % NUM_INFERENCE_STEPS)
         si += 1
     sync()
-    t0 = time.perf_counter()
-    groups_before = st.groups_launched
-    for _ in range(a.steps):
-        pipe.denoise_step(st, si % NUM_INFERENCE_STEPS)
-        si += 1
-    host_s = time.perf_counter() - t0   # host time to ENQUEUE the steps (launches are asynchronous)
-    sync()
-    dt_s = time.perf_counter() - t0
+    clk_idle = gpu_clocks(local_rank)
+    with ClockSampler(local_rank) as clk_timed:
+        t0 = time.perf_counter()
+        groups_before = st.groups_launched
+        for _ in range(a.steps):
+            pipe.denoise_step(st, si % NUM_INFERENCE_STEPS)
+            si += 1
+        host_s = time.perf_counter() - t0   # host time to ENQUEUE the steps (launches are asynchronous)
+        sync()
+        dt_s = time.perf_counter() - t0
     ref_passes = st.groups_launched - groups_before
+    # WHOLE CLIPS right behind the timed region (not `value`): --clips x 50 loop iterations back to back, every ReferenceNet group
+    # of a clip included - the per-step figure of a complete 50-step clip, long enough (seconds) for an external utilisation
+    # sampler to see the GPU busy
+    whole = None
+    if a.clips > 0:
+        while si % NUM_INFERENCE_STEPS:      # start the clips at step 0
+            pipe.denoise_step(st, si % NUM_INFERENCE_STEPS)
+            si += 1
+        sync()
+        with ClockSampler(local_rank) as clk_clip:
+            tc = time.perf_counter()
+            for _ in range(a.clips * NUM_INFERENCE_STEPS):
+                pipe.denoise_step(st, si % NUM_INFERENCE_STEPS)
+                si += 1
+            sync()
+            clip_s = time.perf_counter() - tc
+        if dist:
+            t = torch.tensor([clip_s], device=dev, dtype=torch.float64)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            clip_s = float(t.item())
+        whole = {"clips": a.clips, "steps": a.clips * NUM_INFERENCE_STEPS, "seconds": clip_s,
+                 "ms_per_step": clip_s / (a.clips * NUM_INFERENCE_STEPS) * 1e3, "frames_per_s": a.clips * f_tot / clip_s,
+                 "clocks": clk_clip.summary()}
     # per-kernel roofline pass: the SAME steps launched eagerly with every launch bracketed by HIP events on the launch
     # stream (a graph replay cannot host per-launch events); kernels and shapes are identical to the timed region.  The
     # ReferenceNet group pass (one per REF_GROUP steps) is profiled separately and enters per step with weight 1/REF_GROUP.
@@ -506,7 +617,10 @@ def main():
                        "hip_graphs": not a.no_graphs, "reference_group": st.T,
                        "reference_group_note": "the same group size EMOAnimationPipeline.__call__ uses by default",
                        "reference_passes_in_timed_region": ref_passes,
-                       "reference_passes_fair_share": a.steps / st.T},
+                       "reference_passes_fair_share": a.steps / st.T,
+                       "clocks": {"idle_before": clk_idle, "timed_region": clk_timed.summary(),
+                                  "source": "amdgpu sysfs pp_dpm_sclk / pp_dpm_mclk, sampled every 50 ms on a host thread"},
+                       "whole_clips_after_timed_region": whole},
         }
         # algorithmic work per step: cond + uncond Backbone per window + the ReferenceNet pass.  The reference
         # runs the ReferenceNet on [uncond-text, cond-text] copies of the image (2 x 0.803 TFLOP); the uncond copy's features
@@ -565,7 +679,7 @@ def main():
                             f"{v['bytes'] / (v['ms'] * 1e-3) / 1e9:.0f} |\n")
         if world == 1 and not a.no_cpu_baseline and a.config == "cfg2":   # (the baseline leg times the cfg2 forward)
             try:
-                out["cpu_baseline"] = cpu_baseline(unet, ref, full=not a.cpu_baseline_sample)
+                out["parity"], out["cpu_baseline"] = cpu_baseline(unet, ref, full=not a.cpu_baseline_sample)
             except Exception as ex:   # the baseline leg must never cost the measurement
                 out["cpu_baseline"] = {"error": f"{type(ex).__name__}: {ex}"}
         print(json.dumps(out))

@@ -1192,6 +1192,12 @@ static int launch_gemm(const emo_gemm_params& p, int S, hipStream_t st) {
   }
   const int64_t tiles = ((p.M + Tile::BM - 1) / Tile::BM) * ((p.N + Tile::BN - 1) / Tile::BN);
   if (tiles >= (1ll << 31)) return emo_fail(EMO_ERR_BAD_SHAPE, "emo_gemm: too many tiles");
+  // the split store of emo_gemm_params.vt switches per WAVE (epilogue_vt): whatever tile the dispatch (or one of its fallbacks) ended
+  // up with, a wave's 32 * WTN columns must lie on one side of vt_col0 and its 32 * WTM rows inside one batch of t_rows rows -
+  // checked against the geometry of THIS instantiation, not against gemm.hip's table of planned tiles
+  if (p.vt && (p.vt_col0 % (32 * WTN) != 0 || p.t_rows % (32 * WTM) != 0))
+    return emo_fail(EMO_ERR_UNSUPPORTED, "emo_gemm: vt_col0=%d / t_rows=%d do not fall on the wave boundaries (%d columns, %d rows) of the launched tile",
+                    p.vt_col0, p.t_rows, 32 * WTN, 32 * WTM);
   // persistent launch: as many blocks as the chip holds at once (by LDS, <= 4 per CU), each walking its tiles; a
   // multiple of 8 so that a block's tiles all map to its own XCD
   int64_t slots = (256 * Tile::BPC / S) & ~7;

@@ -262,6 +262,7 @@ def layer_norm_stats(x: torch.Tensor, eps=1e-5) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- GEMM / conv
+_VT_VERDICT = {}   # (M, w shape, vt geometry, dtype, tile hint) -> emo_gemm_vt_ok's answer: unsupported levels go straight to two launches
 GEMM_TILE = 0   # tuning hook for tools/bench: pins emo_gemm_params.tile of every dense GEMM that does not pass tile=
 
 
@@ -280,6 +281,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
     row-major: returns (out (M, N - n), vt) - or None when this GEMM is not served that way (emo_hip.h emo_gemm_params.vt; the caller
     then runs two launches)."""
     _need_cuda(a, w)
+    if vt_cols and _VT_VERDICT.get((a.shape[0], tuple(w.shape), vt_cols, vt_rows, vt_ld, a.dtype, tile, GEMM_TILE)) is False:
+        return None     # asked before (emo_gemm_vt_ok below): not served - no throw-away allocations, no ctypes call
     p = GemmParams()
     pa, lda = _rows(a)
     if w_slab_rows:     # per-instance weights (n_inst, N, K) and bias (n_inst, N): rows [i * w_slab_rows, ...) use slab i (group_norm_fold_linear)
@@ -342,7 +345,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, *, rowbias=None, rows_per_
     lib = _lib.load()
     if vt_cols:
         split_k = 1
-        if not lib.emo_gemm_vt_ok(C.byref(p)):
+        ok = bool(lib.emo_gemm_vt_ok(C.byref(p)))
+        if out.data_ptr() % 16 == 0 and vt.data_ptr() % 16 == 0 and out.stride(0) == N - vt_cols:   # (the verdict of a plain geometry only)
+            _VT_VERDICT[(a.shape[0], tuple(w.shape), vt_cols, vt_rows, vt_ld, a.dtype, tile, GEMM_TILE)] = ok
+        if not ok:
             return None
     sk = lib.emo_gemm_suggest_split_k(M, N, K, p.dtype, int(bool(geglu)), int(bool(transpose_rows))) if split_k is None else split_k
     ws = None

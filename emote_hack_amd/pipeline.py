@@ -53,13 +53,14 @@ class EMOAnimationPipeline:
             raise ValueError("unet and scheduler are required")
         self.vae, self.text_encoder, self.tokenizer = vae, text_encoder, tokenizer
         self.unet, self.controlnet, self.scheduler = unet, controlnet, scheduler
-        if isinstance(scheduler, DDIMScheduler) and scheduler.config.steps_offset != 1:
+        # EMOAnimationPipeline.py:105-117: ANY scheduler whose config has the key, not DDIM only - a DDPMScheduler handed to the
+        # pipeline runs [981, ..., 1] on 50 of 1000 steps, like a diffusers DDPMScheduler would under the reference ctor
+        if getattr(scheduler.config, "steps_offset", 1) != 1:
             scheduler.config.steps_offset = 1
         if getattr(scheduler.config, "clip_sample", False):
             scheduler.config.clip_sample = False
         self.vae_scale_factor = 8
         self.device = unet.device
-        self._bank_pg = {}     # world_size -> the ReferenceNet-bank communicator (created once: td.new_group is a collective + leaks)
         self._plan_cache = None   # (plan key, prepared state) of the last `denoise(reuse_state=True)` / `__call__`
 
     @property
@@ -244,26 +245,17 @@ class EMOAnimationPipeline:
         st.row_table = torch.tensor([((s_ // T) % 2) * T + s_ % T for s_ in range(n_steps)], dtype=torch.int32, device=dev)
         st.bank_idx = torch.zeros(1, dtype=torch.int32, device=dev)
         st.kv_all, st.group_ready, st.group_pending, st.groups_launched = {}, -1, -1, 0
-        st.ref_sel, st.ref_recv, st.ref_gath, st.bank_pg = {}, {}, {}, None
+        st.ref_sel, st.ref_recv, st.ref_gath = {}, {}, {}
         st.bank_pack, st.stage = {}, {}
         spec_r = appearance_encoder.spec
         chan = {a.prefix: a.channels for blk in spec_r.down + [spec_r.mid] + spec_r.up for a in blk.attentions if a is not None}
         st.bank_C = [chan[p] for p in st.writer.order]
-        if st.dist and st.world_size > 1:
-            import torch.distributed as td
-            # once per pipeline AND default process group (denoise_chained prepares per clip; new_group leaks a communicator).  A
-            # communicator made under a default group that has since been destroyed / re-initialised is dead: keyed on its identity
-            world_pg = td.distributed_c10d._get_default_group()
-            entry = self._bank_pg.get(st.world_size)
-            if entry is None or entry[0] is not world_pg:
-                entry = self._bank_pg[st.world_size] = (world_pg, td.new_group(ranks=list(range(st.world_size))))
-            st.bank_pg = entry[1]
-        # look-ahead = group g+1's ReferenceNet pass on a second stream under group g's Backbone steps.  With world_size > 1 that
-        # pass carries an RCCL all_gather on its own communicator, concurrent with the per-step eps all_gather on the main
-        # stream - two collectives whose device-side start order can differ between ranks.  Off by default there (the pass
-        # then costs ~1 % on the main stream); pass reference_lookahead=True to overlap it anyway.
+        # look-ahead = group g+1's ReferenceNet pass on a second stream under group g's Backbone steps.  With world_size > 1 the
+        # side stream carries the WRITE passes only; the bank all_gather stays on the main stream and on the communicator of the
+        # per-step eps all_gather (see _ensure_group): one program order of collectives on every rank, so the overlap is safe
+        # at any world size and on by default.
         if reference_lookahead is None:
-            reference_lookahead = not ((st.dist or st.emulate) and st.world_size > 1)
+            reference_lookahead = True
         st.lookahead = bool(reference_lookahead) and dev.type == "cuda"
         st.side = torch.cuda.Stream() if st.lookahead else None
         # ControlNet branch (EMOAnimationPipeline.py:643-650,678-679,718-746): (F_tot,3,H,W) conditioning images in [0,1]
@@ -470,18 +462,26 @@ class EMOAnimationPipeline:
             k, vt = self.unet.bank_kv(pr, rows.reshape(-1, C_), L)
             st.stage[tv][pr] = (k, vt, L)
 
-    def _reference_group(self, st, g):
-        """Compute group g's projected banks on the CURRENT stream and store them in slot g % 2 of the resident cache."""
+    def _reference_write(self, st, g):
+        """Phase 1 of group g: this rank's share of the group's ReferenceNet write passes (no communication) on the CURRENT stream."""
         steps = st.groups[g]
-        Tg, T, slot = len(steps), st.T, g % 2
+        Tg = len(steps)
         st.groups_launched += 1
         st.ref_t[:Tg].copy_(st.t_table[steps[0]:steps[0] + Tg], non_blocking=True)
         for tv in st.bank_variants:
             self._run(st, ("ref_write", Tg, tv), lambda tv=tv: self._part_reference_write(st, Tg, tv), pool=st.writer_pool)
+
+    def _reference_finish(self, st, g):
+        """Phase 2 of group g on the CURRENT stream: the bank exchange (world_size > 1), the K / V^T projection of the whole group
+        with the Backbone's weights, and the copy into slot g % 2 of the resident cache."""
+        steps = st.groups[g]
+        Tg, T, slot = len(steps), st.T, g % 2
+        for tv in st.bank_variants:
             if st.world_size > 1:
                 # north_star: "RCCL all-gather over xGMI to broadcast ReferenceNet features" - rank r computed timesteps
-                # r, r+world, ... of the group; ONE all_gather hands every rank every timestep's banks (own communicator: the
-                # exchange rides the side stream and must not queue in front of the per-step eps all_gather)
+                # r, r+world, ... of the group; ONE all_gather hands every rank every timestep's banks.  Same communicator and same
+                # stream as the per-step eps all_gather: every rank issues its collectives in ONE program order (eps of the group's
+                # last step, banks of the next group, eps of its first step, ...), so no start-order hazard exists by construction
                 import torch.distributed as td
                 send = st.bank_pack[tv]
                 n = send.shape[0]
@@ -491,7 +491,7 @@ class EMOAnimationPipeline:
                 if st.emulate:      # (stands in for the gathered rows: this rank's banks, repeated)
                     st.ref_recv[(Tg, tv)].view(st.world_size, -1).copy_(send.contiguous().view(1, -1).expand(st.world_size, -1))
                 else:
-                    td.all_gather_into_tensor(st.ref_recv[(Tg, tv)].view(-1), send.contiguous().view(-1), group=st.bank_pg)
+                    td.all_gather_into_tensor(st.ref_recv[(Tg, tv)].view(-1), send.contiguous().view(-1))
                 # row (rank r, slot i) is group-local timestep i*world + r -> group order
                 st.ref_gath[(Tg, tv)].view(n, st.world_size, -1).copy_(st.ref_recv[(Tg, tv)].view(st.world_size, n, -1).transpose(0, 1))
             self._run(st, ("ref_project", Tg, tv), lambda tv=tv: self._part_reference_project(st, Tg, tv), pool=st.writer_pool)
@@ -507,14 +507,26 @@ class EMOAnimationPipeline:
                 srcs += [k[:Tg * L], vt[:Tg]]
             torch._foreach_copy_(dsts, srcs)
 
+    def _reference_group(self, st, g):
+        """Compute group g's projected banks on the CURRENT stream and store them in slot g % 2 of the resident cache."""
+        self._reference_write(st, g)
+        self._reference_finish(st, g)
+
     def _ensure_group(self, st, si):
-        """Group of step si resident (waiting for / computing it if needed), the NEXT group launched on the side stream."""
+        """Group of step si resident (waiting for / computing it if needed), the NEXT group launched on the side stream.
+        world_size 1: the whole pass of group g+1 (write, projection, cache copy) rides the side stream.  world_size > 1: only its
+        WRITE pass does (the ReferenceNet forwards - the expensive, communication-free part); the bank all_gather and the projection are
+        issued on the MAIN stream when the loop reaches the group - in program order with the per-step eps all_gather, on the one
+        communicator both use (EMOAnimationPipeline.py:796-821 is the exchange this replaces)."""
         g = si // st.T
         cuda = self.unet.device.type == "cuda"
         main = torch.cuda.current_stream() if cuda else None
+        split = st.world_size > 1
         if st.group_ready != g:
             if st.group_pending == g:
                 main.wait_stream(st.side)
+                if split:
+                    self._reference_finish(st, g)
             else:
                 self._reference_group(st, g)
             st.group_ready, st.group_pending = g, -1
@@ -522,7 +534,10 @@ class EMOAnimationPipeline:
                 # slot (g+1) % 2 held group g-1: every step of it is already enqueued on the main stream
                 st.side.wait_stream(main)
                 with torch.cuda.stream(st.side):
-                    self._reference_group(st, g + 1)
+                    if split:
+                        self._reference_write(st, g + 1)
+                    else:
+                        self._reference_group(st, g + 1)
                 st.group_pending = g + 1
 
     # ---- ControlNet (per-frame residual cache of the step, :718-746)
@@ -617,12 +632,23 @@ class EMOAnimationPipeline:
         self._accumulate_all(st)
         # (the state's own scheduler object and step count: `self.scheduler` may have been replaced or re-timed since the plan was made)
         sch = st.scheduler
-        c_x, c_eps, c_n = sch.coefficients(t, st.eta if isinstance(sch, DDIMScheduler) else None, st.num_inference_steps)
+        c_x, c_eps, c_n = self._coefficients(sch, t, st.eta if isinstance(sch, DDIMScheduler) else None, st.num_inference_steps)
         eps_out = torch.empty(st.C4 * st.f_tot * st.HW, device=dev, dtype=torch.float32) if st.return_eps else None
         ops.cfg_step(st.noise_pred, st.counter, st.latents, C_=st.C4, F=st.f_tot, HW=st.HW, guidance_scale=st.guidance_scale,
                      c_x=c_x, c_eps=c_eps, c_noise=c_n, seed=st.seed, step=si, eps_out=eps_out)  # :812-817 fused
         if st.return_eps:
             st.eps_trace.append(eps_out.view(1, st.C4, st.f_tot, st.h, st.w))
+
+    @staticmethod
+    def _coefficients(sch, t, eta, num_inference_steps):
+        """(c_x, c_eps, c_noise) of step t from the scheduler object.  The step count goes by KEYWORD, and a user-supplied scheduler
+        with the leaner `coefficients(t[, eta])` signature is still served - as long as it has been timed for this many steps."""
+        try:
+            return sch.coefficients(t, eta, num_inference_steps=num_inference_steps)
+        except TypeError:
+            if getattr(sch, "num_inference_steps", num_inference_steps) != num_inference_steps:
+                raise
+            return sch.coefficients(t, eta) if eta is not None else sch.coefficients(t)
 
     def _run_loop(self, st, num_actual_inference_steps=None, callback=None, callback_steps=1):
         n = st.num_inference_steps
@@ -677,21 +703,22 @@ class EMOAnimationPipeline:
         def wid(m):   # a re-pack (load_state_dict / .to) builds a new dict of packed tensors: captured graphs are stale
             return None if m is None else (id(m), id(getattr(m, "_w", None)), str(getattr(m, "dtype", None)))
         def sched_id(s):   # the scheduler OBJECT the state steps with and everything its tables depend on
-            c = s.config
-            return (id(s), type(s).__name__, c.num_train_timesteps, c.beta_start, c.beta_end, c.beta_schedule, c.steps_offset, c.set_alpha_to_one)
+            c = s.config   # (a user-supplied scheduler may carry a leaner config: absent fields key as None)
+            return (id(s), type(s).__name__) + tuple(getattr(c, f, None) for f in ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule",
+                                                                                   "steps_offset", "set_alpha_to_one", "timestep_spacing"))
 
         def pg_id():       # a state prepared with dist=True holds communicators of the default group it was made under
             if not kw.get("dist"):
                 return None
             import torch.distributed as td
-            return id(td.distributed_c10d._get_default_group()) if td.is_initialized() else None
+            return id(td.group.WORLD) if td.is_initialized() else None     # (the public handle of the default group)
         plan = {k: v for k, v in kw.items() if k not in ("audio_features", "speed_embeddings", "motion_latents", "controlnet_cond",
                                                             "controlnet_conditioning_scale", "guidance_scale", "eta", "seed",
                                                             "appearance_encoder", "controlnet")}
         return (shp(latents), shp(ref_image_latents), shp(text_embeddings), shp(kw.get("audio_features")), shp(kw.get("speed_embeddings")),
                 shp(kw.get("motion_latents")), shp(kw.get("controlnet_cond")), kw.get("controlnet_conditioning_scale", 1.0),
                 self._do_cfg(kw.get("guidance_scale", 7.5)), wid(self.unet), wid(kw.get("appearance_encoder")), wid(kw.get("controlnet")),
-                sched_id(self.scheduler), pg_id(), unet_mod.SHARE_CFG_PREFIX, unet_mod.GN_FOLD_MIN_HW, unet_mod.GN_CONV_MIN_HW,
+                sched_id(self.scheduler), pg_id(), unet_mod.SHARE_CFG_PREFIX, unet_mod.GN_FOLD_MIN_HW, unet_mod.GN_CONV_MIN_HW, unet_mod.MERGE_QKV,
                 tuple(sorted((k, repr(v)) for k, v in plan.items())))
 
     def reset_denoise(self, st, latents, motion_latents=None, **inputs):

@@ -6,7 +6,10 @@ Host side only computes the INTEGER timestep table (bit-exact) and three scalars
 per-element update x <- c_x*x + c_eps*eps + c_noise*z runs in the fused HIP sampler kernel
 (emo_cfg_step) with counter-based noise, so every rank draws identical z without communication.
 
-Pipeline-enforced config (EMOAnimationPipeline.py:105-130): steps_offset=1, clip_sample=False.
+Pipeline-enforced config (EMOAnimationPipeline.py:105-130): steps_offset=1 on every scheduler whose config carries the key
+(both classes here do, like diffusers' since `timestep_spacing` exists), clip_sample=False.  A scheduler built on its own keeps
+diffusers' defaults (DDIM: the pipeline's 1; DDPM: 0) until it is handed to EMOAnimationPipeline.
+`timestep_spacing` is "leading" (diffusers' default for both classes: i * (T // n) + steps_offset); other spacings are refused.
 """
 from __future__ import annotations
 
@@ -29,12 +32,14 @@ class _SchedulerBase:
     init_noise_sigma = 1.0
 
     def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear",
-                 steps_offset=0, clip_sample=False, set_alpha_to_one=True, **_ignored):
+                 steps_offset=0, clip_sample=False, set_alpha_to_one=True, timestep_spacing="leading", **_ignored):
         if clip_sample:
             raise ValueError("clip_sample must be False (EMOAnimationPipeline.py:118-130 forces it)")
+        if timestep_spacing != "leading":
+            raise NotImplementedError(f"timestep_spacing={timestep_spacing!r}: only 'leading' (the diffusers default the reference runs) is built")
         self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
                                       beta_schedule=beta_schedule, steps_offset=steps_offset, clip_sample=False,
-                                      set_alpha_to_one=set_alpha_to_one)
+                                      set_alpha_to_one=set_alpha_to_one, timestep_spacing=timestep_spacing)
         self.betas = _betas(num_train_timesteps, beta_start, beta_end, beta_schedule)
         self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0).double()
         self.final_alpha_cumprod = 1.0 if set_alpha_to_one else float(self.alphas_cumprod[0])

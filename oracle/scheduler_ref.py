@@ -4,7 +4,10 @@ PARITY UNPINNED for the scheduler: the reference calls `diffusers` schedulers (n
 version unpinned - requirements.txt:1; call sites EMOAnimationPipeline.py:653-654,764,817).
 Restated from the papers: DDPM = Ho et al. 2020 Eq. 7 / Eq. 11 with "fixed_small" variance,
 DDIM = Song et al. 2021 Eq. 12 (eta).  In-tree pins honoured: steps_offset=1 and
-clip_sample=False are forced by the pipeline ctor (EMOAnimationPipeline.py:105-130); the
+clip_sample=False are forced by the pipeline ctor on EVERY scheduler whose config carries the key
+(EMOAnimationPipeline.py:105-130: `hasattr(scheduler.config, "steps_offset")` - DDIM always, DDPM in
+every diffusers release that has `timestep_spacing`), so SchedulerRef defaults to offset 1 for both
+kinds: 50 steps of 1000 run the INT table [981, 961, ..., 1]; the
 x0-reconstruction identity of `next_step` (EMOAnimationPipeline.py:379-400) is a self-check.
 
 `uniform_windows` restates magicanimate/pipelines/context.py:12-42 and IS pinned (integer
@@ -27,7 +30,8 @@ def make_betas(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, bet
 
 
 def timestep_table(num_inference_steps, num_train_timesteps=1000, steps_offset=0):
-    """INT, bit-exact: 'leading' spacing. 50 on 1000 -> DDPM [980..0], DDIM(+offset 1) [981..1]."""
+    """INT, bit-exact: 'leading' spacing (diffusers' default `timestep_spacing`): i * (T // n) + steps_offset, descending.
+    50 on 1000 -> [980..0] at offset 0, [981..1] at the offset 1 the pipeline forces."""
     ratio = num_train_timesteps // num_inference_steps
     return [int(i * ratio) + steps_offset for i in range(num_inference_steps)][::-1]
 
@@ -37,7 +41,7 @@ class SchedulerRef:
                  beta_schedule="linear", steps_offset=1, set_alpha_to_one=True, eta=0.0):
         assert kind in ("ddim", "ddpm")
         self.kind, self.T, self.eta = kind, num_train_timesteps, eta
-        self.steps_offset = steps_offset if kind == "ddim" else 0
+        self.steps_offset = steps_offset
         self.betas = make_betas(num_train_timesteps, beta_start, beta_end, beta_schedule)
         self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
         self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]

@@ -89,6 +89,9 @@ def resnet_block(sd, p, x, emb, groups, eps, scale=1.0):
     return (x + h) / scale
 
 
+MAX_SCORE_ELEMS = 1 << 30   # 4 GB of f32 scores per attention chunk
+
+
 def attention(sd, p, x, ctx, heads, upcast=False):
     """orig_attention.py:598-684 (CrossAttention.forward/_attention): q/k/v no bias, scale d^-0.5,
     softmax over keys, to_out[0] Linear+bias."""
@@ -100,8 +103,11 @@ def attention(sd, p, x, ctx, heads, upcast=False):
     q, k, v = sp(q), sp(k), sp(v)
     if upcast:
         q, k = q.float(), k.float()
-    s = torch.matmul(q, k.transpose(-1, -2)) * (d ** -0.5)
-    o = torch.matmul(s.softmax(-1).to(v.dtype), v)
+    # batch rows are independent: the score tensor is formed for MAX_SCORE_ELEMS elements' worth of rows at a time (the full-size
+    # level-0 read pass would otherwise hold 12 x 8 x 4096 x 8192 f32 scores = 12.9 GB twice) - the same per-row arithmetic
+    step = max(1, MAX_SCORE_ELEMS // max(1, heads * lq * k.shape[2]))
+    o = torch.cat([torch.matmul((torch.matmul(q[i:i + step], k[i:i + step].transpose(-1, -2)) * (d ** -0.5)).softmax(-1).to(v.dtype),
+                                v[i:i + step]) for i in range(0, b, step)], 0)
     o = o.permute(0, 2, 1, 3).reshape(b, lq, c)
     return _lin(sd, p + ".to_out.0", o)
 

@@ -15,7 +15,11 @@ sys.path.insert(0, ROOT)
 def main():
     kind, graphs, ref_group, lookahead, cbs, gs = sys.argv[1], sys.argv[2] == "1", int(sys.argv[3]), sys.argv[4] == "1", int(sys.argv[5]), float(sys.argv[6])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    td.init_process_group("gloo")
+    if os.environ.get("EMO_DIST_BACKEND", "gloo") == "nccl":    # one device per rank: the RCCL transport itself (>= `world` GPUs visible)
+        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+        td.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ["LOCAL_RANK"])))
+    else:
+        td.init_process_group("gloo")
     from safetensors.torch import load_file
     from emote_hack_amd import DDIMScheduler, DDPMScheduler
     from emote_hack_amd.appearance_encoder import AppearanceEncoderModel
@@ -40,7 +44,7 @@ def main():
     for r in range(world):
         assert torch.equal(all_l[r], all_l[0]), f"rank {r} differs"
     if rank == 0:
-        print(f"DIST_GPU_OK world={world} {kind} graphs={graphs} ref_group={ref_group} lookahead={lookahead}", flush=True)
+        print(f"DIST_GPU_OK world={world} backend={td.get_backend()} {kind} graphs={graphs} ref_group={ref_group} lookahead={lookahead}", flush=True)
     td.barrier()
     td.destroy_process_group()
 

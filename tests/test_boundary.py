@@ -220,9 +220,15 @@ def test_scheduler_tables_golden(ints):
     """A3 regression pin: INT timestep tables bit-exact, update coefficients to 1e-12 (tests/golden/ints.json
     "scheduler_tables", generated from oracle/scheduler_ref.py - parity UNPINNED against diffusers, which is absent)."""
     from emote_hack_amd import DDIMScheduler, DDPMScheduler
+    from emote_hack_amd.pipeline import EMOAnimationPipeline
+    assert {"ddim_50", "ddpm_50", "ddpm0_50"} <= set(ints["scheduler_tables"])
+    assert ints["scheduler_tables"]["ddpm_50"]["timesteps"] == list(range(981, 0, -20))      # what the pipeline runs (:105-117)
     for name, tab in ints["scheduler_tables"].items():
         kind, n = name.split("_")
         sch = DDIMScheduler() if kind == "ddim" else DDPMScheduler()
+        if kind != "ddpm0":      # through the pipeline ctor, which forces steps_offset = 1 on every scheduler that has the key
+            EMOAnimationPipeline(unet=type("U", (), {"device": "cpu"})(), scheduler=sch)
+            assert sch.config.steps_offset == 1
         assert sch.set_timesteps(int(n)) == tab["timesteps"]
         for t, want in zip(tab["timesteps"], tab["coefficients"]):
             got = sch.coefficients(t)
@@ -265,10 +271,13 @@ def test_ddim_step_inverts_the_in_tree_next_step():
 def test_scheduler_matches_oracle(kind):
     from emote_hack_amd import DDIMScheduler, DDPMScheduler
     from oracle.scheduler_ref import SchedulerRef
-    mine = DDIMScheduler() if kind == "ddim" else DDPMScheduler()
+    mine = DDIMScheduler() if kind == "ddim" else DDPMScheduler(steps_offset=1)
     ref = SchedulerRef(kind)
     assert mine.set_timesteps(50) == ref.set_timesteps(50)          # INT, bit-exact
-    assert mine.timesteps == (list(range(981, 0, -20)) if kind == "ddim" else list(range(980, -1, -20)))
+    assert mine.timesteps == list(range(981, 0, -20))               # the offset the pipeline ctor forces on both (:105-117)
+    assert DDPMScheduler().set_timesteps(50) == SchedulerRef("ddpm", steps_offset=0).set_timesteps(50) == list(range(980, -1, -20))
+    with pytest.raises(NotImplementedError):
+        DDIMScheduler(timestep_spacing="trailing")
     for t in mine.timesteps:
         a, b = mine.coefficients(t), ref.coefficients(t)
         assert all(abs(x - y) <= 1e-12 * max(1, abs(y)) for x, y in zip(a, b)), (t, a, b)

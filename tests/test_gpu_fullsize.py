@@ -257,3 +257,80 @@ def test_deeper_levels_resnet_transformer_motion_at_bench_size_vs_oracle(dtype, 
     check(got_t, ref_t, dtype)
     got_m = ops.rows_to_ncfhw(m._motion(mo, ops.ncfhw_to_rows(ref_t.to(DEV), dtype), c, HW, HW), B, C, Fr, HW, HW)
     check(got_m, ref_m, dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[1] END TO END against the ORACLE at the benchmarked size: the whole 4-level Backbone (skip connections, the fused
+# time_emb_proj table, zero-copy concatenation, the shared CFG prefix) and the ReferenceNet write -> fp16 banks -> read path, not
+# block by block.  ~80 s of oracle time on the GPU box's host cores (two 12-frame 512^2 forwards + one ReferenceNet image).
+
+@pytest.fixture(scope="module")
+def cfg2_oracle(cfg2_models):
+    """(inputs, oracle outputs) of one CFG-batched cfg2 UNet evaluation at t = 981, computed once for the f32 and the bf16 test:
+    uncond row = plain forward under the uncond text; cond row = ReferenceNet write pass on the cond copy of the reference image
+    (unet_controlnet.py:328-483 at F = 1, bank_mode='write') -> banks rounded through fp16 (mutual_self_attention.py:577,588) ->
+    Backbone forward reading them under the cond text (mutual_self_attention.py:232-256)."""
+    import time
+    from oracle import unet_ref as U
+    unet, ref = cfg2_models
+    sd_u = {k: v.float().cpu() for k, v in unet._master.items()}
+    sd_r = {k: v.float().cpu() for k, v in ref._master.items()}
+    x = seeded_randn((1, 4, 12, 64, 64), 1)
+    ctx = seeded_randn((2, 77, 768), 2)            # [uncond text, cond text]
+    ref_lat = seeded_randn((1, 4, 64, 64), 3)
+    t = 981
+    torch.set_num_threads(min(torch.get_num_threads(), 32))
+    t0 = time.time()
+    with torch.no_grad():
+        y_uc = U.unet_forward(sd_u, cases.SD15_MOTION, x, t, ctx[:1])
+        _, written = U.unet_forward(sd_r, cases.SD15, ref_lat[:, :, None], t, ctx[1:], bank_mode="write")
+        banks = U.round_banks_fp16(written)
+        order_r, order_u = U.transformer_block_order(cases.SD15), U.transformer_block_order(cases.SD15_MOTION)
+        y_c = U.unet_forward(sd_u, cases.SD15_MOTION, x, t, ctx[1:], bank_mode="read", banks={pu: banks[pr] for pu, pr in zip(order_u, order_r)})
+    print(f"oracle: uncond + ReferenceNet + cond forward at full size in {time.time() - t0:.0f} s")
+    return dict(x=x, ctx=ctx, ref_lat=ref_lat, t=t, y=torch.cat([y_uc, y_c], 0), banks=[banks[p] for p in order_r])
+
+
+def _hip_cfg2_forward(unet, ref, o):
+    """The product's [uncond, cond] batch through the reference's own protocol: writer on [uncond, cond] copies of the reference
+    image (EMOAnimationPipeline.py:711-716), reader.update(writer), one UNet call (EMOAnimationPipeline.py:759-790)."""
+    from emote_hack_amd.reference_control import ReferenceAttentionControl
+    writer = ReferenceAttentionControl(ref, do_classifier_free_guidance=True, mode="write", batch_size=1)
+    reader = ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", batch_size=1)
+    try:
+        ref(o["ref_lat"].repeat(2, 1, 1, 1).to(DEV), o["t"], encoder_hidden_states=o["ctx"].to(DEV), return_dict=False)
+        banks = [writer.bank[p][0][1:].float().cpu() for p in writer.order]      # the cond copy's rows
+        reader.update(writer)
+        y = unet(o["x"].repeat(2, 1, 1, 1, 1).to(DEV), o["t"], o["ctx"].to(DEV), _halves_identical=True).sample.float().cpu()
+        reader.clear()
+        writer.clear()
+    finally:
+        unet._reference_control = ref._reference_control = None
+    return y, banks
+
+
+def test_cfg2_full_unet_f32_vs_oracle(cfg2_models_f32, cfg2_oracle):
+    """north_star's tolerance at the benchmarked size: the f32 mode of the SAME kernels (v_mfma_f32_32x32x2_f32) against the
+    reference-pinned oracle at rtol 1e-3 / atol 1e-4 - every ReferenceNet bank, the uncond row and the bank-reading cond row."""
+    u32, r32 = cfg2_models_f32
+    y, banks = _hip_cfg2_forward(u32, r32, cfg2_oracle)
+    for i, (b, b_ref) in enumerate(zip(banks, cfg2_oracle["banks"])):
+        # the oracle's banks are already rounded through fp16, the writer's are rounded by update(): compare at fp16 resolution
+        torch.testing.assert_close(b.half().float(), b_ref, rtol=2e-3, atol=2e-3, msg=lambda m, i=i: f"bank {i}: {m}")
+    ref_y = cfg2_oracle["y"]
+    e = (y - ref_y).abs()
+    print(f"cfg2 full size f32 vs oracle: max {float(e.max()):.3e} mean {float(e.mean()):.3e} (mean |ref| {float(ref_y.abs().mean()):.3f})")
+    torch.testing.assert_close(y, ref_y, rtol=1e-3, atol=1e-4)
+    assert float((ref_y[0] - ref_y[1]).abs().mean()) > 1e-2       # the text and the banks are live in the oracle's cond row
+
+
+def test_cfg2_full_unet_bf16_vs_oracle(cfg2_models, cfg2_oracle):
+    """The BENCHMARKED dtype against the same oracle output: inside the low-precision yard-stick (the reference's own bf16 error on
+    the tiny motion UNet relative to its output scale, tests/golden/unet_tiny.safetensors motion/out_bf16)."""
+    unet, ref = cfg2_models
+    y, _ = _hip_cfg2_forward(unet, ref, cfg2_oracle)
+    ref_y = cfg2_oracle["y"]
+    e = (y - ref_y).abs()
+    print(f"cfg2 full size bf16 vs oracle: max {float(e.max()):.3e} mean {float(e.mean()):.3e} (mean |ref| {float(ref_y.abs().mean()):.3f}, "
+          f"max |ref| {float(ref_y.abs().max()):.3f})")
+    check(y, ref_y, torch.bfloat16)

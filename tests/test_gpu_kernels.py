@@ -806,6 +806,43 @@ def test_attention_two_query_tiles_per_wave(dtype, d):
     close(got, ref, dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("d,per_tile_log2", [(40, 7.0), (40, 9.0), (80, 7.0)])
+def test_attention_thresholded_rescale_score_ramp(dtype, d, per_tile_log2):
+    """The worst case of the THRESHOLDED online softmax (attention.hip ATT_TAU = 8 log2 units): every row's maximum climbs by
+    `per_tile_log2` per 64-key tile over many tiles.  At 7 the running reference never moves after the first tile of a run, so P
+    reaches 2^7..2^8 before the 2-byte pack and the denominator row accumulates those values; at 9 every tile takes the rescale
+    branch.  Both against an f32 softmax of the same (quantised) inputs: the bound of the un-rescaled path is pinned on its own,
+    not only through the model-level tests."""
+    o = ops()
+    B, Lq, Lk, heads = 2, 256, 64 * 24 + 13, 2
+    C_ = heads * d
+    scale = d ** -0.5
+    qq = 0.25 * seeded_randn((B, Lq, C_), 61)
+    kk = 0.25 * seeded_randn((B, Lk, C_), 62)
+    vv = seeded_randn((B, Lk, C_), 63)
+    # one channel per head carries the ramp: q = A, k_j = ramp_j / (A * scale) -> score_j = ramp_j (+ the small random part)
+    A = 4.0
+    ramp = (torch.arange(Lk, dtype=torch.float32) / 64.0) * per_tile_log2 * math.log(2.0)
+    for h in range(heads):
+        qq[:, :, h * d] = A
+        kk[:, :, h * d] = ramp / (A * scale)
+    qq, kk, vv = q(qq, dtype), q(kk, dtype), q(vv, dtype)
+    sp = lambda t: t.reshape(B, -1, heads, d).permute(0, 2, 1, 3)
+    ref = attn_ref(sp(qq).double(), sp(kk).double(), sp(vv).double(), scale).float().permute(0, 2, 1, 3).reshape(B * Lq, C_)
+    ld = (Lk + 7) // 8 * 8
+    vt = torch.zeros(B, C_, ld)
+    vt[:, :, :Lk] = vv.permute(0, 2, 1)
+    dv = lambda t: t.to(DEV).to(dtype)
+    got = o.attention(dv(qq.reshape(-1, C_)), dv(kk.reshape(-1, C_)), dv(vt), Lk, B=B, Lq=Lq, heads=heads, d=d, scale=scale)
+    close(got, ref, dtype)
+    # ... and with the ramp continuing through a second (bank) segment
+    got2 = o.attention(dv(qq.reshape(-1, C_)), dv(kk[:, :640].reshape(-1, C_)), dv(vt[:, :, :640].contiguous()), 640, B=B, Lq=Lq, heads=heads, d=d,
+                       scale=scale, k1=dv(kk[:, 640:].reshape(-1, C_)), v1t=dv(vt[:, :, 640:].contiguous()), Lk1=Lk - 640, seg1_div=1,
+                       seg1_first_batch=0)
+    close(got2, ref, dtype)
+
+
 def test_attention_online_softmax_rescale_forced():
     """Spike one key late in the sequence so the running max jumps in a later KV tile (rescale branch)."""
     o = ops()

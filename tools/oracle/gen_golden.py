@@ -159,11 +159,13 @@ def gen_ints():
     # update coefficients of oracle/scheduler_ref.py, so that a silent change of either restatement is caught
     from oracle.scheduler_ref import SchedulerRef
     out["scheduler_tables"] = {}
-    for kind in ("ddim", "ddpm"):
+    # "ddim" / "ddpm": steps_offset 1, as the pipeline ctor forces it on every scheduler that carries the key
+    # (EMOAnimationPipeline.py:105-117); "ddpm0": a DDPM scheduler stepped outside the pipeline (diffusers' default offset 0)
+    for name, kind, off in (("ddim", "ddim", 1), ("ddpm", "ddpm", 1), ("ddpm0", "ddpm", 0)):
         for n in (50, 25, 3):
-            sch = SchedulerRef(kind)
+            sch = SchedulerRef(kind, steps_offset=off)
             ts = sch.set_timesteps(n)
-            out["scheduler_tables"][f"{kind}_{n}"] = dict(timesteps=[int(t) for t in ts],
+            out["scheduler_tables"][f"{name}_{n}"] = dict(timesteps=[int(t) for t in ts],
                                                           coefficients=[[float(c) for c in sch.coefficients(t)] for t in ts])
     # pairing order of the reference-attention banks
     out["bank_order_tiny_midup"] = module_names(tiny, sorted_blocks(tiny, "midup"))
