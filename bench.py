@@ -164,17 +164,38 @@ def parity_vs_oracle(unet, x, ctx, y_ref):
     return out
 
 
+def _sysfs_card(index=0):
+    """/sys/class/drm/cardN/device of the torch device `index`: matched by PCI address (a box of this pool shows all 8 cards of its
+    node in sysfs while the container sees one GPU); None if it cannot be told."""
+    import glob
+    cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+    if not cards:
+        return None
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+        for c in cards:
+            if want in os.path.realpath(os.path.dirname(c)).lower():
+                return os.path.dirname(c)
+    except Exception:
+        pass
+    return os.path.dirname(cards[0]) if len(cards) == 1 else None
+
+
+_CARD = {}
+
+
 def gpu_clocks(index=0):
     """Current shader / memory clock of the GPU (MHz) from the amdgpu sysfs tables (the line marked '*' in pp_dpm_sclk /
     pp_dpm_mclk); None where the node is not readable.  Compute-bound kernels move with SCLK, HBM-bound ones do not - boxes of
     this pool differ by ~8 % on the same build, so the line says which clocks it was measured at."""
-    import glob
     import re
-    cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-    if not cards:
+    if index not in _CARD:
+        _CARD[index] = _sysfs_card(index)
+    base = _CARD[index]
+    if base is None:
         return None
-    base = os.path.dirname(cards[min(index, len(cards) - 1)])
-    out = {}
+    out = {"card": os.path.basename(os.path.dirname(base))}
     for key, fn in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
         try:
             cur = [ln for ln in open(os.path.join(base, fn)).read().splitlines() if ln.strip().endswith("*")]
@@ -211,7 +232,8 @@ class ClockSampler:
         def agg(k):
             v = [s[k] for s in self.samples if s.get(k)]
             return {"min": min(v), "max": max(v), "mean": sum(v) / len(v)} if v else None
-        return {"samples": len(self.samples), "sclk_mhz": agg("sclk_mhz"), "mclk_mhz": agg("mclk_mhz")}
+        return {"samples": len(self.samples), "card": self.samples[0].get("card") if self.samples else None,
+                "sclk_mhz": agg("sclk_mhz"), "mclk_mhz": agg("mclk_mhz")}
 
 
 def _profile_of_this_build(pattern):
