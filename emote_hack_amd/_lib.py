@@ -96,6 +96,8 @@ SIGNATURES = {
     "emo_softmax_rows": (_i, [_p, _i64, _p, _i64, _i64, _i, _f, _i, _p]),
     "emo_audio_windows": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "emo_rows_to_video": (_i, [_p, _i64, _p, _i, _i, _i, _i, _f, _f, _f, _f, _i, _p]),
+    "emo_channelnorm_workspace_bytes": (C.c_size_t, [_i64, _i]),
+    "emo_channelnorm": (_i, [_p, _i64, _p, _p, _p, _i64, _i64, _i, _f, _i, _p, _i, _p]),
     "emo_maxpool2x2": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _i, _i, _p]),
     "emo_bilinear_to_nchw": (_i, [_p, _i64, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
 }

@@ -4,18 +4,18 @@
 
 static inline int cgrid(int64_t n) { int64_t g = (n + 255) / 256; return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g)); }
 
-// act: 0 = SiLU, 1 = ReLU, 2 = tanh
+// act: 0 = SiLU, 1 = ReLU, 2 = tanh, 3 = erf-GELU (the wav2vec2 front-end's activation)
 template <typename T>
 __global__ void act_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, int kind) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float v = TT<T>::ld(x + i);
-    v = kind == 0 ? silu_f(v) : (kind == 1 ? fmaxf(v, 0.f) : tanhf(v));
+    v = kind == 0 ? silu_f(v) : (kind == 1 ? fmaxf(v, 0.f) : (kind == 2 ? tanhf(v) : gelu_for<T>(v)));
     TT<T>::st(y + i, v);
   }
 }
 extern "C" int emo_act(const void* x, void* y, int64_t n, int kind, int dtype, void* stream) {
   EMO_CHECK(x && y, EMO_ERR_NULL, "emo_act: null pointer");
-  EMO_CHECK(n > 0 && kind >= 0 && kind <= 2, EMO_ERR_BAD_SHAPE, "emo_act: n=%lld kind=%d", (long long)n, kind);
+  EMO_CHECK(n > 0 && kind >= 0 && kind <= 3, EMO_ERR_BAD_SHAPE, "emo_act: n=%lld kind=%d", (long long)n, kind);
   EMO_DISPATCH(dtype, "emo_act", (act_kernel<T><<<cgrid(n), 256, 0, as_stream(stream)>>>((const T*)x, (T*)y, n, kind)));
   EMO_LAUNCH_CHECK();
   return EMO_OK;

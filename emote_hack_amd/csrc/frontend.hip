@@ -7,6 +7,9 @@
 //                        (Net.py:649-667 Wav2VecFeatureExtractor.extract_features_from_wav) - pure indexing, bit-exact
 //   emo_rows_to_video  : decoded NHWC rows -> (B, C, F, H, W) f32 with video = (x / 2 + 0.5).clamp(0, 1)
 //                        (EMOAnimationPipeline.py:303-306)
+//   emo_channelnorm    : per-CHANNEL normalisation over the rows of a sequence (nn.GroupNorm(C, C) on (1, C, T): the first conv
+//                        layer of the wav2vec2 feature extractor, transformers Wav2Vec2GroupNormConvLayer) + affine + optional
+//                        erf-GELU; chunk partials in f32, re-reduced in f64 in a fixed order by every apply block (deterministic)
 // All HBM-bound and tiny; 16-byte accesses where the geometry allows.
 #include "common.h"
 
@@ -187,6 +190,88 @@ extern "C" int emo_bilinear_to_nchw(const void* x, int64_t ld, float* y, int n_i
   EMO_CHECK(emo_dtype_ok(dtype), EMO_ERR_BAD_DTYPE, "emo_bilinear_to_nchw: dtype %d", dtype);
   const int64_t total = (int64_t)n_img * C * Ho * Wo;
   EMO_DISPATCH(dtype, "emo_bilinear_to_nchw", (bilinear_kernel<T><<<fgrid(total, 256), 256, 0, as_stream(stream)>>>((const T*)x, ld, y, n_img, C, h, w, Ho, Wo)));
+  EMO_LAUNCH_CHECK();
+  return EMO_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------- channel norm
+// x rows (S, C): y[s, c] = act((x[s, c] - mean_c) * rstd_c * gamma_c + beta_c), statistics over the S rows of each channel
+// (biased variance, like nn.GroupNorm).  Pass 1: block (chunk, column slab of 64 channels) -> partial (sum, sumsq) per channel.
+// Pass 2: every block re-reduces the chunk partials of its slab in f64 in chunk order, then normalises its rows.
+static constexpr int CN_COLS = 64, CN_ROWS_T = 4;   // 256 threads = 64 channels x 4 row lanes
+
+template <typename T>
+__global__ __launch_bounds__(256) void channelnorm_stats_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ part, int64_t S, int C, int nchunk) {
+  const int c = blockIdx.y * CN_COLS + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int64_t per = (S + nchunk - 1) / nchunk, s0 = blockIdx.x * per, s1 = s0 + per < S ? s0 + per : S;
+  float sum = 0.f, sq = 0.f;
+  if (c < C)
+    for (int64_t s_ = s0 + rl; s_ < s1; s_ += CN_ROWS_T) {
+      const float v = TT<T>::ld(x + s_ * ldx + c);
+      sum += v; sq = fmaf(v, v, sq);
+    }
+  __shared__ float sh[2][CN_ROWS_T][CN_COLS];
+  sh[0][rl][threadIdx.x & 63] = sum; sh[1][rl][threadIdx.x & 63] = sq;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int r = 0; r < CN_ROWS_T; r++) { a += sh[0][r][threadIdx.x]; b += sh[1][r][threadIdx.x]; }
+    part[((int64_t)blockIdx.x * C + c) * 2] = a;
+    part[((int64_t)blockIdx.x * C + c) * 2 + 1] = b;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void channelnorm_apply_kernel(const T* __restrict__ x, int64_t ldx, const float* __restrict__ part,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y,
+                                                                int64_t ldy, int64_t S, int C, int nchunk, float eps, int act) {
+  const int cl = threadIdx.x & 63, c = blockIdx.y * CN_COLS + cl, rl = threadIdx.x >> 6;
+  __shared__ float sc[CN_COLS], sf[CN_COLS];
+  if (rl == 0 && c < C) {
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nchunk; k++) { a += (double)part[((int64_t)k * C + c) * 2]; b += (double)part[((int64_t)k * C + c) * 2 + 1]; }
+    const double mean = a / (double)S;
+    double var = b / (double)S - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    sc[cl] = rstd * gamma[c];
+    sf[cl] = beta[c] - (float)mean * rstd * gamma[c];
+  }
+  __syncthreads();
+  if (c >= C) return;
+  const float k = sc[cl], o = sf[cl];
+  for (int64_t s_ = (int64_t)blockIdx.x * CN_ROWS_T + rl; s_ < S; s_ += (int64_t)gridDim.x * CN_ROWS_T) {
+    float v = fmaf(TT<T>::ld(x + s_ * ldx + c), k, o);
+    if (act == 1) v = gelu_for<T>(v);
+    TT<T>::st(y + s_ * ldy + c, v);
+  }
+}
+
+extern "C" size_t emo_channelnorm_workspace_bytes(int64_t S, int C) {
+  int64_t n = (S + 255) / 256;
+  if (n > 64) n = 64;
+  if (n < 1) n = 1;
+  return (size_t)n * C * 2 * sizeof(float);
+}
+extern "C" int emo_channelnorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy, int64_t S, int C, float eps,
+                               int act, void* workspace, int dtype, void* stream) {
+  EMO_CHECK(x && gamma && beta && y && workspace, EMO_ERR_NULL, "emo_channelnorm: null pointer");
+  EMO_CHECK(S > 0 && C > 0 && ldx >= C && ldy >= C && (act == 0 || act == 1), EMO_ERR_BAD_SHAPE, "emo_channelnorm: S=%lld C=%d act=%d", (long long)S, C, act);
+  int64_t n = (S + 255) / 256;
+  if (n > 64) n = 64;
+  if (n < 1) n = 1;
+  const dim3 g1((unsigned)n, (unsigned)((C + CN_COLS - 1) / CN_COLS));
+  int64_t nb = (S + CN_ROWS_T * 16 - 1) / (CN_ROWS_T * 16);
+  if (nb > 512) nb = 512;
+  if (nb < 1) nb = 1;
+  const dim3 g2((unsigned)nb, g1.y);
+  hipStream_t st = as_stream(stream);
+  EMO_DISPATCH(dtype, "emo_channelnorm", (channelnorm_stats_kernel<T><<<g1, 256, 0, st>>>((const T*)x, ldx, (float*)workspace, S, C, (int)n)));
+  EMO_LAUNCH_CHECK();
+  EMO_DISPATCH(dtype, "emo_channelnorm", (channelnorm_apply_kernel<T><<<g2, 256, 0, st>>>((const T*)x, ldx, (const float*)workspace, gamma, beta, (T*)y, ldy, S, C,
+                                                                                               (int)n, eps, act)));
   EMO_LAUNCH_CHECK();
   return EMO_OK;
 }

@@ -453,7 +453,7 @@ def accumulate_window(pred_rows, noise_pred_branch, counter, frames_i32, *, C_, 
 
 
 # ----------------------------------------------------------------------------- EMO conditioning ops (A17/A18)
-_ACT = {"silu": 0, "relu": 1, "tanh": 2}
+_ACT = {"silu": 0, "relu": 1, "tanh": 2, "gelu": 3}
 
 
 def act(x: torch.Tensor, kind: str) -> torch.Tensor:
@@ -522,6 +522,20 @@ def rows_to_video(x: torch.Tensor, B, Cc, F, H, W, mul=0.5, add=0.5, lo=0.0, hi=
     y = torch.empty(B, Cc, F, H, W, device=x.device, dtype=torch.float32)
     check(_lib.load().emo_rows_to_video(px, ld, _ptr(y), B, Cc, F, H * W, float(mul), float(add), float(lo), float(hi), dt(x), _stream()),
           "emo_rows_to_video")
+    return y
+
+
+def channel_norm(x: torch.Tensor, gamma, beta, eps=1e-5, gelu=False) -> torch.Tensor:
+    """nn.GroupNorm(C, C) over a sequence: x rows (S, C) normalised per channel over the S rows, affine, optional erf-GELU (emo_channelnorm)."""
+    _need_cuda(x)
+    lib = _lib.load()
+    S, Cc = x.shape
+    px, ldx = _rows(x)
+    y = torch.empty(S, Cc, device=x.device, dtype=x.dtype)
+    ws = torch.empty(max(lib.emo_channelnorm_workspace_bytes(S, Cc) // 4, 1), device=x.device, dtype=torch.float32)
+    _launch("channelnorm", 0.0, x.element_size() * 3.0 * S * Cc,
+            lambda: check(lib.emo_channelnorm(px, ldx, _ptr(gamma), _ptr(beta), _ptr(y), Cc, S, Cc, float(eps), int(bool(gelu)), _ptr(ws), dt(x), _stream()),
+                          "emo_channelnorm"))
     return y
 
 

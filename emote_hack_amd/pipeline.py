@@ -812,8 +812,8 @@ class EMOAnimationPipeline:
         scope here: text_embeddings=(2,L,D), ref_image_latents=(1,4,h,w), audio_features=(F,L_a,D),
         speed_embeddings=(1,4*C0), seed=int; dist/rank/world_size as in the reference (:636-638).  Execution knobs (all
         optional): use_graphs (default: HIP-graph replay on a HIP device - the path bench.py measures), reference_group
-        (ReferenceNet timesteps per batched pass; default 25 here - a whole 50-step clip makes two passes, 40.03 vs 40.38 ms per step at 10 -
-        `prepare_denoise` / bench.py keep 10 so that any 20-step window holds its fair share), reference_lookahead, fusion_blocks, motion_latents, reuse_state
+        (ReferenceNet timesteps per batched pass; default 10, the configuration bench.py measures - 25 would make two passes per 50-step clip,
+        40.03 vs 40.38 ms per step), reference_lookahead, fusion_blocks, motion_latents, reuse_state
         (default True: a second call with the same geometry reuses the prepared plan and its captured graphs)."""
         height = height or self.unet.config.sample_size * self.vae_scale_factor
         width = width or self.unet.config.sample_size * self.vae_scale_factor
@@ -845,7 +845,17 @@ class EMOAnimationPipeline:
                 raise ValueError("pass ref_image_latents=(1,4,h,w) (no VAE in this build)")
             ref_lat = self._source_image_latents(source_image, width, height)   # :686-689 -> images2latents (:402-414)
         if audio is not None and kwargs.get("audio_features") is None:
-            raise NotImplementedError("wav2vec feature extraction is out of scope: pass audio_features=")
+            # :592-593 `audio_features = feature_extractor.extract_features_from_mp4(audio, m=2, n=2)` (a module-level extractor
+            # there): here `audio` is the mono 16 kHz waveform (the container demux / resampling of Net.py:670-735 stays with the
+            # caller) and feature_extractor= an emote_hack_amd.wav2vec2.Wav2VecFeatureExtractor with caller-loaded weights
+            fx = kwargs.get("feature_extractor")
+            if fx is None:
+                raise ValueError("audio= needs feature_extractor= (emote_hack_amd.wav2vec2.Wav2VecFeatureExtractor), or pass audio_features=")
+            if isinstance(audio, (str, bytes)):
+                raise ValueError("audio= takes the decoded mono 16 kHz waveform (file reading / demuxing is outside this path)")
+            from .conditioning import audio_context_tokens
+            windows = fx.extract_features(audio, m=2, n=2)
+            kwargs["audio_features"] = audio_context_tokens(windows, video_length, fx.model.config.hidden_size)
         if head_rotation_speeds is not None and kwargs.get("speed_embeddings") is None:
             raise NotImplementedError("pass speed_embeddings= (see emote_hack_amd.conditioning.SpeedEncoder)")
         if init_latents is not None:   # (b f) c h w -> b c f h w  (:657-658)

@@ -253,8 +253,9 @@ int emo_accumulate_window(const void* pred, int ld, float* noise_pred_branch, fl
                           int nf, int C, int F, int HW, int add_counter, int dtype, void* stream);
 
 /* ---- EMO conditioning ----------------------------------------------
- * emo_act: y = act(x), kind 0 SiLU | 1 ReLU | 2 tanh over n contiguous elements (the ReLU / tanh of
- *   Net.py:214-218,246 and train_stage_3_speedlayers.py:36-40,66-73).
+ * emo_act: y = act(x), kind 0 SiLU | 1 ReLU | 2 tanh | 3 erf-GELU over n contiguous elements (the ReLU / tanh of
+ *   Net.py:214-218,246 and train_stage_3_speedlayers.py:36-40,66-73; GELU: the activation of the wav2vec2 encoder
+ *   Net.py:611-612 loads - transformers Wav2Vec2FeedForward / conv layers).
  * emo_speed_encode: SpeedEncoder.encode_speed (Net.py:231-247): out[b,i] = tanh((v[b]-centers[i])/radii[i]*3).
  * emo_speed_bucket: SpeedController.map_speed_to_bucket (train_stage_3_speedlayers.py:42-47), INT bit-exact:
  *   idx[b] = argmin_i |v[b] - centers[i]| (first minimum on ties).
@@ -278,6 +279,12 @@ int emo_softmax_rows(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t M
 int emo_audio_windows(const void* feats, void* out, int T, int D, int m, int n, int dtype, void* stream);
 int emo_rows_to_video(const void* x, int64_t ld, float* y, int B, int C, int F, int HW, float mul, float add, float lo, float hi,
                       int dtype, void* stream);
+/* emo_channelnorm: per-channel normalisation over the S rows of a sequence, y = act((x - mean_c) * rstd_c * gamma_c + beta_c), act 0 none |
+ * 1 erf-GELU: nn.GroupNorm(C, C) on (1, C, T) - the first conv layer of the wav2vec2 feature extractor behind
+ * Wav2VecFeatureExtractor (Net.py:607-648; transformers Wav2Vec2GroupNormConvLayer).  workspace: emo_channelnorm_workspace_bytes(S, C). */
+size_t emo_channelnorm_workspace_bytes(int64_t S, int C);
+int emo_channelnorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy, int64_t S, int C, float eps,
+                    int act, void* workspace, int dtype, void* stream);
 /* FaceLocator (Net.py:819-855): nn.MaxPool2d(2, 2) over NHWC rows (H, W -> H/2, W/2), and
  * F.interpolate(logits, size=(Ho, Wo), mode='bilinear', align_corners=False) of rows ((n) h w, ld) into (n, C, Ho, Wo) f32. */
 int emo_maxpool2x2(const void* x, int64_t ldx, void* y, int64_t ldy, int n_img, int H, int W, int C, int dtype, void* stream);

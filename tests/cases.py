@@ -54,3 +54,7 @@ WINDOW_CASES = [(12, 16, 1, 4), (24, 16, 1, 4), (48, 16, 1, 4), (48, 12, 1, 0), 
                 (48, 16, 2, 4), (40, 16, 3, 4), (17, 16, 1, 4)]  # (F_tot, ctx, stride, overlap)
 
 SPEEDS = [-1.0, -0.13, 0.0, 0.07, 0.49, 2.0, 0.125, -0.125, 0.375, -0.875, -3.0, 0.999]
+
+# a 2-layer member of the wav2vec2-base family (feat_extract_norm "group", post-LN): fast CPU check of oracle/wav2vec2_ref.py
+WAV2VEC2_TINY = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, conv_dim=(32,) * 7,
+                     num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4)

@@ -380,3 +380,24 @@ def test_denoise_loop_wrapped_window_is_deterministic():
     finally:
         torch.set_num_threads(n)
     close(a, b, 1e-5, 1e-6)   # thread count only changes the f32 summation order inside the GEMMs
+
+
+# ----------------------------------------------------------------------------- wav2vec2 front-end
+def test_wav2vec2_oracle_matches_transformers_goldens():
+    """oracle/wav2vec2_ref.py against the outputs of transformers' own Wav2Vec2Model (the third-party class Net.py:607-612 loads;
+    tools/oracle/gen_golden_wav2vec2.py): the 2-layer member of the base family, the full wav2vec2-base configuration on 1 s of
+    audio (94 M name-keyed synthetic parameters, regenerated here), the utterance normalisation of its processor and the
+    reference's own windowing (Net.py:646-667)."""
+    from emote_hack_amd.wav2vec2 import wav2vec2_synth_state_dict
+    from oracle import wav2vec2_ref as W
+    g = load_file(os.path.join(cases.GOLDEN_DIR, "wav2vec2.safetensors"))
+    with torch.no_grad():
+        y = W.wav2vec2_forward(wav2vec2_synth_state_dict(cases.WAV2VEC2_TINY), cases.WAV2VEC2_TINY, 0.5 * seeded_randn((1, 4000), 501))
+        torch.testing.assert_close(y, g["tiny/out"], rtol=1e-4, atol=1e-5)
+        sd = wav2vec2_synth_state_dict({})
+        wave = 0.1 * seeded_randn((16000,), 502) + 0.05 * torch.sin(torch.arange(16000) * 0.05)
+        torch.testing.assert_close(W.normalize_waveform(wave.reshape(1, -1)), g["base/input_values"], rtol=1e-5, atol=1e-6)
+        yb = W.wav2vec2_forward(sd, {}, g["base/input_values"])
+        torch.testing.assert_close(yb, g["base/out"], rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(W.audio_features(sd, {}, wave), g["base/features"], rtol=1e-3, atol=1e-4)
+    assert float(g["base/out"].std()) > 0.5        # a live signal, not a constant
