@@ -37,6 +37,11 @@ class TransformerSpec:
     # proj_in and norm1 (whose output is the last bank) and nothing else - attn1 projections are parameter-less, attn2 is None,
     # norm2 / norm3 / ff / proj_out are Identity.  Everything behind its LN1 is dead (the ReferenceNet output is discarded).
     gutted: bool = False
+    # VideoNet only (models/videonet.py:132-196): the attention slot holds a ReferenceConditionedAttentionBlock - this transformer
+    # is its `cross_attn` child (prefix ends in ".cross_attn"), with a SpatialAttentionModule `sam` in front and a motion module
+    # `tam` behind it (prefixes of the siblings; None in a plain UNet)
+    sam: Optional[str] = None
+    tam: Optional["MotionSpec"] = None
 
 
 @dataclass
@@ -46,6 +51,7 @@ class MotionSpec:
     heads: int
     n_attn: int
     pe_len: Optional[int]
+    n_blocks: int = 1      # TemporalTransformer3DModel num_layers (configs/inference.yaml: 1; models/motionmodule.py default: 2)
 
 
 @dataclass
@@ -85,10 +91,8 @@ def build_spec(cfg_kwargs, *, has_out=True, controlnet=None, gut_last_transforme
         if heads * head_dim != c:
             raise NotImplementedError("motion module inner_dim != in_channels")
         return MotionSpec(prefix, c, heads, len(mmk["attention_block_types"]),
-                          mmk["temporal_position_encoding_max_len"] if mmk["temporal_position_encoding"] else None)
-
-    if cfg["use_motion_module"] and mmk["num_transformer_block"] != 1:
-        raise NotImplementedError("num_transformer_block != 1 (configs/inference.yaml:13 uses 1)")
+                          mmk["temporal_position_encoding_max_len"] if mmk["temporal_position_encoding"] else None,
+                          int(mmk["num_transformer_block"]))
 
     def tfm(prefix, c, heads):
         if c % heads:
@@ -177,6 +181,25 @@ def _attn_shapes(p, c, kv, d):
     d[f"{p}.to_out.0.bias"] = (c,)
 
 
+def _sam_shapes(p, c, d):
+    """SpatialAttentionModule(num_inp_channels=c, embed_dim=c) (models/videonet.py:15-37), module registration order."""
+    d[f"{p}.norm_in.weight"] = (c,)
+    d[f"{p}.norm_in.bias"] = (c,)
+    d[f"{p}.proj_in.weight"] = (c, c, 1, 1)
+    d[f"{p}.proj_in.bias"] = (c,)
+    for n in ("to_q", "to_k", "to_v"):
+        d[f"{p}.{n}.weight"] = (c, c)
+        d[f"{p}.{n}.bias"] = (c,)
+    d[f"{p}.norm1.weight"] = (c,)
+    d[f"{p}.norm1.bias"] = (c,)
+    d[f"{p}.ffn.weight"] = (c, c)
+    d[f"{p}.ffn.bias"] = (c,)
+    d[f"{p}.norm2.weight"] = (c,)
+    d[f"{p}.norm2.bias"] = (c,)
+    d[f"{p}.proj_out.weight"] = (c, c, 1, 1)
+    d[f"{p}.proj_out.bias"] = (c,)
+
+
 def _transformer_shapes(t: TransformerSpec, d):
     p, c = t.prefix, t.channels
     d[f"{p}.norm.weight"] = (c,)
@@ -207,16 +230,17 @@ def _motion_shapes(m: MotionSpec, d):
     d[f"{p}.norm.bias"] = (c,)
     d[f"{p}.proj_in.weight"] = (c, c)
     d[f"{p}.proj_in.bias"] = (c,)
-    tb = f"{p}.transformer_blocks.0"
-    for k in range(m.n_attn):
-        _attn_shapes(f"{tb}.attention_blocks.{k}", c, c, d)
-        if m.pe_len:
-            d[f"{tb}.attention_blocks.{k}.pos_encoder.pe"] = (1, m.pe_len, c)
-        d[f"{tb}.norms.{k}.weight"] = (c,)
-        d[f"{tb}.norms.{k}.bias"] = (c,)
-    _ff_shapes(f"{tb}.ff", c, d)
-    d[f"{tb}.ff_norm.weight"] = (c,)
-    d[f"{tb}.ff_norm.bias"] = (c,)
+    for b in range(m.n_blocks):
+        tb = f"{p}.transformer_blocks.{b}"
+        for k in range(m.n_attn):
+            _attn_shapes(f"{tb}.attention_blocks.{k}", c, c, d)
+            if m.pe_len:
+                d[f"{tb}.attention_blocks.{k}.pos_encoder.pe"] = (1, m.pe_len, c)
+            d[f"{tb}.norms.{k}.weight"] = (c,)
+            d[f"{tb}.norms.{k}.bias"] = (c,)
+        _ff_shapes(f"{tb}.ff", c, d)
+        d[f"{tb}.ff_norm.weight"] = (c,)
+        d[f"{tb}.ff_norm.bias"] = (c,)
     d[f"{p}.proj_out.weight"] = (c, c)
     d[f"{p}.proj_out.bias"] = (c,)
 
@@ -257,7 +281,11 @@ def param_shapes(spec: UNetSpec) -> "OrderedDict[str, tuple]":
             _resnet_shapes(r, d)
         for a in b.attentions:
             if a is not None:
-                _transformer_shapes(a, d)
+                _transformer_shapes(a, d)      # (VideoNet: ReferenceConditionedAttentionBlock registers cross_attn, sam, tam in this order)
+                if a.sam is not None:
+                    _sam_shapes(a.sam, a.channels, d)
+                if a.tam is not None:
+                    _motion_shapes(a.tam, d)
         for m in b.motions:
             if m is not None:
                 _motion_shapes(m, d)

@@ -330,35 +330,47 @@ class UNet3DConditionModel:
                 else:
                     w[tb + ".attn2.q"] = lin(tb + ".attn2.to_q.weight")
                     w[tb + ".ff1.w"], w[tb + ".ff1.b"] = geglu(tb + ".ff.net.0.proj")
-            for mo in blk.motions:
+            for mo in list(blk.motions) + [a.tam for a in blk.attentions if a is not None and a.tam is not None]:
                 if mo is None:
                     continue
                 p = mo.prefix + ".temporal_transformer"
-                tb = p + ".transformer_blocks.0"
                 w[p + ".norm.g"], w[p + ".norm.b"] = f32(p + ".norm.weight"), f32(p + ".norm.bias")
                 w[p + ".proj_in.w"], w[p + ".proj_in.b"] = lin(p + ".proj_in.weight"), f32(p + ".proj_in.bias")
                 w[p + ".proj_out.w"], w[p + ".proj_out.b"] = lin(p + ".proj_out.weight"), f32(p + ".proj_out.bias")
-                for k in range(mo.n_attn):
-                    ab = f"{tb}.attention_blocks.{k}"
-                    wqkv = torch.cat([m[ab + ".to_q.weight"], m[ab + ".to_k.weight"], m[ab + ".to_v.weight"]], 0)
-                    w[ab + ".o.w"], w[ab + ".o.b"] = lin(ab + ".to_out.0.weight"), f32(ab + ".to_out.0.bias")
+                for bi in range(mo.n_blocks):
+                    tb = f"{p}.transformer_blocks.{bi}"
+                    for k in range(mo.n_attn):
+                        ab = f"{tb}.attention_blocks.{k}"
+                        wqkv = torch.cat([m[ab + ".to_q.weight"], m[ab + ".to_k.weight"], m[ab + ".to_v.weight"]], 0)
+                        w[ab + ".o.w"], w[ab + ".o.b"] = lin(ab + ".to_out.0.weight"), f32(ab + ".to_out.0.bias")
+                        if fold:
+                            w[ab + ".qkv_ln"] = ln_fold(wqkv, None, f"{tb}.norms.{k}")
+                            if mo.pe_len:   # (LN(x) + pe[f]) W^T = LN(x) W^T + (pe W^T)[f]: a per-frame row bias (motion_module.py:246-248,282-283)
+                                w[ab + ".pe_w"] = (m[ab + ".pos_encoder.pe"][0].float() @ wqkv.to(dtp).float().t()).contiguous()
+                        else:
+                            w[ab + ".qkv"] = wqkv.to(dtp).contiguous()
+                            w[f"{tb}.norms.{k}.g"], w[f"{tb}.norms.{k}.b"] = f32(f"{tb}.norms.{k}.weight"), f32(f"{tb}.norms.{k}.bias")
+                            if mo.pe_len:
+                                w[ab + ".pe"] = m[ab + ".pos_encoder.pe"][0].float().contiguous()
                     if fold:
-                        w[ab + ".qkv_ln"] = ln_fold(wqkv, None, f"{tb}.norms.{k}")
-                        if mo.pe_len:   # (LN(x) + pe[f]) W^T = LN(x) W^T + (pe W^T)[f]: a per-frame row bias (motion_module.py:246-248,282-283)
-                            w[ab + ".pe_w"] = (m[ab + ".pos_encoder.pe"][0].float() @ wqkv.to(dtp).float().t()).contiguous()
+                        w[tb + ".ff1_ln"] = geglu_ln(tb + ".ff.net.0.proj", tb + ".ff_norm")
                     else:
-                        w[ab + ".qkv"] = wqkv.to(dtp).contiguous()
-                        w[f"{tb}.norms.{k}.g"], w[f"{tb}.norms.{k}.b"] = f32(f"{tb}.norms.{k}.weight"), f32(f"{tb}.norms.{k}.bias")
-                        if mo.pe_len:
-                            w[ab + ".pe"] = m[ab + ".pos_encoder.pe"][0].float().contiguous()
-                if fold:
-                    w[tb + ".ff1_ln"] = geglu_ln(tb + ".ff.net.0.proj", tb + ".ff_norm")
-                else:
-                    w[tb + ".ff_norm.g"], w[tb + ".ff_norm.b"] = f32(tb + ".ff_norm.weight"), f32(tb + ".ff_norm.bias")
-                    w[tb + ".ff1.w"], w[tb + ".ff1.b"] = geglu(tb + ".ff.net.0.proj")
-                w[tb + ".ff2.w"], w[tb + ".ff2.b"] = lin(tb + ".ff.net.2.weight"), f32(tb + ".ff.net.2.bias")
-                if self._fuse_tail:
-                    w[tb + ".tail.w"], w[tb + ".tail.b"] = ff_tail(tb + ".ff.net.2", p + ".proj_out")
+                        w[tb + ".ff_norm.g"], w[tb + ".ff_norm.b"] = f32(tb + ".ff_norm.weight"), f32(tb + ".ff_norm.bias")
+                        w[tb + ".ff1.w"], w[tb + ".ff1.b"] = geglu(tb + ".ff.net.0.proj")
+                    w[tb + ".ff2.w"], w[tb + ".ff2.b"] = lin(tb + ".ff.net.2.weight"), f32(tb + ".ff.net.2.bias")
+                    if self._fuse_tail and bi == mo.n_blocks - 1:      # the LAST block's ff.net.2 composes with proj_out
+                        w[tb + ".tail.w"], w[tb + ".tail.b"] = ff_tail(tb + ".ff.net.2", p + ".proj_out")
+            for a in blk.attentions:      # VideoNet: the SpatialAttentionModule in front of each transformer (models/videonet.py:15-77)
+                if a is None or a.sam is None:
+                    continue
+                sp = a.sam
+                w[sp + ".norm_in.g"], w[sp + ".norm_in.b"] = f32(sp + ".norm_in.weight"), f32(sp + ".norm_in.bias")
+                for n_ in ("proj_in", "to_q", "ffn", "proj_out"):
+                    w[f"{sp}.{n_}.w"], w[f"{sp}.{n_}.b"] = lin(f"{sp}.{n_}.weight"), f32(f"{sp}.{n_}.bias")
+                w[sp + ".k.w"], w[sp + ".k.b"] = lin(sp + ".to_k.weight"), f32(sp + ".to_k.bias")
+                w[sp + ".v.w"], w[sp + ".v.b"] = lin(sp + ".to_v.weight"), f32(sp + ".to_v.bias")
+                for n_ in ("norm1", "norm2"):
+                    w[f"{sp}.{n_}.g"], w[f"{sp}.{n_}.b"] = f32(f"{sp}.{n_}.weight"), f32(f"{sp}.{n_}.bias")
             if blk.sampler:
                 w[blk.sampler + ".w"], w[blk.sampler + ".b"] = conv3(blk.sampler + ".conv.weight"), f32(blk.sampler + ".conv.bias")
         w["temb_all.w"] = torch.cat(temb_w, 0).to(dtp).contiguous()
@@ -547,35 +559,38 @@ class UNet3DConditionModel:
         if mo.pe_len and c.F > mo.pe_len:
             raise ValueError(f"video_length {c.F} exceeds temporal_position_encoding_max_len {mo.pe_len}")
         h = self._norm_proj_in(x, p, nb, HW, 32)  # norm_num_groups=32 default (:104)
-        for k in range(mo.n_attn):
-            ab = f"{tb}.attention_blocks.{k}"
-            if self._fold_ln:   # LN folded into the q|k|v projection, the positional encoding into a per-frame row bias
-                wq, cs, bq = w[ab + ".qkv_ln"]
-                kw = {}
-                if mo.pe_len:
-                    key = (ab, c.B, c.F)
-                    if key not in self._pe_rows:
-                        self._pe_rows[key] = w[ab + ".pe_w"][:c.F].repeat(c.B, 1).contiguous()
-                    kw = dict(rowbias=self._pe_rows[key], rows_per_batch=HW)
-                qkv = ops.gemm(h, wq, bq, ln=(cs, ops.layer_norm_stats(h, 1e-5)), **kw)
+        gh = None
+        for bi in range(mo.n_blocks):       # TemporalTransformer3DModel.transformer_blocks (motion_module.py:139-163; 1 in configs/inference.yaml)
+            tb = f"{p}.transformer_blocks.{bi}"
+            last_block = bi == mo.n_blocks - 1
+            g_out = h_out = None
+            for k in range(mo.n_attn):
+                ab = f"{tb}.attention_blocks.{k}"
+                if self._fold_ln:   # LN folded into the q|k|v projection, the positional encoding into a per-frame row bias
+                    wq, cs, bq = w[ab + ".qkv_ln"]
+                    kw = {}
+                    if mo.pe_len:
+                        key = (ab, c.B, c.F)
+                        if key not in self._pe_rows:
+                            self._pe_rows[key] = w[ab + ".pe_w"][:c.F].repeat(c.B, 1).contiguous()
+                        kw = dict(rowbias=self._pe_rows[key], rows_per_batch=HW)
+                    qkv = ops.gemm(h, wq, bq, ln=(cs, ops.layer_norm_stats(h, 1e-5)), **kw)
+                else:
+                    n = ops.layer_norm(h, w[f"{tb}.norms.{k}.g"], w[f"{tb}.norms.{k}.b"], pe=w.get(ab + ".pe"), rows_per_frame=HW, frames=c.F)
+                    qkv = ops.gemm(n, w[ab + ".qkv"])
+                att = ops.temporal_attention(qkv, c.B, c.F, HW, heads, d, d ** -0.5)
+                if last_block and k == mo.n_attn - 1:
+                    gh, g_out, h_out = self._tail_buffer(h, C_)
+                h = ops.gemm(att, w[ab + ".o.w"], w[ab + ".o.b"], residual=h, out=h_out)
+            if self._fold_ln:
+                wf, cs, bf = w[tb + ".ff1_ln"]
+                g = ops.gemm(h, wf, bf, geglu=True, ln=(cs, ops.layer_norm_stats(h, 1e-5)), out=g_out)
             else:
-                n = ops.layer_norm(h, w[f"{tb}.norms.{k}.g"], w[f"{tb}.norms.{k}.b"], pe=w.get(ab + ".pe"), rows_per_frame=HW, frames=c.F)
-                qkv = ops.gemm(n, w[ab + ".qkv"])
-            att = ops.temporal_attention(qkv, c.B, c.F, HW, heads, d, d ** -0.5)
-            if k == mo.n_attn - 1:
-                gh, g_out, h_out = self._tail_buffer(h, C_)
-            h = ops.gemm(att, w[ab + ".o.w"], w[ab + ".o.b"], residual=h, out=h_out if k == mo.n_attn - 1 else None)
-        if mo.n_attn == 0:
-            gh, g_out, h_out = None, None, None
-        if self._fold_ln:
-            wf, cs, bf = w[tb + ".ff1_ln"]
-            g = ops.gemm(h, wf, bf, geglu=True, ln=(cs, ops.layer_norm_stats(h, 1e-5)), out=g_out)
-        else:
-            n = ops.layer_norm(h, w[tb + ".ff_norm.g"], w[tb + ".ff_norm.b"])
-            g = ops.gemm(n, w[tb + ".ff1.w"], w[tb + ".ff1.b"], geglu=True, out=g_out)
-        if gh is not None:
-            return ops.gemm(gh, w[tb + ".tail.w"], w[tb + ".tail.b"], residual=x, out=out)
-        h = ops.gemm(g, w[tb + ".ff2.w"], w[tb + ".ff2.b"], residual=h)
+                n = ops.layer_norm(h, w[tb + ".ff_norm.g"], w[tb + ".ff_norm.b"])
+                g = ops.gemm(n, w[tb + ".ff1.w"], w[tb + ".ff1.b"], geglu=True, out=g_out)
+            if last_block and gh is not None:
+                return ops.gemm(gh, w[tb + ".tail.w"], w[tb + ".tail.b"], residual=x, out=out)
+            h = ops.gemm(g, w[tb + ".ff2.w"], w[tb + ".ff2.b"], residual=h)
         return ops.gemm(h, w[p + ".proj_out.w"], w[p + ".proj_out.b"], residual=x, out=out)
 
     # ------------------------------------------------------------------ forward (three stages so that the sampler can

@@ -182,27 +182,31 @@ def positional_encoding(d_model, max_len=24):
 
 def motion_module(sd, p, x, heads, groups=32, n_attn=2):
     """motion_module.py:82-87,139-163,215-227,275-334 (VanillaTemporalModule): per-frame GN(32,
-    eps 1e-6) -> Linear -> [LN -> (tokens (b hw) f c, +PE, temporal self-attn) -> +res] x n_attn
-    -> LN -> GEGLU FF -> +res -> Linear -> + residual."""
+    eps 1e-6) -> Linear -> num_transformer_block x { [LN -> (tokens (b hw) f c, +PE, temporal self-attn) -> +res] x n_attn
+    -> LN -> GEGLU FF -> +res } -> Linear -> + residual.  The block count is read off the state dict
+    (configs/inference.yaml: 1; the ctor default, which models/videonet.py:151-153 takes: 2)."""
     p = p + ".temporal_transformer"
     b, c, f, hh, ww = x.shape
     xf = x.permute(0, 2, 1, 3, 4).reshape(b * f, c, hh, ww)
     h = F.group_norm(xf, groups, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6)
     h = h.permute(0, 2, 3, 1).reshape(b * f, hh * ww, c)
     h = _lin(sd, p + ".proj_in", h)
-    tb = p + ".transformer_blocks.0"
     d = hh * ww
-    for k in range(n_attn):
-        n = F.layer_norm(h, (c,), sd[f"{tb}.norms.{k}.weight"], sd[f"{tb}.norms.{k}.bias"])
-        t = n.reshape(b, f, d, c).permute(0, 2, 1, 3).reshape(b * d, f, c)   # (b f) d c -> (b d) f c
-        pe_key = f"{tb}.attention_blocks.{k}.pos_encoder.pe"
-        if pe_key in sd:
-            t = t + sd[pe_key][:, :f]
-        a = attention(sd, f"{tb}.attention_blocks.{k}", t, None, heads)
-        a = a.reshape(b, d, f, c).permute(0, 2, 1, 3).reshape(b * f, d, c)
-        h = a + h
-    n = F.layer_norm(h, (c,), sd[tb + ".ff_norm.weight"], sd[tb + ".ff_norm.bias"])
-    h = feed_forward(sd, tb + ".ff", n) + h
+    bi = 0
+    while f"{p}.transformer_blocks.{bi}.ff_norm.weight" in sd:
+        tb = f"{p}.transformer_blocks.{bi}"
+        for k in range(n_attn):
+            n = F.layer_norm(h, (c,), sd[f"{tb}.norms.{k}.weight"], sd[f"{tb}.norms.{k}.bias"])
+            t = n.reshape(b, f, d, c).permute(0, 2, 1, 3).reshape(b * d, f, c)   # (b f) d c -> (b d) f c
+            pe_key = f"{tb}.attention_blocks.{k}.pos_encoder.pe"
+            if pe_key in sd:
+                t = t + sd[pe_key][:, :f]
+            a = attention(sd, f"{tb}.attention_blocks.{k}", t, None, heads)
+            a = a.reshape(b, d, f, c).permute(0, 2, 1, 3).reshape(b * f, d, c)
+            h = a + h
+        n = F.layer_norm(h, (c,), sd[tb + ".ff_norm.weight"], sd[tb + ".ff_norm.bias"])
+        h = feed_forward(sd, tb + ".ff", n) + h
+        bi += 1
     h = _lin(sd, p + ".proj_out", h)
     h = h.reshape(b * f, hh, ww, c).permute(0, 3, 1, 2) + xf
     return h.reshape(b, f, c, hh, ww).permute(0, 2, 1, 3, 4)
@@ -253,14 +257,16 @@ def transformer_block_order(cfg, fusion_blocks="midup"):
 def unet_forward(sd, cfg, sample, timestep, encoder_hidden_states, *, bank_mode=None, banks=None,
                  uc_rows=None, fusion_blocks="midup", down_block_additional_residuals=None,
                  mid_block_additional_residual=None, speed_embeddings=None, audio_features=None,
-                 return_banks=False):
+                 return_banks=False, attention_hook=None):
     """unet_controlnet.py:328-483 (UNet3DConditionModel.forward).
 
     bank_mode='write': returns (sample, {block_prefix: LN1 output}) - the ReferenceNet pass.
     bank_mode='read' : `banks` maps block_prefix -> (B_ref, L, C) tensor; `uc_rows` bool (B*F,).
     EMO extension (no reference behaviour): `audio_features` (B*F, L_a, D) replaces
     encoder_hidden_states as the per-frame attn2 context; `speed_embeddings` (B, 4*C0) is added to
-    the time embedding (class-embedding slot, unet_controlnet.py:400-408)."""
+    the time embedding (class-embedding slot, unet_controlnet.py:400-408).
+    attention_hook(prefix, x, ctx, heads): replaces the transformer of every attention slot (models/videonet.py:216-234 puts a
+    ReferenceConditionedAttentionBlock there - oracle/videonet_ref.py)."""
     cfg = normalize_config(cfg)
     boc, G, eps = cfg["block_out_channels"], cfg["norm_num_groups"], cfg["norm_eps"]
     hd = cfg["attention_head_dim"]
@@ -286,6 +292,8 @@ def unet_forward(sd, cfg, sample, timestep, encoder_hidden_states, *, bank_mode=
     written = {}
 
     def tf(p, x, heads):
+        if attention_hook is not None:
+            return attention_hook(p, x, ctx, heads)
         kw = dict(upcast=upc)
         if p in active:
             if bank_mode == "write":

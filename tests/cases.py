@@ -58,3 +58,7 @@ SPEEDS = [-1.0, -0.13, 0.0, 0.07, 0.49, 2.0, 0.125, -0.125, 0.375, -0.875, -3.0,
 # a 2-layer member of the wav2vec2-base family (feat_extract_norm "group", post-LN): fast CPU check of oracle/wav2vec2_ref.py
 WAV2VEC2_TINY = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, conv_dim=(32,) * 7,
                      num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4)
+
+# models/videonet.py: the 2-D UNet a VideoNet starts from (no motion modules; 8-head sam / tam need channels that are multiples of 64)
+VIDEONET_TINY = dict(sample_size=16, block_out_channels=(64, 64, 128, 128), norm_num_groups=32, attention_head_dim=8, cross_attention_dim=32,
+                     unet_use_cross_frame_attention=False, unet_use_temporal_attention=False)

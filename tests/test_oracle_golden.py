@@ -401,3 +401,57 @@ def test_wav2vec2_oracle_matches_transformers_goldens():
         torch.testing.assert_close(yb, g["base/out"], rtol=1e-3, atol=1e-4)
         torch.testing.assert_close(W.audio_features(sd, {}, wave), g["base/features"], rtol=1e-3, atol=1e-4)
     assert float(g["base/out"].std()) > 0.5        # a live signal, not a constant
+
+
+# ----------------------------------------------------------------------------- VideoNet (models/videonet.py)
+def _rcab_sd():
+    """weights of the golden's ReferenceConditionedAttentionBlock: name-keyed under the block's own key names, salt 'rcab.'"""
+    from emote_hack_amd.spec import param_shapes
+    from emote_hack_amd.unet import UNet3DConditionModel  # noqa: F401  (host-side structure walk only)
+    from emote_hack_amd.videonet import VideoNet
+    vn = VideoNet(cases.VIDEONET_TINY, num_frames=4)
+    slot = "down_blocks.0.attentions.0."
+    return synth_state_dict({k[len(slot):]: v for k, v in param_shapes(vn.spec).items() if k.startswith(slot)}, prefix="rcab.")
+
+
+def test_videonet_oracle_matches_the_reference_classes():
+    """oracle/videonet_ref.py against goldens produced by the reference's own class bodies (tools/oracle/gen_golden.py gen_videonet):
+    SpatialAttentionModule, ReferenceConditionedAttentionBlock.forward (sam -> cross_attn -> tam, skip_temporal_attn, a changed
+    num_frames), and VideoNet.__init__ / update_reference_embeddings (block order, dealing, key listing)."""
+    from oracle import videonet_ref as V
+    g = load_file(os.path.join(cases.GOLDEN_DIR, "videonet.safetensors"))
+    sd = {"sam." + k: v for k, v in synth_state_dict({k[4:]: v for k, v in _sam_shapes(64).items()}, prefix="videonet_spatial.").items()}
+    with torch.no_grad():
+        y = V.spatial_attention_module(sd, "sam", seeded_randn((3, 64, 4, 8), 80), seeded_randn((3, 64, 4, 8), 81))
+        torch.testing.assert_close(y, g["spatial/out"], rtol=1e-4, atol=1e-5)
+        rsd = {"blk." + k: v for k, v in _rcab_sd().items()}
+        x, r, ctx = seeded_randn((8, 64, 4, 8), 83), seeded_randn((8, 64, 4, 8), 84), seeded_randn((8, 5, 32), 85)
+        torch.testing.assert_close(V.rcab(rsd, "blk", x, r, ctx, 8, 32, 4), g["rcab/out"], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(V.rcab(rsd, "blk", x, r, ctx, 8, 32, 4, skip_temporal_attn=True), g["rcab/out_skip"], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(V.rcab(rsd, "blk", x, r, ctx, 8, 32, 2), g["rcab/out_frames2"], rtol=1e-4, atol=1e-5)
+    assert float((g["rcab/out"] - g["rcab/out_skip"]).abs().mean()) > 1e-2 and float((g["rcab/out"] - g["rcab/out_frames2"]).abs().mean()) > 1e-3
+    wiring = json.load(open(os.path.join(cases.GOLDEN_DIR, "videonet_wiring.json")))
+    assert V.block_order(cases.VIDEONET_TINY) == wiring["block_order"]
+    assert wiring["reference_index_of_block"] == list(range(len(wiring["block_order"])))
+
+
+def _sam_shapes(c):
+    from emote_hack_amd.spec import _sam_shapes as shapes
+    d = {}
+    shapes("sam", c, d)
+    return d
+
+
+def test_videonet_state_dict_keys_and_block_order_match_the_reference_ctor():
+    """The product VideoNet owns exactly the keys (and shapes) of the reference's VideoNet built on the same 2-D UNet, and deals the
+    reference embeddings to its blocks in the reference's order (tests/golden/videonet_wiring.json)."""
+    from emote_hack_amd.videonet import VideoNet
+    wiring = json.load(open(os.path.join(cases.GOLDEN_DIR, "videonet_wiring.json")))
+    vn = VideoNet(cases.VIDEONET_TINY, num_frames=4)
+    assert {"unet." + k: list(v) for k, v in vn._shapes.items()} == {k: v for k, v in wiring["keys"]}
+    assert [h.slot for h in vn.ref_cond_attn_blocks] == wiring["block_order"]
+    refs = [torch.full((1,), float(i)) for i in range(len(vn.ref_cond_attn_blocks))]
+    vn.update_reference_embeddings(refs)
+    assert [int(b.reference_tensor.item()) for b in vn.ref_cond_attn_blocks] == wiring["reference_index_of_block"]
+    with pytest.raises(ValueError, match="2-D UNet"):
+        VideoNet(cases.TINY_MOTION)

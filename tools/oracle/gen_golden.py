@@ -424,8 +424,52 @@ def gen_videonet():
     T["spatial/out"] = sp(x, r)
     tm = load_synth(V["TemporalAttentionModule"](64, 4, embed_dim=64, num_heads=8), "videonet_temporal.")
     T["temporal/out"] = tm(seeded_randn((2 * 4, 64, 4, 4), 82))
+    # ---- ReferenceConditionedAttentionBlock.forward (models/videonet.py:132-196): sam -> cross_attn -> tam, the reference's own
+    # class body.  Its two third-party members are stood in by the reference's IN-TREE equivalents: `cross_attn` (a diffusers
+    # Transformer2DModel) by magicanimate's Transformer3DModel at one frame behind the 2-D call signature, and
+    # models/motionmodule.get_motion_module (diffusers Attention / FeedForward inside) by magicanimate/models/motion_module.py's
+    # (same module tree and key names, in-tree attention) - with the ctor's own defaults, i.e. TWO transformer blocks, no PE.
+    from types import SimpleNamespace
+
+    class CrossAttn2D(ref_attention.Transformer3DModel):
+        def forward(self, hidden_states, encoder_hidden_states=None, timestep=None, added_cond_kwargs=None, class_labels=None,
+                    cross_attention_kwargs=None, attention_mask=None, encoder_attention_mask=None, return_dict=True):
+            y = super().forward(hidden_states[:, :, None], encoder_hidden_states=encoder_hidden_states, return_dict=False)[0]
+            return (y[:, :, 0],)
+
+    R = shim.extract_classes("/root/reference/models/videonet.py", ["SpatialAttentionModule", "ReferenceConditionedAttentionBlock", "VideoNet"],
+                             extra_ns={"rearrange": rearrange, "memory_efficient_attention": mea, "Transformer2DModel": CrossAttn2D,
+                                       "UNet2DConditionModel": object, "get_motion_module": ref_mm.get_motion_module,
+                                       "copy": __import__("copy")})
+    C_, heads, nfr = 64, 8, 4
+    ca = CrossAttn2D(num_attention_heads=heads, attention_head_dim=C_ // heads, in_channels=C_, cross_attention_dim=32, norm_num_groups=32,
+                     unet_use_cross_frame_attention=False, unet_use_temporal_attention=False)
+    blk = load_synth(R["ReferenceConditionedAttentionBlock"](ca, nfr), "rcab.")
+    x, r, ctx = seeded_randn((2 * nfr, C_, 4, 8), 83), seeded_randn((2 * nfr, C_, 4, 8), 84), seeded_randn((2 * nfr, 5, 32), 85)
+    blk.update_reference_tensor(r)
+    T["rcab/out"] = blk(x, ctx)[0]
+    blk.skip_temporal_attn = True
+    T["rcab/out_skip"] = blk(x, ctx)[0]
+    blk.skip_temporal_attn = False
+    blk.update_num_frames(2)          # the same rows regrouped as 4 clips of 2 frames
+    T["rcab/out_frames2"] = blk(x, ctx)[0]
     save_file({k: v.contiguous() for k, v in T.items()}, os.path.join(GOLD, "videonet.safetensors"))
     print("videonet.safetensors", {k: tuple(v.shape) for k, v in T.items()})
+    # ---- VideoNet.__init__ / update_reference_embeddings (models/videonet.py:199-247) on the reference's own tiny 3-D UNet (a
+    # diffusers 2-D UNet is absent; the ctor only walks down_blocks / mid_block / up_blocks `.attentions`): which attention slots
+    # become ReferenceConditionedAttentionBlocks, in which ORDER the reference embeddings are dealt to them, and the resulting
+    # state-dict key listing (INT goldens, tests/golden/ints.json is rewritten by gen_ints: stored in their own file here)
+    sd_unet = UNet3DConditionModel(**cases.VIDEONET_TINY)
+    vn = R["VideoNet"](sd_unet, num_frames=nfr)
+    names = {id(m): n for n, m in vn.unet.named_modules()}
+    order = [names[id(b)] for b in vn.ref_cond_attn_blocks]
+    refs = [torch.full((1,), float(i)) for i in range(len(order))]
+    vn.update_reference_embeddings(refs)
+    dealt = [int(b.reference_tensor.item()) for b in vn.ref_cond_attn_blocks]
+    keys = [[k, list(v.shape)] for k, v in vn.state_dict().items()]
+    json.dump({"block_order": order, "reference_index_of_block": dealt, "n_keys": len(keys), "keys": keys},
+              open(os.path.join(GOLD, "videonet_wiring.json"), "w"), indent=0)
+    print("videonet_wiring.json", len(order), "blocks,", len(keys), "keys")
 
 
 # =============================================================================== audio windows
