@@ -283,6 +283,7 @@ def unet_forward(sd, cfg, sample, timestep, encoder_hidden_states, *, bank_mode=
         timestep = timestep[None]
     timestep = timestep.expand(B)
     t_emb = timestep_embedding(timestep, boc[0], cfg["flip_sin_to_cos"], cfg["freq_shift"])
+    t_emb = t_emb.to(sd["time_embedding.linear_1.weight"].dtype)      # unet_controlnet.py:397 `t_emb.to(dtype=self.dtype)` (a no-op in f32)
     emb = _lin(sd, "time_embedding.linear_2", F.silu(_lin(sd, "time_embedding.linear_1", t_emb)))
     if speed_embeddings is not None:
         emb = emb + speed_embeddings

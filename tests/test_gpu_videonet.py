@@ -68,10 +68,18 @@ def test_videonet_forward_vs_oracle(dtype):
     with torch.no_grad():
         want = V.videonet_forward(sd, cases.VIDEONET_TINY, noise, t, refs, ctx, T)
         want_skip = V.videonet_forward(sd, cases.VIDEONET_TINY, noise, t, refs, ctx, T, skip_temporal_attn=True)
+        # low-precision gate: the same torch statements run in bf16 on the CPU (what the reference's modules would do in that dtype) - this
+        # 16-block network is deeper than the tiny motion UNet the relative yard-stick was measured on (torch bf16: mean 1.24e-2 / max 6.4e-2)
+        low = low_skip = None
+        if dtype != torch.float32:
+            b = lambda x_: x_.to(dtype)
+            sdl = {k: b(v) for k, v in sd.items()}
+            low = V.videonet_forward(sdl, cases.VIDEONET_TINY, b(noise), t, [b(r) for r in refs], b(ctx), T).float()
+            low_skip = V.videonet_forward(sdl, cases.VIDEONET_TINY, b(noise), t, [b(r) for r in refs], b(ctx), T, skip_temporal_attn=True).float()
     got = vn(noise.to(DEV), t.to(DEV), [r.to(DEV) for r in refs], ctx.to(DEV))
     assert got.shape == (bt, 4, 16, 16)
-    check(got, want, dtype)
-    check(vn(noise.to(DEV), t.to(DEV), [r.to(DEV) for r in refs], ctx.to(DEV), skip_temporal_attn=True), want_skip, dtype)
+    check(got, want, dtype, low)
+    check(vn(noise.to(DEV), t.to(DEV), [r.to(DEV) for r in refs], ctx.to(DEV), skip_temporal_attn=True), want_skip, dtype, low_skip)
     assert float((want - want_skip).abs().mean()) > 1e-3          # the temporal modules are live
     if dtype == torch.float32:   # the reference embeddings are live and dealt in order: swapping two of equal shape changes the result
         sw = list(refs)
