@@ -98,3 +98,33 @@ def stage3_combine(latents, face_feat, unet_out_fn, speed_embed):
     """train_stage_3_speedlayers.py:242-271 (EMOStage3.forward) combine rule:
     unet(latents + face_feat) + speed_embed[..., None, None]."""
     return unet_out_fn(latents + face_feat) + speed_embed.unsqueeze(-1).unsqueeze(-1)
+
+
+# ----------------------------------------------------------------------------- Net.py placeholders (SURVEY A21)
+def net_reference_attention(sd, x, ref):
+    """Net.py:1487-1511 (ReferenceAttention): q = Wq LN(x), k = Wk LN(ref), v = Wv ref, one head, scale channels^-0.5, no residual."""
+    B, C, H, W = x.shape
+    xf, rf = x.flatten(2).permute(0, 2, 1), ref.flatten(2).permute(0, 2, 1)
+    ln = lambda t: F.layer_norm(t, (C,), sd["norm.weight"], sd["norm.bias"])
+    q = F.linear(ln(xf), sd["q_proj.weight"], sd["q_proj.bias"])
+    k = F.linear(ln(rf), sd["k_proj.weight"], sd["k_proj.bias"])
+    v = F.linear(rf, sd["v_proj.weight"], sd["v_proj.bias"])
+    out = F.softmax(q @ k.transpose(-2, -1) * C ** -0.5, dim=-1) @ v
+    return out.permute(0, 2, 1).reshape(B, C, H, W)
+
+
+def net_motion_module(sd, x, heads=8):
+    """Net.py:1449-1485 (MotionModule + TemporalAttention) on (B, C, T, 1, 1): Conv3d over time, LayerNorm(channels), multi-head
+    attention over T (nn.MultiheadAttention: biased in_proj, q scaled by d^-0.5, out_proj), + identity."""
+    B, C, T, _, _ = x.shape
+    k = sd["temporal_conv.weight"].shape[2]
+    y = F.conv3d(x, sd["temporal_conv.weight"], sd["temporal_conv.bias"], padding=(k // 2, 0, 0))
+    t = y.reshape(B, C, T).permute(0, 2, 1)                                           # (B, T, C)
+    n = F.layer_norm(t, (C,), sd["temporal_attention.norm.weight"], sd["temporal_attention.norm.bias"])
+    qkv = F.linear(n, sd["temporal_attention.attention.in_proj_weight"], sd["temporal_attention.attention.in_proj_bias"])
+    d = C // heads
+    sp = lambda u: u.reshape(B, T, heads, d).permute(0, 2, 1, 3)
+    q, kk, v = (sp(u) for u in qkv.chunk(3, dim=-1))
+    a = (F.softmax(q @ kk.transpose(-1, -2) * d ** -0.5, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B, T, C)
+    a = F.linear(a, sd["temporal_attention.attention.out_proj.weight"], sd["temporal_attention.attention.out_proj.bias"])
+    return a.permute(0, 2, 1).reshape(B, C, T, 1, 1) + x

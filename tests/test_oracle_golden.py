@@ -455,3 +455,30 @@ def test_videonet_state_dict_keys_and_block_order_match_the_reference_ctor():
     assert [int(b.reference_tensor.item()) for b in vn.ref_cond_attn_blocks] == wiring["reference_index_of_block"]
     with pytest.raises(ValueError, match="2-D UNet"):
         VideoNet(cases.TINY_MOTION)
+
+
+# ----------------------------------------------------------------------------- Net.py placeholders
+def test_net_placeholder_oracles_match_the_reference_classes():
+    """oracle/conditioning_ref.py against the reference's own ReferenceAttention / MotionModule class bodies and the runnable stages of
+    BackboneNetwork.forward (tests/golden/net_placeholders.safetensors); net_placeholders.json records what the reference RAISES for the
+    geometries / classes that do not run (the product refuses the same ones)."""
+    g = load_file(os.path.join(cases.GOLDEN_DIR, "net_placeholders.safetensors"))
+    J = json.load(open(os.path.join(cases.GOLDEN_DIR, "net_placeholders.json")))
+    assert J == {"motion_module_4x4": "RuntimeError", "motion_module_even_kernel": "RuntimeError", "temporal_module": "RuntimeError",
+                 "backbone_forward": "AssertionError"}
+    from emote_hack_amd.net_placeholders import MotionModule, ReferenceAttention
+    with torch.no_grad():
+        sd = synth_state_dict(ReferenceAttention(64)._shapes, prefix="net_reference_attention.")
+        y = C.net_reference_attention(sd, seeded_randn((2, 64, 4, 6), 400), seeded_randn((2, 64, 4, 6), 401))
+        torch.testing.assert_close(y, g["reference_attention/out"], rtol=1e-4, atol=1e-5)
+        sd = synth_state_dict(MotionModule(64, 3)._shapes, prefix="net_motion_module.")
+        torch.testing.assert_close(C.net_motion_module(sd, seeded_randn((2, 64, 6, 1, 1), 402)), g["motion_module/out"], rtol=1e-4, atol=1e-5)
+        feat = 32
+        shp = {f"{i}.{n}.{w}": ((feat, feat) if w == "weight" else (feat,)) for i in range(2) for n in ("query", "key", "value") for w in ("weight", "bias")}
+        rsd = synth_state_dict(shp, prefix="net_backbone_ref.")
+        asd = synth_state_dict({"layers." + k: v for k, v in shp.items()}, prefix="net_backbone_audio.")
+        lat, aud, ref = seeded_randn((2, 5, feat), 405), seeded_randn((2, 5, feat), 406), seeded_randn((2, 1, feat), 407)
+        x = lat
+        for i in range(2):      # BackboneNetwork.forward :401-403 adds a SECOND skip around a layer that already has one
+            x = C.net_reference_attention_layer({k[2:]: v for k, v in rsd.items() if k.startswith(f"{i}.")}, x, ref) + x
+        torch.testing.assert_close(C.net_audio_attention_layers(asd, x, aud, 2), g["backbone/before_temporal"], rtol=1e-4, atol=1e-5)

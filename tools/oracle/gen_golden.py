@@ -472,6 +472,51 @@ def gen_videonet():
     print("videonet_wiring.json", len(order), "blocks,", len(keys), "keys")
 
 
+# =============================================================================== Net.py placeholders
+def gen_net_placeholders():
+    """Net.py's never-wired placeholder modules, run as they stand (AST-extracted class bodies) wherever they run at all:
+      ReferenceAttention  :1487-1511   single-head attention of LN(x) tokens over LN(ref) keys / raw ref values, no residual
+      MotionModule + TemporalAttention :1449-1485   Conv3d over time + nn.MultiheadAttention over (T, B, C*H*W) - LayerNorm(channels)
+                          is applied to a C*H*W-wide axis, so the pair runs for 1x1 feature maps (and odd temporal_length) only
+      TemporalModule      :520-552     `x.view(b, -1, c, h, w)` hands Conv3d a 1-channel volume: raises for every channels % 8 == 0
+      BackboneNetwork     :368-411     reference- and audio-attention stacks run; the VanillaTemporalModule stage receives the 3-D
+                          latent and trips its own ndim == 5 assertion
+    What runs is stored as tensors; what does not is stored as the exception type the reference raises (net_placeholders.json)."""
+    T, J = {}, {}
+    N = shim.extract_classes("/root/reference/Net.py", ["ReferenceAttention", "MotionModule", "TemporalAttention", "TemporalModule",
+                                                        "BackboneNetwork", "ReferenceAttentionLayer", "AudioAttentionLayers", "CrossAttentionLayer"],
+                             extra_ns={"VanillaTemporalModule": ref_mm.VanillaTemporalModule})
+    ra = load_synth(N["ReferenceAttention"](64), "net_reference_attention.")
+    T["reference_attention/out"] = ra(seeded_randn((2, 64, 4, 6), 400), seeded_randn((2, 64, 4, 6), 401))
+    mm = load_synth(N["MotionModule"](64, 3), "net_motion_module.")
+    T["motion_module/out"] = mm(seeded_randn((2, 64, 6, 1, 1), 402))
+    for name, fn in (("motion_module_4x4", lambda: mm(seeded_randn((2, 64, 6, 4, 4), 403))),
+                     ("motion_module_even_kernel", lambda: load_synth(N["MotionModule"](64, 4), "net_motion_module4.")(seeded_randn((2, 64, 6, 1, 1), 402))),
+                     ("temporal_module", lambda: load_synth(N["TemporalModule"](64, 4), "net_temporal_module.")(seeded_randn((2, 64, 4, 4), 404), None))):
+        try:
+            fn()
+            J[name] = "runs"
+        except Exception as ex:
+            J[name] = type(ex).__name__
+    feat = 32
+    audio_layers = load_synth(N["AudioAttentionLayers"](feat, 2), "net_backbone_audio.")
+    bb = N["BackboneNetwork"](feat, 2, lambda img: img, audio_layers, temporal_module_kwargs=dict(num_attention_heads=4, num_transformer_block=1))
+    load_synth(bb.reference_attention_layers, "net_backbone_ref.")
+    lat, aud, ref = seeded_randn((2, 5, feat), 405), seeded_randn((2, 5, feat), 406), seeded_randn((2, 1, feat), 407)
+    try:
+        bb(lat, aud, ref)
+        J["backbone_forward"] = "runs"
+    except Exception as ex:
+        J["backbone_forward"] = type(ex).__name__
+    x = lat
+    for layer in bb.reference_attention_layers:                    # the stages in front of the assertion, as :401-407 run them
+        x = layer(x, ref) + x
+    T["backbone/before_temporal"] = bb.audio_attention_layers(x, aud)
+    save_file({k: v.contiguous() for k, v in T.items()}, os.path.join(GOLD, "net_placeholders.safetensors"))
+    json.dump(J, open(os.path.join(GOLD, "net_placeholders.json"), "w"), indent=1, sort_keys=True)
+    print("net_placeholders", {k: tuple(v.shape) for k, v in T.items()}, J)
+
+
 # =============================================================================== audio windows (SURVEY 8f rank 4)
 def gen_audio_windows():
     """Net.py:649-667: the per-frame windowing loop of Wav2VecFeatureExtractor.extract_features_from_wav, run on synthetic
@@ -539,7 +584,7 @@ if __name__ == "__main__":
     ap.add_argument("--skip-cfg1", action="store_true")
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    todo = a.only.split(",") if a.only else ["ints", "modules", "unet", "cond", "controlnet", "audio", "videonet", "cfg1"]
+    todo = a.only.split(",") if a.only else ["ints", "modules", "unet", "cond", "controlnet", "audio", "videonet", "net", "cfg1"]
     if "ints" in todo:
         gen_ints()
     if "modules" in todo:
@@ -555,5 +600,7 @@ if __name__ == "__main__":
         gen_audio_windows()
     if "videonet" in todo:
         gen_videonet()
+    if "net" in todo:
+        gen_net_placeholders()
     if "cfg1" in todo and not a.skip_cfg1:
         gen_cfg1()
