@@ -46,7 +46,8 @@ __device__ __forceinline__ float fma_asm(float x, unsigned a, unsigned b) {
 //   * persistent blocks, continuous loader stream across tiles, weights one stage ahead (requested right behind the
 //     barrier), vmcnt(0) + one s_barrier per tap-stage.
 //   * epilogue = the GEMM's row-major fused epilogue (bias, temb row bias, residual), rows mapped through the patch.
-// Needs Cin % (128 B of channels) == 0, H % 8 == 0, W % 16 == 0; everything else stays on the im2col loader.
+// Needs Cin % (128 B of channels) == 0, H >= 8, W >= 16 (frames that are not whole patches: overlapped last patch, see tpx below);
+// everything else stays on the im2col loader.
 // PH_ = patch height: 8 (4 waves, 128 output pixels, 78 KB of LDS, 2 blocks per CU) or 16 (8 waves, 256 pixels, 114 KB,
 // 1 block per CU).  The weight tile is the larger stream: 16 KB per tap-stage against 2.6 KB of halo (PH 8) - the 16-row
 // patch feeds twice the MFMAs from the same weights, 4.9 KB of LDS-DMA traffic per MFLOP instead of 8.9 (the direct-to-LDS
@@ -91,7 +92,12 @@ __global__ __launch_bounds__(32 * PH_, 2) void conv3x3_halo_kernel(const emo_gem
   // grid lives on the UPSAMPLED frame (He x We), a halo pixel (y, x) is read from source pixel (y >> 1, x >> 1)
   const int ups = p.upsample2x ? 1 : 0;
   const int He = p.H << ups, We = p.W_ << ups;
-  const int tpx = We / Halo::PW, tpy = He / Halo::PH, tpi = tpx * tpy;   // patches per frame
+  // patches per frame.  A frame that is not a whole number of patches (24 x 24 at BASELINE configs[4]) gets its LAST patch column /
+  // row shifted back inside the frame (x0 = We - PW): the overlapped pixels are computed by two blocks - the same arithmetic in the
+  // same order, so both store the same bits - and no store needs a mask.  (The host keeps such frames off in-place epilogues.)
+  const int tpx = (We + Halo::PW - 1) / Halo::PW, tpy = (He + Halo::PH - 1) / Halo::PH, tpi = tpx * tpy;
+  auto patch_y0 = [&](int rem) { const int y = (rem / tpx) * Halo::PH; return y + Halo::PH > He ? He - Halo::PH : y; };
+  auto patch_x0 = [&](int rem) { const int x = (rem % tpx) * Halo::PW; return x + Halo::PW > We ? We - Halo::PW : x; };
   const int tiles_m = (int)(p.M / ((int64_t)He * We)) * tpi;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_all = tiles_m * tiles_n;
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(32 * PH_, 2) void conv3x3_halo_kernel(const emo_gem
     const int img = tm / tpi, rem = tm % tpi;
     if constexpr (GN) g_row = (int64_t)(img / p.gn_imgs_per_inst) * 2 * p.Cin;
     h_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (int64_t)img * p.H * p.W_ * p.lda), 0, (int)frame_bytes, 0x00020000);
-    const int y0 = (rem / tpx) * Halo::PH - 1, x0 = (rem % tpx) * Halo::PW - 1;
+    const int y0 = patch_y0(rem) - 1, x0 = patch_x0(rem) - 1;
 #pragma unroll
     for (int i = 0; i < LH; i++) {
       const int hp = (i * NW + wave) * 8 + lrow, hy = hp / Halo::HW_, hx = hp - hy * Halo::HW_;
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(32 * PH_, 2) void conv3x3_halo_kernel(const emo_gem
     // ---- epilogue: MFMA tile row i of this wave = patch rows 2*(wvm*2+i), +1 (16 pixels each)
     const int tm = c_tile / tiles_n;
     const int img = tm / tpi, rem = tm % tpi;
-    const int y0 = (rem / tpx) * Halo::PH, x0 = (rem % tpx) * Halo::PW;
+    const int y0 = patch_y0(rem), x0 = patch_x0(rem);
     const int wn0 = (c_tile % tiles_n) * BN + wvn * 32 * WTN;
     bool staged = false;
     if constexpr (sizeof(T) == 2) {

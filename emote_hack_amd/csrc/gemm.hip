@@ -36,14 +36,21 @@ static bool halo_conv_ok(const emo_gemm_params& p) {
   const int bk = KBYTES / (p.dtype == EMO_F32 ? 4 : 2);
   // (the nearest x2 upsampling of resnet.py:74-82 rides along: the patch grid lives on the upsampled frame)
   const int He = p.upsample2x ? 2 * p.H : p.H, We = p.upsample2x ? 2 * p.W_ : p.W_;
+  // Frames that are not a whole number of 8 x 16 patches (24 x 24: BASELINE configs[4]) run with an overlapped last patch row / column
+  // whose pixels two blocks store (identical bits): not with the GroupNorm fold, and not when the output aliases the residual
+  const bool whole = He % 8 == 0 && We % HaloGeom::PW == 0;
+  const int esz_ = p.dtype == EMO_F32 ? 4 : 2;
+  const char* c0 = (const char*)p.C; const char* r0 = (const char*)p.residual;
+  const bool alias = r0 && c0 && !(r0 + ((p.M - 1) * p.ldr + p.N) * esz_ <= c0 || c0 + ((p.M - 1) * p.ldc + p.N) * esz_ <= r0);
+  const bool ragged_ok = He >= 8 && We >= HaloGeom::PW && !p.gn_coef && !alias;
   return p.conv_taps == 9 && p.stride == 1 && !p.conv_asym && !p.up_h && !p.transpose_out && !p.geglu && S == 1 && p.Cin > 0 && p.Cin % bk == 0 &&
-         He % 8 == 0 && We % HaloGeom::PW == 0 && (p.N & 3) == 0 &&
+         (whole || ragged_ok) && (p.N & 3) == 0 &&
          // (its loaders address one frame / one weight tile through 32-bit buffer offsets)
          (int64_t)p.H * p.W_ * p.lda * (p.dtype == EMO_F32 ? 4 : 2) < (1ll << 31) && (int64_t)HaloGeom::BN * p.K * (p.dtype == EMO_F32 ? 4 : 2) < (1ll << 31) &&
          (!p.rowbias || (p.rows_per_batch % (He * We) == 0 && (p.ld_rowbias & 3) == 0));
 }
 extern "C" int emo_conv3x3_gn_fusable(const emo_gemm_params* pp) {
-  return pp && emo_dtype_ok(pp->dtype) && pp->H > 0 && pp->W_ > 0 && halo_conv_ok(*pp) && !pp->upsample2x ? 1 : 0;
+  return pp && emo_dtype_ok(pp->dtype) && pp->H > 0 && pp->W_ > 0 && pp->H % 8 == 0 && pp->W_ % HaloGeom::PW == 0 && halo_conv_ok(*pp) && !pp->upsample2x ? 1 : 0;
 }
 
 // columns a wave of the planned tile covers: the split store of emo_gemm_params.vt switches per wave
@@ -119,7 +126,9 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
     if (conv && halo_conv_ok(p)) {
       const int64_t nt = (p.N + HaloGeom::BN - 1) / HaloGeom::BN;
       // 16-row patches (8 waves, one block per CU) when they still give (nearly) every CU a block; p.tile 1 / 2 pins 8 / 16
-      const int64_t tiles16 = (p.M / 256) * nt;
+      const int We = p.upsample2x ? 2 * p.W_ : p.W_;
+      const int64_t n_img = p.M / ((int64_t)He * We), tpx = (We + HaloGeom::PW - 1) / HaloGeom::PW;
+      const int64_t tiles16 = n_img * tpx * ((He + 15) / 16) * nt;
       const bool ph16 = He % 16 == 0 && ((p.tile & 3) == 2 || ((p.tile & 3) != 1 && tiles16 >= 200));
       // A width that is an odd multiple of 64 (N = 320 = 128 + 128 + 64): the last 128-column tile would multiply 64 columns of
       // zeros - 17 % of the launch at N = 320.  The 64 remainder columns get their own launch of 64-channel blocks instead
@@ -127,7 +136,7 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
       const int n_rem = (p.N > HaloGeom::BN && p.N % HaloGeom::BN == 64 && !(p.tile & 4)) ? 64 : 0;
       auto launch = [&](const emo_gemm_params& q, int bn) {
         const int64_t ntq = (q.N + bn - 1) / bn;
-        const int64_t tiles = (ph16 ? q.M / 256 : q.M / 128) * ntq, slots = ph16 ? 256 : 512;
+        const int64_t tiles = n_img * tpx * (ph16 ? He / 16 : (He + 7) / 8) * ntq, slots = ph16 ? 256 : 512;
         const int64_t gx = tiles > slots ? slots : tiles;
         int rc_h = EMO_OK;
         EMO_DISPATCH(q.dtype, "emo_gemm", rc_h = gemm_run_halo<T>(q, ph16 ? 16 : 8, bn, gx, as_stream(stream)));
