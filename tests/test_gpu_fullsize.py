@@ -121,8 +121,8 @@ def test_cfg2_reference_group_size_does_not_change_the_result(cfg2_models_f32):
 
 
 def test_cfg2_reference_net_on_bf16_vs_f32(cfg2_models, cfg2_models_f32):
-    """eps of the first step, bf16 HIP vs f32 HIP, ReferenceNet on, CFG 7.5: within the reference's own bf16 error scale
-    (the guidance formula amplifies the per-branch error by up to 1 + 2 * 7.5)."""
+    """eps of the first step, bf16 HIP vs f32 HIP, ReferenceNet on, CFG 7.5: within 3 x the reference's own bf16 error scale relative
+    to the guided eps (the f32 HIP path itself is held to the ORACLE at this size by test_cfg2_full_unet_f32_vs_oracle below)."""
     unet, ref = cfg2_models
     u32, r32 = cfg2_models_f32
     _, eps_b = _run_loop(unet, ref, 1, graphs=False, ref_group=1)
@@ -131,7 +131,9 @@ def test_cfg2_reference_net_on_bf16_vs_f32(cfg2_models, cfg2_models_f32):
     k_mean, _ = yardstick(torch.bfloat16)
     e = (eps_b[0] - eps_f[0]).abs()
     print("cfg2 eps bf16 vs f32: mean err", float(e.mean()), "mean |eps|", float(eps_f[0].abs().mean()))
-    assert float(e.mean()) <= 16 * 1.25 * k_mean * float(eps_f[0].abs().mean()), (float(e.mean()), float(eps_f[0].abs().mean()))
+    # measured: 1.99 x the yard-stick relative to mean |eps| (the two branches' errors add up under eps = 8.5 c - 7.5 uc, but eps itself is
+    # that much larger than a branch's output); the worst-case bound of the formula, 16 x, would hide a broken branch
+    assert float(e.mean()) <= 3.0 * k_mean * float(eps_f[0].abs().mean()), (float(e.mean()), float(eps_f[0].abs().mean()))
 
 
 def test_cfg3_audio_context_in_the_loop(cfg2_models):

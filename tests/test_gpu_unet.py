@@ -238,8 +238,10 @@ def test_shared_prefix_of_a_cfg_batch_is_the_same_forward(dtype):
     y_plain = m(x2.to(DEV), 961, ctx2.to(DEV)).sample.float()
     y_dup = m(x2.to(DEV), 961, ctx2.to(DEV), _halves_identical=True).sample.float()
     assert float((y_plain[0] - y_plain[1]).abs().max()) > 1e-3          # the two rows do differ (different text)
-    tol = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
-    torch.testing.assert_close(y_dup, y_plain, **tol)
+    if dtype == torch.float32:
+        torch.testing.assert_close(y_dup, y_plain, rtol=1e-4, atol=1e-5)
+    else:       # two associations of the same arithmetic in bf16: inside the yard-stick every bf16 forward is held to
+        _same_function(y_dup, y_plain, dtype)
 
 
 def _same_function(y_a, y_b, dtype):
