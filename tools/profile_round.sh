@@ -8,8 +8,8 @@ TAG=${1:-rXX}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python bench.py --steps 10 --warmup 2 --no-profile --no-cpu-baseline"
-PMC_CMD="python bench.py --steps 1 --warmup 1 --no-graphs --no-profile --no-cpu-baseline"
+CMD="python bench.py --steps 10 --warmup 2 --no-profile --no-cpu-baseline --clips 0"
+PMC_CMD="python bench.py --steps 1 --warmup 1 --no-graphs --no-profile --no-cpu-baseline --clips 0"
 rocprofv3 -L > $OUT/counters.txt 2>&1 || true
 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $CMD > $OUT/kt.log 2>&1
 python tools/rocpd_summary.py $(ls /tmp/prof_kt/*/kt_results.db /tmp/prof_kt/kt_results.db 2>/dev/null | head -1) > $OUT/kernel_stats.md 2>> $OUT/kt.log
