@@ -27,7 +27,10 @@ ReferenceNet timesteps dealt over the ranks + one all_gather of the banks per gr
 
 Adds to the JSON line:  "roofline" for the dominant kernel (live HIP-event timing of every launch of that
 kernel family in an eager pass right after the timed region; algorithmic FLOPs per launch = 2*M*N*K for the GEMM/conv
-kernel) and "cpu_baseline" (the CPU oracle timed on the host cores on a bounded sample, rank 0, N=1 only).
+kernel) and "cpu_baseline" (the CPU oracle timed on the host cores on a bounded sample, rank 0, N=1 only); "parity": the full-size oracle
+forward that leg computes, used as the CHECKER of the HIP output in the benchmarked dtype and in f32 mode (max / mean abs error, north_star's
+rtol 1e-3 / atol 1e-4 verdict); config.clocks: SCLK / MCLK of the device during the timed region (amdgpu sysfs);
+config.whole_clips_after_timed_region: --clips whole 50-step clips run back to back behind the timed region (not `value`).
 """
 from __future__ import annotations
 
@@ -84,7 +87,8 @@ def cpu_baseline(unet, ref, full=False):
     the 12-frame window (conv / linear / spatial attention scale linearly in F - 6x the 2-frame time; cond carries the
     reference K/V: x 14.319 / 13.251 by FLOPs) + the ReferenceNet on two copies of the image (EMOAnimationPipeline.py:711-716),
     once per window, not per frame.  Also one cold 1-frame forward on 8 threads (the survey's thread count) and BASELINE
-    configs[0] ("cfg1": 256x256 single frame, no motion module) in full."""
+    configs[0] ("cfg1": 256x256 single frame, no motion module) in full.  Returns (parity, baseline): with full=True the 12-frame
+    forward's OUTPUT is handed to parity_vs_oracle as the reference of the HIP path."""
     from oracle import unet_ref as U
     from tests import cases
     from emote_hack_amd.synth import seeded_randn
@@ -120,7 +124,10 @@ def cpu_baseline(unet, ref, full=False):
         with torch.no_grad():
             t_full = timed(lambda: kept.append(U.unet_forward(sd_u, cases.SD15_MOTION, xf, 981, ctx)), warm=False)
         t_uncond = t_full
-        parity = parity_vs_oracle(unet, xf, ctx, kept[0])
+        try:
+            parity = parity_vs_oracle(unet, xf, ctx, kept[0])
+        except Exception as ex:   # the checker must never cost the baseline figure
+            parity = {"error": f"{type(ex).__name__}: {ex}"}
     t_cond = t_uncond * TFLOP_COND / TFLOP_UNCOND
     t_step = t_uncond + t_cond + 2 * t_ref
     t_step8 = (t_unet8 * F_WIN) * (1 + TFLOP_COND / TFLOP_UNCOND) + 2 * t_ref * (t_unet8 / (t_unet / Fs))
