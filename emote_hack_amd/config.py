@@ -72,8 +72,8 @@ def normalize_unet_config(kwargs: dict, *, strict: bool = True) -> FrozenConfig:
         raise NotImplementedError("dual_cross_attention")  # unet_3d_blocks.py:232
     if cfg["resnet_time_scale_shift"] != "default":
         raise NotImplementedError("resnet_time_scale_shift != 'default' is outside the hot path")
-    if cfg["class_embed_type"] is not None or cfg["num_class_embeds"] is not None:
-        raise NotImplementedError("class embeddings are outside the hot path (SURVEY.md 8a A18 uses the slot)")
+    if cfg["class_embed_type"] not in (None, "timestep", "identity"):      # unet_controlnet.py:120-127: anything else leaves class_embedding None
+        cfg["class_embed_type"] = None
     if cfg["unet_use_cross_frame_attention"]:
         raise NotImplementedError("SparseCausalAttention2D is undefined in the reference (attention.py:190)")
     if cfg["unet_use_temporal_attention"]:

@@ -265,6 +265,14 @@ def param_shapes(spec: UNetSpec) -> "OrderedDict[str, tuple]":
     d["time_embedding.linear_1.bias"] = (boc[0] * 4,)
     d["time_embedding.linear_2.weight"] = (boc[0] * 4, boc[0] * 4)
     d["time_embedding.linear_2.bias"] = (boc[0] * 4,)
+    # class embedding (unet_controlnet.py:119-127): nn.Embedding table | TimestepEmbedding | Identity (no parameters)
+    if cfg.get("class_embed_type") is None and cfg.get("num_class_embeds") is not None:
+        d["class_embedding.weight"] = (int(cfg["num_class_embeds"]), boc[0] * 4)
+    elif cfg.get("class_embed_type") == "timestep":
+        d["class_embedding.linear_1.weight"] = (boc[0] * 4, boc[0])
+        d["class_embedding.linear_1.bias"] = (boc[0] * 4,)
+        d["class_embedding.linear_2.weight"] = (boc[0] * 4, boc[0] * 4)
+        d["class_embedding.linear_2.bias"] = (boc[0] * 4,)
     if spec.controlnet is not None:   # ControlNetConditioningEmbedding (controlnet.py:49-91), module registration order
         cc = spec.controlnet
         d["controlnet_cond_embedding.conv_in.weight"] = (cc[0], cfg.get("conditioning_channels", 3), 3, 3)

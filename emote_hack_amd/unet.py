@@ -278,6 +278,11 @@ class UNet3DConditionModel:
         w["conv_in.w"], w["conv_in.b"] = conv3("conv_in.weight"), f32("conv_in.bias")
         for n_ in ("linear_1", "linear_2"):
             w[f"time_embedding.{n_}.w"], w[f"time_embedding.{n_}.b"] = lin(f"time_embedding.{n_}.weight"), f32(f"time_embedding.{n_}.bias")
+        if "class_embedding.weight" in m:                       # nn.Embedding(num_class_embeds, time_embed_dim) (unet_controlnet.py:120-121)
+            w["class_embedding.table"] = m["class_embedding.weight"].to(dtp).contiguous()
+        elif "class_embedding.linear_1.weight" in m:            # TimestepEmbedding (unet_controlnet.py:122-123)
+            for n_ in ("linear_1", "linear_2"):
+                w[f"class_embedding.{n_}.w"], w[f"class_embedding.{n_}.b"] = lin(f"class_embedding.{n_}.weight"), f32(f"class_embedding.{n_}.bias")
         half = spec.cfg["block_out_channels"][0] // 2
         expo = -math.log(10000) * torch.arange(half, dtype=torch.float32) / (half - spec.cfg["freq_shift"])  # embeddings.py:47-51
         w["time_freqs"] = torch.exp(expo).to(dev)
@@ -597,7 +602,7 @@ class UNet3DConditionModel:
     # overlap the ReferenceNet pass with the bank-independent down path on a second HIP stream)
     def _begin(self, sample, timestep, encoder_hidden_states, audio_features=None, speed_embeddings=None,
                down_block_additional_residuals=None, mid_block_additional_residual=None, add_after_conv_in=None, _ctx_kv=None,
-               halves_identical=False):
+               halves_identical=False, class_labels=None):
         if self._w is None:
             absent = self._absent_keys()
             raise EmoHipError("UNet3DConditionModel: weights not loaded / model not on a HIP device "
@@ -612,8 +617,6 @@ class UNet3DConditionModel:
         up = 2 ** self.num_upsamplers
         # unet_controlnet.py:357-365: inputs that are not a multiple of 2^num_upsamplers forward the skip's size to the upsamplers
         forward_upsample_size = bool(H % up or W % up)
-        if cfg["center_input_sample"]:
-            raise NotImplementedError("center_input_sample=True is outside the hot path (False in every shipped config)")
         dev = self.device
         s = _State()
         s.c = _Ctx(B, F, H, W)
@@ -629,6 +632,21 @@ class UNet3DConditionModel:
         t_emb = ops.timestep_embedding(timesteps, w["time_freqs"], cfg["block_out_channels"][0], cfg["flip_sin_to_cos"], dtp)
         e = ops.gemm(t_emb, w["time_embedding.linear_1.w"], w["time_embedding.linear_1.b"])
         emb = ops.gemm(ops.silu(e), w["time_embedding.linear_2.w"], w["time_embedding.linear_2.b"])
+        has_class = cfg["class_embed_type"] is not None or cfg["num_class_embeds"] is not None
+        if has_class:       # unet_controlnet.py:400-408
+            if class_labels is None:
+                raise ValueError("class_labels should be provided when num_class_embeds > 0")
+            cl = class_labels.to(dev)
+            if cfg["class_embed_type"] == "timestep":
+                ce = ops.timestep_embedding(cl.reshape(-1).to(torch.int64).expand(B).contiguous(), w["time_freqs"], cfg["block_out_channels"][0],
+                                            cfg["flip_sin_to_cos"], dtp)
+                ce = ops.gemm(ops.silu(ops.gemm(ce, w["class_embedding.linear_1.w"], w["class_embedding.linear_1.b"])),
+                              w["class_embedding.linear_2.w"], w["class_embedding.linear_2.b"])
+            elif cfg["class_embed_type"] == "identity":
+                ce = ops.convert(cl.float().reshape(B, -1).contiguous(), dtp)
+            else:
+                ce = ops.gather_rows(w["class_embedding.table"], cl.reshape(-1).to(torch.int32).expand(B).contiguous())
+            emb = ops.add(emb, ce)
         if speed_embeddings is not None:  # EMO extension: class-embedding slot (unet_controlnet.py:400-408)
             se = ops.convert(speed_embeddings.to(dev).float().reshape(B, -1), dtp)
             emb = ops.add(emb, se)
@@ -649,6 +667,10 @@ class UNet3DConditionModel:
         s.ctx_rows = None if _ctx_kv is not None else ops.convert(ctx.float().reshape(-1, ctx.shape[2]), dtp)
         s.ctrl = (down_block_additional_residuals, mid_block_additional_residual)
         x = ops.ncfhw_to_rows(sample, dtp, cpad=_round_up(Cin, 8))
+        if cfg["center_input_sample"]:      # sample = 2 * sample - 1.0 (unet_controlnet.py:371-373); the pad channels stay zero
+            m1 = torch.zeros(1, x.shape[1], device=dev, dtype=dtp)
+            m1[:, :Cin] = -1.0
+            x = ops.add_rowbias(ops.add(x, x), m1, x.shape[0])
         # Zero-copy skip connections: every skip tensor is produced straight into the RIGHT columns of the buffer the up
         # path will read as cat([hidden, skip]) (unet_3d_blocks.py:627-629), and the up path's producers write `hidden`
         # into its LEFT columns - the concatenation never runs.  (ControlNet residuals re-materialise the skips: old path.)
@@ -659,7 +681,7 @@ class UNet3DConditionModel:
         # cross-attention on - conv_in, the first resnet and the first transformer up to and including its self-attention
         # output projection (no reference bank in the down path under fusion_blocks="midup") are computed ONCE on half the rows
         # and duplicated.  Same arithmetic, half the rows: ~0.8 ms of the 44 ms step (a 64x64-level self-attention alone is 0.45).
-        s.dup = SHARE_CFG_PREFIX and bool(halves_identical) and B % 2 == 0 and add_after_conv_in is None and speed_embeddings is None
+        s.dup = SHARE_CFG_PREFIX and bool(halves_identical) and B % 2 == 0 and add_after_conv_in is None and speed_embeddings is None and not has_class
         s.x_half = None
         if s.dup:
             Mh = (B // 2) * F * H * W
@@ -804,11 +826,9 @@ class UNet3DConditionModel:
         audio_features (B*F, L_a, D) per-frame attn2 context; speed_embeddings (B, 4*C0) added to emb."""
         if attention_mask is not None:
             raise NotImplementedError("attention_mask is outside the hot path (always None in the pipeline)")
-        if class_labels is not None:
-            raise NotImplementedError("class embeddings are outside the hot path")
         s = self._begin(sample, timestep, encoder_hidden_states, audio_features, speed_embeddings,
                         down_block_additional_residuals, mid_block_additional_residual, _ctx_kv=_ctx_kv,
-                        halves_identical=_halves_identical)
+                        halves_identical=_halves_identical, class_labels=class_labels)
         if self._reference_control is not None:
             self._reference_control._prepare(s.c, self)
         self._run_down(s)

@@ -1,4 +1,4 @@
-"""VideoNet - the reference's alternative denoising network (/root/reference/models/videonet.py:132-267) on MI355X.
+"""VideoNet - the reference's alternative denoising network (models/videonet.py:132-267) on MI355X.
 
 The reference deep-copies a Stable-Diffusion 2-D UNet and replaces every attention slot (down blocks, mid block, up blocks - in
 that order) by a `ReferenceConditionedAttentionBlock`:

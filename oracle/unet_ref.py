@@ -257,7 +257,7 @@ def transformer_block_order(cfg, fusion_blocks="midup"):
 def unet_forward(sd, cfg, sample, timestep, encoder_hidden_states, *, bank_mode=None, banks=None,
                  uc_rows=None, fusion_blocks="midup", down_block_additional_residuals=None,
                  mid_block_additional_residual=None, speed_embeddings=None, audio_features=None,
-                 return_banks=False, attention_hook=None):
+                 return_banks=False, attention_hook=None, class_labels=None):
     """unet_controlnet.py:328-483 (UNet3DConditionModel.forward).
 
     bank_mode='write': returns (sample, {block_prefix: LN1 output}) - the ReferenceNet pass.
@@ -285,6 +285,17 @@ def unet_forward(sd, cfg, sample, timestep, encoder_hidden_states, *, bank_mode=
     t_emb = timestep_embedding(timestep, boc[0], cfg["flip_sin_to_cos"], cfg["freq_shift"])
     t_emb = t_emb.to(sd["time_embedding.linear_1.weight"].dtype)      # unet_controlnet.py:397 `t_emb.to(dtype=self.dtype)` (a no-op in f32)
     emb = _lin(sd, "time_embedding.linear_2", F.silu(_lin(sd, "time_embedding.linear_1", t_emb)))
+    if cfg["class_embed_type"] is not None or cfg["num_class_embeds"] is not None:      # unet_controlnet.py:400-408
+        if class_labels is None:
+            raise ValueError("class_labels should be provided when num_class_embeds > 0")
+        if cfg["class_embed_type"] == "timestep":
+            ce = timestep_embedding(class_labels.reshape(-1), boc[0], cfg["flip_sin_to_cos"], cfg["freq_shift"]).to(emb.dtype)
+            ce = _lin(sd, "class_embedding.linear_2", F.silu(_lin(sd, "class_embedding.linear_1", ce)))
+        elif cfg["class_embed_type"] == "identity":
+            ce = class_labels
+        else:
+            ce = F.embedding(class_labels, sd["class_embedding.weight"])
+        emb = emb + ce.to(emb.dtype)
     if speed_embeddings is not None:
         emb = emb + speed_embeddings
     ctx = encoder_hidden_states if audio_features is None else audio_features

@@ -489,3 +489,20 @@ def test_call_entry_runs_the_graph_path_and_reuses_its_plan():
     assert pipe._plan_cache[1] is not st1
     want4 = pipe.denoise(lat[:, :, :4].to(DEV), refl, text, appearance_encoder=ref, seed=0, use_graphs=False, **kw)
     assert torch.equal(out4, want4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["center", "class_table", "class_timestep", "class_identity"])
+def test_unet_forward_switches_vs_reference(name, dtype):
+    """center_input_sample (unet_controlnet.py:371-373) and the class embedding in its three ctor forms (:119-127,400-408) - off in every
+    shipped config, run by the reference model for the goldens (tests/golden/unet_switches.safetensors)."""
+    from tests.test_oracle_golden import SWITCH_CASES
+    g = load_file(os.path.join(G, "unet_switches.safetensors"))
+    extra, labels = SWITCH_CASES[name]
+    m = build(dict(cases.TINY_MOTION, **extra), dtype)
+    x, ctx = cases.tiny_inputs(2, 4)
+    kw = dict(class_labels=labels().to(DEV)) if labels else {}
+    check(m(x.to(DEV), 961, ctx.to(DEV), **kw).sample, g[name + "/out"], dtype)
+    if labels:
+        with pytest.raises(ValueError, match="class_labels"):
+            m(x.to(DEV), 961, ctx.to(DEV))

@@ -482,3 +482,27 @@ def test_net_placeholder_oracles_match_the_reference_classes():
         for i in range(2):      # BackboneNetwork.forward :401-403 adds a SECOND skip around a layer that already has one
             x = C.net_reference_attention_layer({k[2:]: v for k, v in rsd.items() if k.startswith(f"{i}.")}, x, ref) + x
         torch.testing.assert_close(C.net_audio_attention_layers(asd, x, aud, 2), g["backbone/before_temporal"], rtol=1e-4, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- UNet forward switches (unet_controlnet.py:371-373,400-408)
+SWITCH_CASES = {"center": (dict(center_input_sample=True), None),
+                "class_table": (dict(num_class_embeds=7), lambda: torch.tensor([3, 5])),
+                "class_timestep": (dict(class_embed_type="timestep"), lambda: torch.tensor([10, 500])),
+                "class_identity": (dict(class_embed_type="identity"), lambda: 0.1 * seeded_randn((2, 128), 71))}
+
+
+@pytest.mark.parametrize("name", sorted(SWITCH_CASES))
+def test_unet_forward_switches_oracle_vs_reference(name):
+    """center_input_sample and the three class-embedding forms: the oracle against the reference model's own output."""
+    from emote_hack_amd.spec import build_spec, param_shapes
+    g = load_file(os.path.join(cases.GOLDEN_DIR, "unet_switches.safetensors"))
+    extra, labels = SWITCH_CASES[name]
+    cfg = dict(cases.TINY_MOTION, **extra)
+    sd = synth_state_dict(param_shapes(build_spec(cfg)))
+    x, ctx = cases.tiny_inputs(2, 4)
+    with torch.no_grad():
+        y = U.unet_forward(sd, cfg, x, 961, ctx, class_labels=labels() if labels else None)
+    torch.testing.assert_close(y, g[name + "/out"], rtol=1e-4, atol=1e-5)
+    if labels:
+        with pytest.raises(ValueError, match="class_labels"):
+            U.unet_forward(sd, cfg, x, 961, ctx)

@@ -302,6 +302,30 @@ def gen_unet_tiny():
     return u1, ref
 
 
+# =============================================================================== UNet forward switches off the shipped configs
+def gen_unet_switches():
+    """The two forward switches of unet_controlnet.py that no shipped config turns on and that need no third-party code:
+    center_input_sample (:371-373) and the class embedding in its three ctor forms (:119-127,400-408) - the reference model itself on
+    the tiny motion config."""
+    T = {}
+    x, ctx = cases.tiny_inputs(2, 4)
+    u = load_synth(UNet3DConditionModel(**dict(cases.TINY_MOTION, center_input_sample=True)))
+    T["center/out"] = u(x, 961, ctx).sample
+    u = load_synth(UNet3DConditionModel(**dict(cases.TINY_MOTION, num_class_embeds=7)))
+    T["class_table/out"] = u(x, 961, ctx, class_labels=torch.tensor([3, 5])).sample
+    u = load_synth(UNet3DConditionModel(**dict(cases.TINY_MOTION, class_embed_type="timestep")))
+    T["class_timestep/out"] = u(x, 961, ctx, class_labels=torch.tensor([10, 500])).sample
+    u = load_synth(UNet3DConditionModel(**dict(cases.TINY_MOTION, class_embed_type="identity")))
+    T["class_identity/out"] = u(x, 961, ctx, class_labels=0.1 * seeded_randn((2, 128), 71)).sample
+    try:
+        u(x, 961, ctx)
+        raise SystemExit("the reference accepted a missing class_labels")
+    except ValueError:
+        pass
+    save_file({k: v.contiguous() for k, v in T.items()}, os.path.join(GOLD, "unet_switches.safetensors"))
+    print("unet_switches.safetensors", {k: tuple(v.shape) for k, v in T.items()})
+
+
 # =============================================================================== loop re-enactment
 def gen_loop(u1, ref):
     """Re-enact EMOAnimationPipeline.py:698-823 around the reference's own UNet (the file itself
@@ -584,7 +608,7 @@ if __name__ == "__main__":
     ap.add_argument("--skip-cfg1", action="store_true")
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    todo = a.only.split(",") if a.only else ["ints", "modules", "unet", "cond", "controlnet", "audio", "videonet", "net", "cfg1"]
+    todo = a.only.split(",") if a.only else ["ints", "modules", "unet", "cond", "controlnet", "audio", "videonet", "net", "switches", "cfg1"]
     if "ints" in todo:
         gen_ints()
     if "modules" in todo:
@@ -602,5 +626,7 @@ if __name__ == "__main__":
         gen_videonet()
     if "net" in todo:
         gen_net_placeholders()
+    if "switches" in todo:
+        gen_unet_switches()
     if "cfg1" in todo and not a.skip_cfg1:
         gen_cfg1()
