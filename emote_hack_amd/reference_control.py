@@ -23,8 +23,11 @@ class ReferenceAttentionControl:
         assert mode in ["read", "write"]
         assert fusion_blocks in ["midup", "full"]
         if reference_adain:
-            raise NotImplementedError("reference_adain (GroupNorm AdaIN hacks, mutual_self_attention.py:319-530) "
-                                      "is off by default and outside the hot path")
+            # mutual_self_attention.py:319-530,544-575: the AdaIN forwards are bound to diffusers' 2-D block classes (isinstance checks,
+            # :565-572) - on the 3-D Backbone only the mid block gets one, whose var_mean over dims (2, 3) of a 5-D tensor and 4-D banks from
+            # the 2-D writer do not broadcast: the switch does not run upstream on this pipeline's reader either
+            raise NotImplementedError("reference_adain (GroupNorm AdaIN hacks, mutual_self_attention.py:319-530) is off by default, bound to "
+                                      "diffusers' 2-D block classes upstream, and outside the hot path")
         self.unet = unet
         self.mode = mode
         self.do_classifier_free_guidance = do_classifier_free_guidance

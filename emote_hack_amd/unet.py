@@ -824,8 +824,12 @@ class UNet3DConditionModel:
         """unet_controlnet.py:328-483.  sample (B,C,F,h,w); timestep Tensor|int|float;
         encoder_hidden_states (B|B*F, L, D).  EMO extension kwargs (EMOAnimationPipeline.py:783-784):
         audio_features (B*F, L_a, D) per-frame attn2 context; speed_embeddings (B, 4*C0) added to emb."""
-        if attention_mask is not None:
-            raise NotImplementedError("attention_mask is outside the hot path (always None in the pipeline)")
+        # attention_mask: the reference prepares it (unet_controlnet.py:366-369) and hands it to its blocks, whose forwards never pass it
+        # on to their transformers (unet_3d_blocks.py:276-283,384-410,618-660; Transformer3DModel.forward has no such parameter): a DEAD
+        # input - the reference's output with a mask equals its output without (tests/golden/unet_switches.safetensors attention_mask/out).
+        # Accepted and ignored, like upstream.
+        if attention_mask is not None and not torch.is_tensor(attention_mask):
+            raise TypeError("attention_mask must be a tensor or None")
         s = self._begin(sample, timestep, encoder_hidden_states, audio_features, speed_embeddings,
                         down_block_additional_residuals, mid_block_additional_residual, _ctx_kv=_ctx_kv,
                         halves_identical=_halves_identical, class_labels=class_labels)

@@ -506,3 +506,14 @@ def test_unet_forward_switches_vs_reference(name, dtype):
     if labels:
         with pytest.raises(ValueError, match="class_labels"):
             m(x.to(DEV), 961, ctx.to(DEV))
+
+
+def test_attention_mask_is_accepted_and_ignored_like_the_reference(tiny):
+    """unet_controlnet.py:366-369 prepares the mask, no block of the reference uses it: same output with and without."""
+    x, ctx = cases.tiny_inputs(2, 4)
+    m = build(cases.TINY_MOTION, torch.float32)
+    mask = (seeded_randn((2, 256), 72) > 0).float()
+    y = m(x.to(DEV), 961, ctx.to(DEV), attention_mask=mask.to(DEV)).sample
+    assert torch.equal(y, m(x.to(DEV), 961, ctx.to(DEV)).sample)
+    g = load_file(os.path.join(G, "unet_switches.safetensors"))
+    check(y, g["attention_mask/out"], torch.float32)

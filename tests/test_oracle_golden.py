@@ -506,3 +506,10 @@ def test_unet_forward_switches_oracle_vs_reference(name):
     if labels:
         with pytest.raises(ValueError, match="class_labels"):
             U.unet_forward(sd, cfg, x, 961, ctx)
+
+
+def test_attention_mask_is_a_dead_input_of_the_reference_unet():
+    """The reference forwards attention_mask to its blocks and the blocks drop it: the golden taken WITH a mask equals the plain forward's."""
+    g = load_file(os.path.join(cases.GOLDEN_DIR, "unet_switches.safetensors"))
+    tiny = load_file(os.path.join(cases.GOLDEN_DIR, "unet_tiny.safetensors"))
+    assert torch.equal(g["attention_mask/out"], tiny["motion/out"])

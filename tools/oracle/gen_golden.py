@@ -322,6 +322,12 @@ def gen_unet_switches():
         raise SystemExit("the reference accepted a missing class_labels")
     except ValueError:
         pass
+    # attention_mask (unet_controlnet.py:366-369,421-443): prepared and handed to the blocks, whose forwards never pass it to their
+    # transformers (unet_3d_blocks.py:276-283,384-410,618-660; Transformer3DModel.forward has no such parameter) - a DEAD input
+    um = load_synth(UNet3DConditionModel(**cases.TINY_MOTION))
+    mask = (seeded_randn((2, 256), 72) > 0).float()
+    T["attention_mask/out"] = um(x, 961, ctx, attention_mask=mask).sample
+    assert torch.equal(T["attention_mask/out"], um(x, 961, ctx).sample), "attention_mask is live in the reference"
     save_file({k: v.contiguous() for k, v in T.items()}, os.path.join(GOLD, "unet_switches.safetensors"))
     print("unet_switches.safetensors", {k: tuple(v.shape) for k, v in T.items()})
 
