@@ -528,6 +528,8 @@ class EMOAnimationPipeline:
                 if split:
                     self._reference_finish(st, g)
             else:
+                if st.group_pending >= 0 and cuda:   # a look-ahead pass for ANOTHER group is in flight (the caller jumped): it shares the
+                    main.wait_stream(st.side)        # timestep buffer and the captured write graphs with the pass below
                 self._reference_group(st, g)
             st.group_ready, st.group_pending = g, -1
             if g + 1 < len(st.groups) and st.lookahead:
