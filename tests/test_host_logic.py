@@ -151,3 +151,26 @@ def test_geglu_polynomial_constants():
     with np.errstate(over="ignore"):
         e = E(t)
     assert not np.isnan(e).any() and e.min() >= 0.5 and (np.diff(e[np.isfinite(e)]) >= 0).all()
+
+
+def test_context_windows_equal_the_oracle_over_a_sweep():
+    """emote_hack_amd.context.uniform (an independent restatement: integer bit reversal, explicit start / hop walk) against
+    oracle.scheduler_ref.uniform_windows (the reference's formulation, pinned by tests/golden/ints.json) over a sweep of geometries,
+    `step` values (the pattern rotation) and both loop modes."""
+    from emote_hack_amd.context import ordered_halving, uniform
+    from oracle.scheduler_ref import ordered_halving as oh_ref, uniform_windows
+    for v in (0, 1, 2, 3, 5, 8, 49, 1 << 40, (1 << 64) - 1):
+        assert ordered_halving(v) == oh_ref(v)
+    n_cases = 0
+    for step in (0, 1, 2, 3, 7, 13):
+        for n in (8, 12, 17, 24, 40, 48, 96):
+            for size in (4, 12, 16):
+                for stride in (1, 2, 3):
+                    for ov in (0, 2, 4):
+                        if ov >= size:
+                            continue
+                        for closed in (True, False):
+                            got = list(uniform(step, 50, n, size, stride, ov, closed))
+                            assert got == uniform_windows(step, 50, n, size, stride, ov, closed), (step, n, size, stride, ov, closed)
+                            n_cases += 1
+    assert n_cases > 1000
