@@ -59,3 +59,10 @@ def test_multi_rank_loop_over_rccl_one_device_per_rank(world, kind, graphs, ref_
     if _n_gpus() < world:
         pytest.skip(f"needs {world} GPUs for one device per rank (RCCL), {_n_gpus()} visible")
     _run(world, kind, graphs, ref_group, lookahead, cbs, gs, backend="nccl", timeout=600)
+
+
+def test_two_ranks_at_full_size_equal_the_single_process_loop():
+    """512x512 latents, two 12-frame windows over two ranks (sharing the one GPU over gloo; over RCCL with one device per rank when two
+    are visible), f32, graphs + look-ahead + two ReferenceNet groups: the ranks hold bit-identical latents and they equal the single-process
+    loop at the loop tolerance 2e-3 / 5e-4 (tests/dist_gpu_worker.py fullsize)."""
+    _run(2, "fullsize", backend="nccl" if _n_gpus() >= 2 else "gloo", timeout=900)
