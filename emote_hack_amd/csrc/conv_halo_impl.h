@@ -53,14 +53,17 @@ __device__ __forceinline__ float fma_asm(float x, unsigned a, unsigned b) {
 // patch feeds twice the MFMAs from the same weights, 4.9 KB of LDS-DMA traffic per MFLOP instead of 8.9 (the direct-to-LDS
 // path, ~9 TB/s chip-wide, is what the 8-row kernel sits on at 1000-1050 TFLOP/s).
 // BN_ = output channels per block: 128, or 64 for the REMAINDER columns of a width that is an odd multiple of 64 (N = 320: two
-// 128-column tiles + one of 64 - a third 128-column tile computed 64 columns of zeros, 17 % of the launch; host side: gemm.hip)
+// 128-column tiles + one of 64 - a third 128-column tile computed 64 columns of zeros, 17 % of the launch; host side: gemm.hip).
+// Round 6: with 16-row patches (one block per CU either way: 82 KB of halo buffers) a 192-column block fits - 131 KB of LDS, 96
+// accumulator registers (223 in all) - and N = 320 can run as 128 + 192 columns, two launches of full-width blocks instead of three
+// with a half-width tail; it pays where a launch of one block per patch is a single round (gemm.hip plans it, profiles/r06k)
 template <int PH_, int BN_ = HaloGeom::BN> struct HaloT {
   static constexpr int PH = PH_, PW = HaloGeom::PW, NW = PH_ / 2, HW_ = PW + 2, HPIX = (PH + 2) * (PW + 2);   // 180 / 324 halo pixels
   static constexpr int PIECES = (HPIX + 7) / 8;                 // 1 KB glds pieces of 8 pixels: 23 / 41
   static constexpr int LH = (PIECES + NW - 1) / NW;             // pieces per wave: 6 (the last round is partial)
   static constexpr int HALO_BYTES = PIECES * 1024;              // 23 / 41 KB
   static constexpr int BN = BN_, LB = BN / (8 * NW);            // weight tile rows, glds per wave per stage
-  static_assert(BN_ == 128 || BN_ == 64, "halo conv: 128 or 64 output channels per block");
+  static_assert(BN_ == 128 || BN_ == 64 || (BN_ == 192 && PH_ == 16), "halo conv: 128 or 64 output channels per block (192 with 16-row patches)");
   static constexpr int B_BYTES = BN * KBYTES;                   // 16 KB
   static constexpr int B_OFF = 2 * HALO_BYTES;
   static constexpr int LDS_BYTES = 2 * HALO_BYTES + 2 * B_BYTES;   // 79872 / 116736
@@ -458,5 +461,9 @@ template <typename T> int gemm_run_halo(const emo_gemm_params& p, int ph, int bn
     return ph == 16 ? launch_halo<T, 16, 128, true>(p, gx, st) : launch_halo<T, 8, 128, true>(p, gx, st);
   }
   if (bn == 64) return ph == 16 ? launch_halo<T, 16, 64, false>(p, gx, st) : launch_halo<T, 8, 64, false>(p, gx, st);
+  if (bn == 192) {
+    if (ph != 16) return emo_fail(EMO_ERR_UNSUPPORTED, "emo_gemm: 192-channel halo blocks need 16-row patches");
+    return launch_halo<T, 16, 192, false>(p, gx, st);
+  }
   return ph == 16 ? launch_halo<T, 16, 128, false>(p, gx, st) : launch_halo<T, 8, 128, false>(p, gx, st);
 }

@@ -134,6 +134,12 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
       // zeros - 17 % of the launch at N = 320.  The 64 remainder columns get their own launch of 64-channel blocks instead
       // (same patches, half the weight tile, half the MFMAs per stage); p.tile bit 2 (4) keeps the single launch (tools/bench A/B).
       const int n_rem = (p.N > HaloGeom::BN && p.N % HaloGeom::BN == 64 && !(p.tile & 4)) ? 64 : 0;
+      // ... and with 16-row patches the LAST 192 columns may go to 192-channel blocks (N = 320 = 128 + 192: two launches of full-width
+      // blocks instead of 128 + 128 + a half-width 64) - when a launch of one block per patch still fits the chip in ONE round: at
+      // M = 49152 (192 patches: the shared-prefix half batch) +15 %, N = 192 +23 %; at M = 98304 (384 patches) each of the two
+      // launches would run a second, half-empty round: 0.4-4.5 % SLOWER than 768 + 384 blocks (profiles/r06k_conv_bn192.txt).
+      // p.tile bit 3 (8) keeps the 64-column remainder launch, bit 4 (16) forces the 192-column blocks (tools/bench A/B)
+      const bool wide = n_rem && ph16 && !p.gn_coef && !(p.tile & 8) && (n_img * tpx * (He / 16) <= 256 || p.N == 192 || (p.tile & 16));   // (N = 192: ONE launch instead of two)
       auto launch = [&](const emo_gemm_params& q, int bn) {
         const int64_t ntq = (q.N + bn - 1) / bn;
         const int64_t tiles = n_img * tpx * (ph16 ? He / 16 : (He + 7) / 8) * ntq, slots = ph16 ? 256 : 512;
@@ -142,11 +148,11 @@ extern "C" int emo_gemm(const emo_gemm_params* pp, void* stream) {
         EMO_DISPATCH(q.dtype, "emo_gemm", rc_h = gemm_run_halo<T>(q, ph16 ? 16 : 8, bn, gx, as_stream(stream)));
         return rc_h;
       };
-      if (!n_rem) return launch(p, p.N == 64 ? 64 : HaloGeom::BN);
+      if (!n_rem) return launch(p, p.N == 64 ? 64 : ((p.N == 192 && ph16 && !p.gn_coef && !(p.tile & 8)) ? 192 : HaloGeom::BN));
       emo_gemm_params a = p;
-      a.N = p.N - n_rem;
-      const int rc_a = launch(a, HaloGeom::BN);
-      return rc_a ? rc_a : launch(output_columns(p, a.N, n_rem), 64);
+      a.N = p.N - (wide ? 192 : n_rem);
+      const int rc_a = a.N > 0 ? launch(a, HaloGeom::BN) : EMO_OK;
+      return rc_a ? rc_a : launch(output_columns(p, a.N, p.N - a.N), wide ? 192 : 64);
     }
   }
   GemmPlan pl = plan_gemm(p.M, p.N, p.K, p.dtype, p.geglu, p.transpose_out, p.tile & 15, p.ln_colsum != nullptr);   // (tile >> 4: tile-order override, gemm_impl.h)

@@ -468,6 +468,14 @@ def test_conv3x3_halo_patch_heights(dtype, ph, n, H, W, Cin, Cout):
     got, _, _ = o.conv3x3(rows.to(DEV).to(dtype), wp.to(DEV).to(dtype).contiguous(), bias.to(DEV), n, H, W,
                           rowbias=rb.to(DEV), rows_per_batch=H * W, residual=rrows.to(DEV).to(dtype), split_k=1, tile=1 if ph == 8 else 2)
     close(got, ref.permute(0, 2, 3, 1).reshape(-1, Cout), dtype)
+    if ph == 16 and Cout % 128 == 64:
+        # widths that are odd multiples of 64 with 16-row patches: the last 192 columns on 192-channel blocks (planned when one block per
+        # patch is a single round - these shapes - or forced by tile bit 4) vs the 64-column remainder launch (tile bit 3): the same conv
+        got_64, _, _ = o.conv3x3(rows.to(DEV).to(dtype), wp.to(DEV).to(dtype).contiguous(), bias.to(DEV), n, H, W,
+                                 rowbias=rb.to(DEV), rows_per_batch=H * W, residual=rrows.to(DEV).to(dtype), split_k=1, tile=2 | 8)
+        got_192, _, _ = o.conv3x3(rows.to(DEV).to(dtype), wp.to(DEV).to(dtype).contiguous(), bias.to(DEV), n, H, W,
+                                  rowbias=rb.to(DEV), rows_per_batch=H * W, residual=rrows.to(DEV).to(dtype), split_k=1, tile=2 | 16)
+        assert torch.equal(got_64, got_192) and torch.equal(got, got_192)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
