@@ -283,6 +283,13 @@ def mfma_util_from_profiles():
     return {"mfma_busy_frac": d["mfma_busy_frac"], "source": os.path.relpath(f, ROOT), "csrc_sha256": d["csrc_sha256"][:16]}
 
 
+def _rccl_version():
+    try:
+        return ".".join(map(str, torch.cuda.nccl.version()))
+    except Exception as ex:   # (evidence only: never cost the measurement)
+        return f"unavailable ({type(ex).__name__})"
+
+
 def spawn_command(argv, n, port=None):
     """The command bench.py re-executes itself as when --gpus N > 1 and no launcher set WORLD_SIZE: one rank per GPU under
     torch.distributed.run on 127.0.0.1 (the container's hostname may not resolve)."""
@@ -647,6 +654,12 @@ def main():
                        "reference_group_note": "the same group size EMOAnimationPipeline.__call__ uses by default",
                        "reference_passes_in_timed_region": ref_passes,
                        "reference_passes_fair_share": a.steps / st.T,
+                       "distributed": None if not dist else {
+                           "backend": td.get_backend(), "world_size": td.get_world_size(),
+                           "rccl_version": _rccl_version() if td.get_backend() == "nccl" else None,
+                           "devices_visible": torch.cuda.device_count(), "one_device_per_rank": not a.share_gpu,
+                           "collectives_per_step": "1 all_gather_into_tensor of the eps slices (main stream, default group)",
+                           "collectives_per_reference_group": f"{len(st.bank_variants)} all_gather_into_tensor of the fp16-rounded banks (main stream, default group)"},
                        "clocks": {"idle_before": clk_idle, "timed_region": clk_timed.summary(),
                                   "source": "amdgpu sysfs pp_dpm_sclk / pp_dpm_mclk, sampled every 50 ms on a host thread"},
                        "whole_clips_after_timed_region": whole},
