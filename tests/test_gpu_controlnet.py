@@ -137,3 +137,26 @@ def test_denoise_loop_with_controlnet_vs_oracle(graphs):
     torch.testing.assert_close(got.cpu(), want, rtol=1e-3, atol=1e-4)
     # and the branch matters: without it the latents differ
     assert float((_LOOP_CACHE["base"] - want).abs().max()) > 1e-2
+
+
+def test_controlnet_sd15_size_vs_oracle():
+    """The SD-1.5-sized ControlNet bench.py --controlnet runs (the Backbone's encoder geometry: 320 / 640 / 1280 / 1280 channels, 8 heads)
+    on two 512 x 512 conditioning images (64 x 64 latents), f32 mode, against the oracle: all 12 down residuals and the mid residual at
+    north_star's rtol 1e-3 / atol 1e-4 - the full-size plans (halo conv, 256 x 256 tiles, GroupNorm fold, d = 40 / 80 / 160 attention)
+    of the (f)1 row, not only the tiny network."""
+    from emote_hack_amd import ControlNetModel
+    from oracle.controlnet_ref import controlnet_forward
+    cfg = dict(cases.SD15, down_block_types=("CrossAttnDownBlock2D",) * 3 + ("DownBlock2D",))
+    m = ControlNetModel(**cfg)
+    sd = synth_state_dict(param_shapes(m.spec), prefix=CN_PREFIX)
+    m.load_state_dict(sd)
+    m.to(DEV, torch.float32)
+    x, ctx = seeded_randn((2, 4, 64, 64), 171), seeded_randn((2, 77, 768), 172)
+    cond = seeded_randn((2, 3, 512, 512), 173).clamp(-1, 1) * 0.5 + 0.5
+    with torch.no_grad():
+        ref_down, ref_mid = controlnet_forward(sd, cfg, x, 500, ctx, cond)
+    out = m(x.to(DEV), 500, ctx.to(DEV), cond.to(DEV))
+    assert len(out.down_block_res_samples) == len(ref_down) == 12
+    for got, ref in zip(out.down_block_res_samples, ref_down):
+        torch.testing.assert_close(got.float().cpu(), ref, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(out.mid_block_res_sample.float().cpu(), ref_mid, rtol=1e-3, atol=1e-4)

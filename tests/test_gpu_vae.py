@@ -78,7 +78,7 @@ def test_vae_old_attention_key_names_and_strict_load():
         AutoencoderKL(**SMALL).load_state_dict({k: v for k, v in sd.items() if "conv_out" not in k}, strict=True)
 
 
-def test_vae_full_size_decode_one_frame_bf16_vs_f32():
+def test_vae_full_size_decode_one_frame_vs_oracle_and_bf16_vs_f32():
     """The SD-1.5 VAE at 512x512 (64x64 latent: 4096 tokens through the single-head mid attention = a 4096 x 4096 score
     matrix between two MFMA GEMMs), one frame: bf16 vs f32 HIP within the bf16 error scale."""
     from emote_hack_amd.vae import AutoencoderKL, vae_param_shapes, VAE_DEFAULTS
@@ -93,6 +93,11 @@ def test_vae_full_size_decode_one_frame_bf16_vs_f32():
         del m
     assert outs[torch.float32].shape == (1, 3, 512, 512) and bool(torch.isfinite(outs[torch.bfloat16]).all())
     check(outs[torch.bfloat16], outs[torch.float32], torch.bfloat16)
+    # ... and the f32 mode against the ORACLE at this size (one 512 x 512 frame of the SD-1.x decoder: ~10 s of CPU time)
+    from oracle import vae_ref as V
+    with torch.no_grad():
+        ref = V.decode({k: v.float().cpu() for k, v in sd.items()}, z)
+    torch.testing.assert_close(outs[torch.float32], ref, rtol=1e-3, atol=1e-4)
 
 
 def test_pipeline_source_image_goes_through_images2latents(tmp_path):
