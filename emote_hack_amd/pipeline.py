@@ -45,6 +45,32 @@ def _default(v, d):
     return d if v is None else v
 
 
+# ---- magicanimate/utils/util.py:116-140 (the frame interpolation `interpolate_latents` uses)
+tensor_interpolation = None
+
+
+def get_tensor_interpolation_method():
+    return tensor_interpolation
+
+
+def set_tensor_interpolation_method(is_slerp):
+    global tensor_interpolation
+    tensor_interpolation = slerp if is_slerp else linear
+
+
+def linear(v1, v2, t):
+    return (1.0 - t) * v1 + t * v2
+
+
+def slerp(v0: torch.Tensor, v1: torch.Tensor, t: float, DOT_THRESHOLD: float = 0.9995) -> torch.Tensor:
+    """spherical interpolation of two tensors taken as single vectors; linear when they are nearly parallel (util.py:128-140)"""
+    dot = ((v0 / v0.norm()) * (v1 / v1.norm())).sum()
+    if dot.abs() > DOT_THRESHOLD:
+        return (1.0 - t) * v0 + t * v1
+    omega = dot.acos()
+    return (((1.0 - t) * omega).sin() * v0 + (t * omega).sin() * v1) / omega.sin()
+
+
 class EMOAnimationPipeline:
     def __init__(self, vae=None, text_encoder=None, tokenizer=None, unet=None, controlnet=None, scheduler=None):
         """EMOAnimationPipeline.py:87-130.  The ctor forces steps_offset=1 / clip_sample=False on the
@@ -797,6 +823,141 @@ class EMOAnimationPipeline:
         if source_image.shape[0] % 8 or source_image.shape[1] % 8:
             raise ValueError(f"source_image {source_image.shape[:2]} must be a multiple of 8 in both directions")
         return self.images2latents(source_image[None], None)
+
+    # ------------------------------------------------------------------ the rest of the reference class's surface
+    def prepare_latents(self, batch_size, num_channels_latents, video_length, height, width, dtype, device, generator, latents=None, clip_length=16):
+        """EMOAnimationPipeline.py:341-368: noise for `clip_length` frames, TILED video_length // clip_length times along the frame axis (so a
+        video_length < 16 yields an empty tensor upstream - pass `latents` / `init_latents` there), times `scheduler.init_noise_sigma`.  Host
+        RNG, like the reference (`torch.randn(shape, generator=generator)`)."""
+        shape = (batch_size, num_channels_latents, clip_length, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                             f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        device = torch.device(device)
+        if latents is None:
+            if isinstance(generator, list):
+                latents = torch.cat([torch.randn(shape, generator=generator[i], device=generator[i].device, dtype=dtype) for i in range(batch_size)], dim=0).to(device)
+            else:
+                latents = torch.randn(shape, generator=generator, device=generator.device if generator is not None else device, dtype=dtype).to(device)
+            latents = latents.repeat(1, 1, video_length // clip_length, 1, 1)
+        else:
+            if tuple(latents.shape) != shape:
+                raise ValueError(f"Unexpected latents shape, got {latents.shape}, expected {shape}")
+            latents = latents.to(device)
+        return latents * self.scheduler.init_noise_sigma
+
+    def prepare_condition(self, condition, num_videos_per_prompt, device, dtype, do_classifier_free_guidance):
+        """:370-377: uint8 (f, h, w, c) conditioning frames -> / 255, one copy per video, 'b f h w c -> (b f) c h w', doubled under CFG."""
+        import numpy as np
+        condition = torch.from_numpy(np.ascontiguousarray(condition).copy()).to(device=device, dtype=dtype) / 255.0
+        condition = torch.stack([condition for _ in range(num_videos_per_prompt)], dim=0)
+        condition = condition.permute(0, 1, 4, 2, 3).reshape(-1, condition.shape[4], condition.shape[2], condition.shape[3]).clone()
+        return torch.cat([condition] * 2) if do_classifier_free_guidance else condition
+
+    def select_controlnet_res_samples(self, controlnet_res_samples_cache_dict, context, do_classifier_free_guidance, b, f):
+        """:514-540: the cached per-frame ControlNet residuals of the windows in `context`, '(b f) c h w -> b c f h w', repeated for CFG
+        (the loop itself keeps this cache in rows - `_controlnet_residuals`; this is the reference's tensor-level helper)."""
+        frames = [i for c in context for i in c]
+        n_down = len(controlnet_res_samples_cache_dict[frames[-1]][0])
+        down = [torch.cat([controlnet_res_samples_cache_dict[i][0][k] for i in frames]) for k in range(n_down)]
+        mid = torch.cat([controlnet_res_samples_cache_dict[i][1] for i in frames])
+        b = b // 2 if do_classifier_free_guidance else b
+
+        def to5(t):
+            t = t.reshape(b, f, *t.shape[1:]).permute(0, 2, 1, 3, 4)
+            return t.repeat(2, 1, 1, 1, 1) if do_classifier_free_guidance else t
+        return [to5(t) for t in down], to5(mid)
+
+    @torch.no_grad()
+    def decode_latents(self, latents, rank=0, decoder_consistency=None):
+        """:291-307: latents / 0.18215 -> the VAE decoder frame by frame (or `decoder_consistency(frame_latents)`) -> (b, 3, f, H, W) in
+        [0, 1] as a float32 numpy array."""
+        if decoder_consistency is not None:
+            f = latents.shape[2]
+            lat = (1 / 0.18215 * latents).permute(0, 2, 1, 3, 4).reshape(-1, *latents.shape[1:2], *latents.shape[3:])
+            video = torch.cat([decoder_consistency(lat[i:i + 1]) for i in range(lat.shape[0])])
+            video = video.reshape(-1, f, *video.shape[1:]).permute(0, 2, 1, 3, 4)
+            return (video / 2 + 0.5).clamp(0, 1).cpu().float().numpy()
+        if self.vae is None:
+            raise ValueError("decode_latents needs a VAE (emote_hack_amd.vae.AutoencoderKL)")
+        return self.vae.decode_video(latents).cpu().float().numpy()
+
+    def next_step(self, model_output, timestep: int, x, eta=0., verbose=False):
+        """:379-400 - one step of DDIM INVERSION (x_t -> x_{t + T/n}): pred_x0 = (x - sqrt(1 - a) eps) / sqrt(a) with a taken one stride BELOW
+        `timestep` (final_alpha_cumprod below 0), x_next = sqrt(a_next) pred_x0 + sqrt(1 - a_next) eps.  Returns (x_next, pred_x0).  Scalars
+        on the host in f64; the two linear combinations run as emo_add launches on the device (plain torch for CPU tensors)."""
+        sch = self.scheduler
+        if verbose:
+            print("timestep: ", timestep)
+        nxt = int(timestep)
+        t = min(nxt - sch.config.num_train_timesteps // sch.num_inference_steps, 999)
+        a_t = float(sch.alphas_cumprod[t]) if t >= 0 else float(sch.final_alpha_cumprod)
+        a_next = float(sch.alphas_cumprod[nxt])
+        k0x, k0e = 1.0 / a_t ** 0.5, -((1.0 - a_t) ** 0.5) / a_t ** 0.5               # pred_x0 = k0x x + k0e eps
+        knx, kne = a_next ** 0.5 * k0x, a_next ** 0.5 * k0e + (1.0 - a_next) ** 0.5    # x_next  = knx x + kne eps
+
+        def lincomb(cx, ce):
+            if not x.is_cuda:
+                return cx * x + ce * model_output
+            xf, ef = x.float().reshape(1, -1).contiguous(), model_output.float().reshape(1, -1).contiguous()
+            z = ops.add(xf, ef, alpha=ce / cx)                     # x + (ce / cx) eps
+            return ops.add(z, z, alpha=cx - 1.0).reshape(x.shape).to(x.dtype)      # ... times cx
+        return lincomb(knx, kne), lincomb(k0x, k0e)
+
+    @torch.no_grad()
+    def invert(self, image, prompt=None, num_inference_steps=20, num_actual_inference_steps=10, eta=0.0, return_intermediates=False, **kwargs):
+        """:417-477 - deterministic DDIM inversion of real frames into a noise map: frames -> latents (`images2latents`, or pass
+        latents=(f, 4, h, w)), then for the ascending timesteps x <- next_step(unet(x as one (1, c, f, h, w) clip, t, text), t, x), stopping after
+        `num_actual_inference_steps`.  The CLIP text encoder is outside this build: pass text_embeddings=(1, L, D) (or a text_encoder +
+        tokenizer pair on the pipeline, called like upstream)."""
+        text_embeddings = kwargs.get("text_embeddings")
+        if text_embeddings is None:
+            if self.text_encoder is None or self.tokenizer is None:
+                raise ValueError("invert: pass text_embeddings=(1, L, D) (no CLIP text encoder in this build)")
+            text_input = self.tokenizer(prompt, padding="max_length", max_length=77, return_tensors="pt")
+            text_embeddings = self.text_encoder(text_input.input_ids.to(self._execution_device))[0]
+        latents = kwargs.get("latents")
+        if latents is None:
+            latents = self.images2latents(image)
+        latents = latents.to(self._execution_device)
+        self.scheduler.set_timesteps(num_inference_steps)
+        latents_list, pred_x0_list = [latents], [latents]
+        for i, t in enumerate(reversed(self.scheduler.timesteps)):
+            if num_actual_inference_steps is not None and i >= num_actual_inference_steps:
+                continue
+            model_inputs = latents.permute(1, 0, 2, 3).unsqueeze(0)                          # 'f c h w -> 1 c f h w'
+            noise_pred = self.unet(model_inputs, int(t), encoder_hidden_states=text_embeddings).sample
+            noise_pred = noise_pred[0].permute(1, 0, 2, 3)                                   # 'b c f h w -> (b f) c h w'
+            latents, pred_x0 = self.next_step(noise_pred.to(latents.dtype), int(t), latents)
+            latents_list.append(latents)
+            pred_x0_list.append(pred_x0)
+        if return_intermediates:
+            return latents, latents_list
+        return latents
+
+    def interpolate_latents(self, latents: torch.Tensor, interpolation_factor: int, device):
+        """:479-512: `interpolation_factor - 1` frames interpolated between every two consecutive frames with the method set by
+        `set_tensor_interpolation_method` (magicanimate/utils/util.py:116-140: slerp over the whole frame tensor, linear when the two are
+        nearly parallel).  `__call__` hard-codes the factor 1 (:824), for which this is the identity - outside the loop, host-level torch math."""
+        if interpolation_factor < 2:
+            return latents
+        method = get_tensor_interpolation_method()
+        if method is None:
+            raise TypeError("'NoneType' object is not callable: call set_tensor_interpolation_method(is_slerp) first (magicanimate/utils/util.py:116-123)")
+        n = latents.shape[2]
+        out = torch.zeros((latents.shape[0], latents.shape[1], (n - 1) * interpolation_factor + 1, latents.shape[3], latents.shape[4]),
+                          device=latents.device, dtype=latents.dtype)
+        rate = [i / interpolation_factor for i in range(interpolation_factor)][1:]
+        k = 0
+        for i0 in range(n - 1):
+            v0, v1 = latents[:, :, i0], latents[:, :, i0 + 1]
+            out[:, :, k] = v0
+            k += 1
+            for fr in rate:
+                out[:, :, k] = method(v0.to(device=device), v1.to(device=device), fr).to(latents.device)
+                k += 1
+        out[:, :, k] = latents[:, :, n - 1]
+        return out
 
     # ------------------------------------------------------------------ reference-compatible entry point
     @torch.no_grad()

@@ -517,3 +517,27 @@ def test_attention_mask_is_accepted_and_ignored_like_the_reference(tiny):
     assert torch.equal(y, m(x.to(DEV), 961, ctx.to(DEV)).sample)
     g = load_file(os.path.join(G, "unet_switches.safetensors"))
     check(y, g["attention_mask/out"], torch.float32)
+
+
+def test_invert_ddim_inversion_vs_the_reference_method():
+    """EMOAnimationPipeline.invert (EMOAnimationPipeline.py:417-477) - DDIM inversion of four frames through the HIP UNet and the
+    device branch of next_step (:379-400) - against the golden produced by the reference's own `invert` / `next_step` method bodies
+    around the reference's UNet (tokenizer / text encoder / VAE stubbed by tensors): 5 steps scheduled, 3 taken."""
+    from emote_hack_amd import DDIMScheduler
+    from emote_hack_amd.pipeline import EMOAnimationPipeline
+    g = load_file(os.path.join(G, "pipeline_methods.safetensors"))
+    pipe = EMOAnimationPipeline(unet=build(cases.TINY_MOTION, torch.float32), scheduler=DDIMScheduler())
+    text, frames = seeded_randn((1, 5, 32), 503), seeded_randn((4, 4, 16, 16), 504)
+    lat, inter = pipe.invert(None, "", num_inference_steps=5, num_actual_inference_steps=3, return_intermediates=True,
+                             text_embeddings=text.to(DEV), latents=frames.to(DEV))
+    assert len(inter) == 4
+    torch.testing.assert_close(inter[1].float().cpu(), g["invert/step1"], rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(lat.float().cpu(), g["invert/latents"], rtol=1e-3, atol=1e-4)
+    with pytest.raises(ValueError, match="text_embeddings"):
+        pipe.invert(None, "", latents=frames.to(DEV))
+    # the device branch of next_step against the host branch
+    pipe.scheduler.set_timesteps(50)
+    x, eps = seeded_randn((4, 4, 16, 16), 500), seeded_randn((4, 4, 16, 16), 501)
+    xn, x0 = pipe.next_step(eps.to(DEV), 481, x.to(DEV))
+    torch.testing.assert_close(xn.cpu(), g["next_step/481/x_next"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(x0.cpu(), g["next_step/481/pred_x0"], rtol=1e-5, atol=1e-5)

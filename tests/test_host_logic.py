@@ -1,9 +1,13 @@
 """CPU tests of host-side logic that needs no device: the GEMM planner's split-K rules through the C ABI (pure host code in
 libemo_hip.so) and the algebra of the two linear-map compositions the UNet packs at load time."""
+import os
+
+import pytest
 import torch
 
 from emote_hack_amd import _lib
 from emote_hack_amd.synth import seeded_randn
+from tests import cases
 
 BF16, F32 = 1, 0
 
@@ -174,3 +178,37 @@ def test_context_windows_equal_the_oracle_over_a_sweep():
                             assert got == uniform_windows(step, 50, n, size, stride, ov, closed), (step, n, size, stride, ov, closed)
                             n_cases += 1
     assert n_cases > 1000
+
+
+def test_pipeline_helper_methods_equal_the_reference_method_bodies():
+    """The methods of EMOAnimationPipeline around __call__ (EMOAnimationPipeline.py:341-540) against goldens produced by running the
+    reference's own method bodies on stub objects (tools/oracle/gen_golden.py gen_pipeline_methods): prepare_latents (host RNG, tiled
+    clip noise), prepare_condition, next_step (DDIM inversion step), interpolate_latents with slerp / linear, select_controlnet_res_samples."""
+    import numpy as np
+    from safetensors.torch import load_file
+    from emote_hack_amd import DDIMScheduler
+    from emote_hack_amd import pipeline as P
+    from emote_hack_amd.synth import seeded_randn
+    g = load_file(os.path.join(cases.GOLDEN_DIR, "pipeline_methods.safetensors"))
+    sch = DDIMScheduler()
+    pipe = P.EMOAnimationPipeline(unet=type("U", (), {"device": torch.device("cpu")})(), scheduler=sch)
+    sch.set_timesteps(50)
+    x, eps = seeded_randn((4, 4, 16, 16), 500), seeded_randn((4, 4, 16, 16), 501)
+    for t in (1, 21, 481, 981):
+        xn, x0 = pipe.next_step(eps, t, x)
+        torch.testing.assert_close(xn, g[f"next_step/{t}/x_next"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(x0, g[f"next_step/{t}/pred_x0"], rtol=1e-5, atol=1e-5)
+    lat = pipe.prepare_latents(1, 4, 32, 64, 64, torch.float32, torch.device("cpu"), torch.Generator().manual_seed(5))
+    assert torch.equal(lat, g["prepare_latents/out"])                      # the same host RNG stream, tiled the same way
+    with pytest.raises(ValueError, match="Unexpected latents shape"):
+        pipe.prepare_latents(1, 4, 32, 64, 64, torch.float32, "cpu", None, latents=torch.zeros(1, 4, 32, 8, 8))
+    cond = pipe.prepare_condition(g["prepare_condition/in"].numpy(), 1, "cpu", torch.float32, True)
+    assert torch.equal(cond, g["prepare_condition/out"])
+    l3 = seeded_randn((1, 4, 3, 4, 4), 502)
+    assert pipe.interpolate_latents(l3, 1, "cpu") is l3                      # the factor __call__ hard-codes (:824)
+    for name, is_slerp in (("slerp", True), ("linear", False)):
+        P.set_tensor_interpolation_method(is_slerp)
+        torch.testing.assert_close(pipe.interpolate_latents(l3, 3, "cpu"), g[f"interpolate/{name}"], rtol=1e-6, atol=1e-6)
+    cache = {i: ([seeded_randn((1, 8, 4, 4), 600 + 10 * i + k) for k in range(3)], seeded_randn((1, 8, 2, 2), 700 + i)) for i in range(6)}
+    down, mid = pipe.select_controlnet_res_samples(cache, [[0, 1], [4, 5]], True, 4, 2)
+    assert all(torch.equal(d, g[f"select/down{k}"]) for k, d in enumerate(down)) and torch.equal(mid, g["select/mid"])

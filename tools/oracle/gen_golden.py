@@ -547,6 +547,80 @@ def gen_net_placeholders():
     print("net_placeholders", {k: tuple(v.shape) for k, v in T.items()}, J)
 
 
+# =============================================================================== EMOAnimationPipeline methods next to __call__
+def _pipeline_methods(names):
+    """AST-extract methods of the EMOAnimationPipeline class (the file does not import here) as plain functions taking `self`."""
+    import ast
+    import typing
+
+    import numpy as np
+    from einops import rearrange
+    util = ast.parse(open("/root/reference/magicanimate/utils/util.py").read())
+    ns = {"torch": torch, "np": np, "rearrange": rearrange, "tqdm": lambda it, **kw: it, "Optional": typing.Optional, "List": typing.List,
+          "Union": typing.Union, "Callable": typing.Callable}
+    keep = [n for n in util.body if (isinstance(n, ast.FunctionDef) and n.name in ("get_tensor_interpolation_method", "set_tensor_interpolation_method",
+                                                                                   "linear", "slerp"))
+            or (isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") == "tensor_interpolation")]
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "util.py", "exec"), ns)
+    tree = ast.parse(open("/root/reference/EMOAnimationPipeline.py").read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "EMOAnimationPipeline")
+    fns = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "EMOAnimationPipeline.py", "exec"), ns)
+    return ns
+
+
+def gen_pipeline_methods(u1):
+    """The methods of EMOAnimationPipeline around its __call__ (EMOAnimationPipeline.py:341-540), run as they stand on stub `self` objects:
+    prepare_latents, prepare_condition, next_step, invert (around the reference's own tiny UNet; tokenizer / text encoder / VAE stubbed by
+    tensors), interpolate_latents (+ magicanimate/utils/util.py slerp / linear), select_controlnet_res_samples."""
+    import numpy as np
+    from types import SimpleNamespace
+
+    from oracle.scheduler_ref import SchedulerRef
+    M = _pipeline_methods(["prepare_latents", "prepare_condition", "next_step", "invert", "interpolate_latents", "select_controlnet_res_samples"])
+    T = {}
+
+    def sched(n):
+        r = SchedulerRef("ddim")
+        r.set_timesteps(n)
+        return SimpleNamespace(config=SimpleNamespace(num_train_timesteps=1000), num_inference_steps=n, alphas_cumprod=r.alphas_cumprod,
+                               final_alpha_cumprod=r.final_alpha_cumprod, timesteps=list(r.timesteps), init_noise_sigma=1.0,
+                               set_timesteps=lambda k: None)
+    me = SimpleNamespace(scheduler=sched(50), vae_scale_factor=8)
+    x, eps = seeded_randn((4, 4, 16, 16), 500), seeded_randn((4, 4, 16, 16), 501)
+    for t in (1, 21, 481, 981):
+        xn, x0 = M["next_step"](me, eps, t, x)
+        T[f"next_step/{t}/x_next"], T[f"next_step/{t}/pred_x0"] = xn, x0
+    T["prepare_latents/out"] = M["prepare_latents"](me, 1, 4, 32, 64, 64, torch.float32, torch.device("cpu"), torch.Generator().manual_seed(5))
+    cond = np.random.RandomState(7).randint(0, 256, size=(3, 16, 24, 3)).astype(np.uint8)
+    T["prepare_condition/in"] = torch.from_numpy(cond.copy())
+    T["prepare_condition/out"] = M["prepare_condition"](me, cond, 1, "cpu", torch.float32, True)
+    lat = seeded_randn((1, 4, 3, 4, 4), 502)
+    for name, is_slerp in (("slerp", True), ("linear", False)):
+        M["set_tensor_interpolation_method"](is_slerp)
+        T[f"interpolate/{name}"] = M["interpolate_latents"](me, lat, 3, "cpu")
+    cache = {i: ([seeded_randn((1, 8, 4, 4), 600 + 10 * i + k) for k in range(3)], seeded_randn((1, 8, 2, 2), 700 + i)) for i in range(6)}
+    down, mid = M["select_controlnet_res_samples"](me, cache, [[0, 1], [4, 5]], True, 4, 2)
+    for k, d in enumerate(down):
+        T[f"select/down{k}"] = d
+    T["select/mid"] = mid
+    # invert (:417-477) around the reference's own tiny motion UNet: 5 inversion steps scheduled, 3 taken, 4 frames
+    text = seeded_randn((1, 5, 32), 503)
+    frames = seeded_randn((4, 4, 16, 16), 504)
+    inv = SimpleNamespace(scheduler=sched(5), unet=u1, _execution_device="cpu",
+                          tokenizer=lambda prompt, **kw: SimpleNamespace(input_ids=torch.zeros(1, 77, dtype=torch.long)),
+                          text_encoder=lambda ids: [text], images2latents=lambda image: image)
+    inv.next_step = lambda *a, **k: M["next_step"](inv, *a, **k)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        out, inter = M["invert"](inv, frames, "", num_inference_steps=5, num_actual_inference_steps=3, return_intermediates=True)
+    T["invert/latents"] = out
+    T["invert/step1"] = inter[1]
+    save_file({k: v.contiguous() for k, v in T.items()}, os.path.join(GOLD, "pipeline_methods.safetensors"))
+    print("pipeline_methods.safetensors", {k: tuple(v.shape) for k, v in T.items() if "/" in k and not k.startswith("next_step")})
+
+
 # =============================================================================== audio windows (SURVEY 8f rank 4)
 def gen_audio_windows():
     """Net.py:649-667: the per-frame windowing loop of Wav2VecFeatureExtractor.extract_features_from_wav, run on synthetic
@@ -622,6 +696,7 @@ if __name__ == "__main__":
     if "unet" in todo:
         u1, ref = gen_unet_tiny()
         gen_loop(u1, ref)
+        gen_pipeline_methods(u1)
     if "cond" in todo:
         gen_conditioning()
     if "controlnet" in todo:
