@@ -290,10 +290,16 @@ def cfg2_oracle(cfg2_models):
         order_r, order_u = U.transformer_block_order(cases.SD15), U.transformer_block_order(cases.SD15_MOTION)
         y_c = U.unet_forward(sd_u, cases.SD15_MOTION, x, t, ctx[1:], bank_mode="read", banks={pu: banks[pr] for pu, pr in zip(order_u, order_r)})
     print(f"oracle: uncond + ReferenceNet + cond forward at full size in {time.time() - t0:.0f} s")
-    return dict(x=x, ctx=ctx, ref_lat=ref_lat, t=t, y=torch.cat([y_uc, y_c], 0), banks=[banks[p] for p in order_r])
+    # BASELINE configs[2]: the same cond row with per-frame wav2vec audio tokens (12, 5, 768) as its attn2 context
+    audio = seeded_randn((12, 5, 768), 4)
+    with torch.no_grad():
+        y_a = U.unet_forward(sd_u, cases.SD15_MOTION, x, t, ctx[1:], bank_mode="read", banks={pu: banks[pr] for pu, pr in zip(order_u, order_r)},
+                             audio_features=audio)
+    print(f"oracle: + the audio-context cond forward, {time.time() - t0:.0f} s in all")
+    return dict(x=x, ctx=ctx, ref_lat=ref_lat, t=t, y=torch.cat([y_uc, y_c], 0), banks=[banks[p] for p in order_r], audio=audio, y_audio=y_a)
 
 
-def _hip_cfg2_forward(unet, ref, o):
+def _hip_cfg2_forward(unet, ref, o, audio=False):
     """The product's [uncond, cond] batch through the reference's own protocol: writer on [uncond, cond] copies of the reference
     image (EMOAnimationPipeline.py:711-716), reader.update(writer), one UNet call (EMOAnimationPipeline.py:759-790)."""
     from emote_hack_amd.reference_control import ReferenceAttentionControl
@@ -303,7 +309,10 @@ def _hip_cfg2_forward(unet, ref, o):
         ref(o["ref_lat"].repeat(2, 1, 1, 1).to(DEV), o["t"], encoder_hidden_states=o["ctx"].to(DEV), return_dict=False)
         banks = [writer.bank[p][0][1:].float().cpu() for p in writer.order]      # the cond copy's rows
         reader.update(writer)
-        y = unet(o["x"].repeat(2, 1, 1, 1, 1).to(DEV), o["t"], o["ctx"].to(DEV), _halves_identical=True).sample.float().cpu()
+        kw = {}
+        if audio:   # [uncond row: a zero context, cond row: the audio tokens] per frame - what the pipeline binds for configs[2]
+            kw["audio_features"] = torch.cat([torch.zeros_like(o["audio"]), o["audio"]]).to(DEV)
+        y = unet(o["x"].repeat(2, 1, 1, 1, 1).to(DEV), o["t"], o["ctx"].to(DEV), _halves_identical=True, **kw).sample.float().cpu()
         reader.clear()
         writer.clear()
     finally:
@@ -336,3 +345,15 @@ def test_cfg2_full_unet_bf16_vs_oracle(cfg2_models, cfg2_oracle):
     print(f"cfg2 full size bf16 vs oracle: max {float(e.max()):.3e} mean {float(e.mean()):.3e} (mean |ref| {float(ref_y.abs().mean()):.3f}, "
           f"max |ref| {float(ref_y.abs().max()):.3f})")
     check(y, ref_y, torch.bfloat16)
+
+
+def test_cfg3_full_unet_audio_context_f32_vs_oracle(cfg2_models_f32, cfg2_oracle):
+    """BASELINE configs[2] at the benchmarked size: the bank-reading cond row with per-frame audio tokens as the attn2 context (f32 mode,
+    rtol 1e-3 / atol 1e-4 against the oracle's forward with `audio_features`), and it differs from the text-context row."""
+    u32, r32 = cfg2_models_f32
+    y, _ = _hip_cfg2_forward(u32, r32, cfg2_oracle, audio=True)
+    ref = cfg2_oracle["y_audio"]
+    e = (y[1:] - ref).abs()
+    print(f"cfg3 full size f32 vs oracle (cond row, audio context): max {float(e.max()):.3e} mean {float(e.mean()):.3e}")
+    torch.testing.assert_close(y[1:], ref, rtol=1e-3, atol=1e-4)
+    assert float((ref - cfg2_oracle["y"][1:]).abs().mean()) > 1e-3
