@@ -176,10 +176,12 @@ def test_cfg4_48_frames_four_windows_full_size(cfg2_models):
     assert torch.equal(lat_48[:, :, 36:], lat_12)                          # the LAST window: the fourth UNet call of a step
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_level0_transformer_and_motion_block_at_bench_size_vs_oracle(dtype):
+@pytest.mark.parametrize("dtype,Fr,H,W", [(torch.float32, 12, 64, 64), (torch.bfloat16, 12, 64, 64),
+                                          (torch.float32, 24, 96, 96), (torch.float16, 24, 96, 96)])     # cfg2 / cfg3 geometry; cfg5: 768^2, 24 frames, fp16
+def test_level0_transformer_and_motion_block_at_bench_size_vs_oracle(dtype, Fr, H, W):
     """One level-0 Transformer3DModel block (attention.py:112-161,276-320) + its motion module (motion_module.py:139-334) at the size
-    bench.py runs them - 12 frames x 64 x 64 tokens x 320 channels, 8 heads of 40, 77 text keys - against the reference-pinned CPU
+    bench.py runs them - 12 frames x 64 x 64 tokens x 320 channels, 8 heads of 40, 77 text keys (BASELINE configs[1] / [2]), and
+    24 frames x 96 x 96 (configs[4]: 9216 keys per frame, the temporal kernel's two 16-frame blocks) - against the reference-pinned CPU
     oracle (oracle/unet_ref.py), not HIP-vs-HIP: f32 at north_star's rtol 1e-3 / atol 1e-4; bf16 (the run that takes the
     full-size-only plans: 256x256 ping-pong tiles, GroupNorm folded into per-frame proj_in slabs at HW >= 4096, LayerNorm-folded
     projections, the fused ff.net.2 + proj_out tail, the pipelined d = 40 attention) within the low-precision yard-stick."""
@@ -196,7 +198,6 @@ def test_level0_transformer_and_motion_block_at_bench_size_vs_oracle(dtype):
     m.to(DEV, dtype)
     a, mo = m.spec.down[0].attentions[0], m.spec.down[0].motions[0]
     assert a.channels == 320 and a.heads == 8 and mo is not None
-    Fr, H, W = 12, 64, 64
     x = seeded_randn((1, 320, Fr, H, W), 21)
     ctx = seeded_randn((1, 77, 768), 22)
     # ---- oracle, frame by frame for the spatial transformer (per-frame GroupNorm, per-frame attention: 2 x 8 x 4096^2 f32 scores a go)
